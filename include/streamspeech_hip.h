@@ -1,0 +1,134 @@
+/* streamspeech_hip.h -- C ABI of the MI355X-native StreamSpeech S2ST forward pass.
+ *
+ * Drop-in boundary: the reference has no FFI -- its S2ST path is torch modules
+ * called from the SimulEval agent -- so each entry point below replaces one module call the agent
+ * makes (reference agent/speech_to_speech.streamspeech.agent.py, cited per function).  Signatures
+ * carry only plain pointers and sizes: `d_*` arguments are DEVICE (HBM) pointers, `h_*` are host
+ * pointers, `stream` is a hipStream_t passed as void*.  Every call is stream-ordered unless it
+ * says "synchronises".  All arithmetic is FP32.  Return value: 0 = ok, non-zero = SS_ERR_*.
+ *
+ * Weight ownership: the caller owns one packed FP32 weight blob in HBM (built once from a fairseq
+ * state dict by streamspeech_amd/weights.py) and lends it to ss_model_create(); the library keeps
+ * borrowed pointers into it plus its own scratch / caches (hipMalloc).
+ */
+#ifndef STREAMSPEECH_HIP_H
+#define STREAMSPEECH_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SS_ABI_VERSION 1
+
+typedef struct ss_model ss_model;      /* StreamSpeechModel replacement (encoder + CTC + MT + T2U + unit decoder) */
+typedef struct ss_vocoder ss_vocoder;  /* CodeHiFiGANVocoderWithDur replacement */
+
+/* Architecture hyper-parameters (reference researches/ctc_unity/models/streamspeech_model.py:418-430
+ * and train_scripts/train.offline-s2st.sh). */
+typedef struct ss_config {
+  int32_t input_feat, conv_channels, conv_kernel;
+  int32_t enc_dim, enc_ffn, enc_heads, enc_layers, dw_kernel;
+  int32_t src_vocab, tgt_vocab;
+  int32_t mt_layers, dec_dim, dec_ffn, dec_heads;
+  int32_t t2u_layers, unit_layers, unit_vocab, ctc_upsample;
+  int32_t pad, eos, unk;
+  int32_t max_rel_pos;     /* Tmax: the projected rel-pos table covers offsets -(Tmax-1)..Tmax-1 */
+  int32_t max_tgt_pos;     /* rows in the MT sinusoid table */
+} ss_config;
+
+typedef struct ss_vocoder_config {
+  int32_t num_embeddings, embedding_dim, model_in_dim, upsample_initial_channel;
+  int32_t n_up;  int32_t upsample_rates[8];  int32_t upsample_kernel_sizes[8];
+  int32_t n_res; int32_t resblock_kernel_sizes[4]; int32_t resblock_dilations[4][3];
+  int32_t dur_hidden, dur_kernel;
+} ss_vocoder_config;
+
+int ss_abi_version(void);
+const char* ss_error_string(int code);
+
+/* ---- model lifetime ------------------------------------------------------------------------
+ * names[i] / offsets[i] / numels[i]: slot i of the packed blob starts offsets[i] floats into
+ * d_blob and holds numels[i] floats.  Replaces load_model_ensemble + model.cuda()
+ * (agent :355-420).  Synchronises (builds the per-layer projected rel-pos tables). */
+int ss_model_create(const ss_config* cfg, const float* d_blob, size_t blob_floats,
+                    const char* const* names, const int64_t* offsets, const int64_t* numels,
+                    int n_slots, ss_model** out);
+void ss_model_destroy(ss_model* m);
+
+/* ---- a1: OnlineFeatureExtractor.__call__ (agent :66-98) on 16 kHz PCM already in HBM.
+ * d_feat must hold ss_fbank_num_frames(n_samples)*80 floats. */
+int ss_fbank_num_frames(int n_samples);
+int ss_fbank_cmvn(ss_model* m, void* stream, const float* d_pcm16k, int n_samples, float pcm_scale,
+                  float* d_feat, int* h_n_frames);
+
+/* ---- a2-a7: model.encoder(src_tokens, src_lengths) for one utterance (agent :433-435 ->
+ * chunk_unity/models/s2t_conformer.py:111-163).  d_fbank [T,80] -> d_enc_out [T',256].
+ * attn_chunk = encoder.chunk_size, conv_chunk = ChunkCausalConv1d.chunk_size as the agent sets
+ * them (:395-413); values >= 999 mean "offline" (no chunking). */
+int ss_encoder_out_len(int T);
+int ss_encoder_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
+                       int conv_chunk, float* d_enc_out);
+
+/* ---- a8: CTCDecoder.generate (agent/ctc_decoder.py:39-111): head 0 = source_unigram (ASR),
+ * 1 = ctc_target_unigram (ST).  Outputs (device int32): raw argmax per frame [Tp], collapsed
+ * tokens / frame index [<=Tp], *d_count.  d_logits may be NULL (else [Tp,vocab] is written). */
+int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d_enc_out, int Tp,
+                  int32_t* d_raw, int32_t* d_tokens, int32_t* d_index, int32_t* d_count,
+                  float* d_logits);
+
+/* ---- a9-a10: first-pass MT decoder with KV cache (the reference re-runs it on the whole prefix
+ * every step, agent/sequence_generator.py:313-346; per-position results are identical).
+ * ss_mt_begin: bind encoder output, project cross-attention K/V for all layers, reset the cache.
+ * ss_mt_append: feed n tokens occupying positions pos0..pos0+n-1 (position 0 is the leading
+ *   </s>); writes features (post final LayerNorm, = mt_decoder(..., features_only=True)) for
+ *   those positions to d_feats [n,512] if non-NULL, and the greedy next token after the LAST fed
+ *   position to *d_next: argmax over the vocabulary with `pad` never selected, `eos` banned when
+ *   ban_eos, and forced to eos when force_eos (agent/sequence_generator.py:350-372 at beam 1). */
+int ss_mt_begin(ss_model* m, void* stream, const float* d_enc_out, int Tp);
+int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, int n, int pos0, int ban_eos,
+                 int force_eos, float* d_feats, int32_t* d_next);
+/* Truncate the self-attention cache to `len` positions (whole-word rollback, agent :540-574). */
+int ss_mt_truncate(ss_model* m, int len);
+
+/* ---- a11-a13: synthesizer_encoder + CTCTransformerUnitDecoder + CTC unit search
+ * (agent :661-717).  d_mt_feats [n,512] -> raw argmax [25n], collapsed unit-vocabulary tokens
+ * (blank 1004 / pad dropped) and *d_count; d_logits optional [25n,1005].  t2u_causal = the
+ * checkpoint's --uni-encoder flag; mask_eos = the offline generator's extra eos mask
+ * (researches/ctc_unity/ctc_generator.py:58). */
+int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, int n, int t2u_causal,
+                 int mask_eos, int32_t* d_raw, int32_t* d_tokens, int32_t* d_count, float* d_logits);
+
+/* ---- a14-a15: CodeHiFiGANVocoderWithDur.forward (agent/tts/vocoder.py:48-60). -------------- */
+int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_blob, size_t blob_floats,
+                      const char* const* names, const int64_t* offsets, const int64_t* numels,
+                      int n_slots, ss_vocoder** out);
+void ss_vocoder_destroy(ss_vocoder* v);
+/* d_codes [K] int32 unit ids (0..999).  dur_prediction != 0 runs the duration predictor, else every
+ * unit lasts one frame; d_forced_dur (may be NULL) overrides both.  d_wav must hold
+ * wav_capacity floats; *h_n_samples = 320 * sum(dur).  d_dur [K] int32.  Synchronises once
+ * (the frame count sizes the generator launches). */
+int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_codes, int K, int dur_prediction,
+                       const int32_t* d_forced_dur, float* d_wav, int64_t wav_capacity,
+                       int32_t* d_dur, int64_t* h_n_samples);
+
+/* ---- op-level entry points (unit tests of single kernels; same launchers the stages use) ---- */
+int ss_op_conv_gemm(void* stream, const float* dA, int lda, const float* dW, const float* dbias,
+                    const float* dR, int ldr, const float* dR2, int ldr2, float* dC, int ldc,
+                    int M, int N, int Cin, int taps, int dil, int stride, int pad, int in_len,
+                    int chunk, int in_act, float in_slope, int act, float alpha, float div, int glu);
+int ss_op_layernorm(void* stream, const float* dx, int ldx, float* dy, int ldy, const float* dg,
+                    const float* db, int M, int D, float eps);
+int ss_op_attention(void* stream, const float* dQ, int ldq, const float* dK, int ldk, const float* dV,
+                    int ldv, float* dO, int ldo, int Tq, int Tk, int H, float scale, int causal,
+                    int chunk, const float* dP, int ldp, const float* du, const float* dv);
+int ss_op_dwconv_bn_silu(void* stream, const float* dx, int ldx, float* dy, int ldy, const float* dwt,
+                         int K, const float* mean, const float* var, const float* gamma,
+                         const float* beta, float eps, int T, int C, int chunk);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STREAMSPEECH_HIP_H */

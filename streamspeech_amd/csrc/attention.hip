@@ -1,0 +1,162 @@
+// Attention, wavefront-softmax form (see attention.hpp).
+//
+// Workgroup = 4 wave64 = 16 query rows of one head; wave w owns rows 4w..4w+3.  Keys are walked
+// in tiles of 64 (lane = key).  K / V (and, for the rel-pos form, the 79 positional rows the
+// 16x64 (query,key) pairs of the tile can touch) are staged in LDS; the query rows live in
+// registers (lane d holds q[.,d]) and are broadcast with v_readlane, as are the probabilities
+// for P.V (lane = output dim).  Softmax is the online (running max / running sum) form with
+// wave-wide shuffles, so the [T,T] and [T,2T-1] score matrices the reference materialises
+// (espnet_multihead_attention.py:186-196) never exist.
+#include "attention.hpp"
+
+namespace ss {
+
+constexpr int QB = 16;     // query rows per workgroup
+constexpr int KT = 64;     // keys per tile
+constexpr int DH = 64;     // head dim
+constexpr int LDKS = DH + 1;
+
+__device__ __forceinline__ float rdlane(float v, int l) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <bool RELPOS>
+__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
+  __shared__ float Ks[KT * LDKS];
+  __shared__ float Vs[KT * DH];
+  __shared__ float Ps[RELPOS ? (KT + QB - 1) * LDKS : 1];
+
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int h = blockIdx.y;
+  const int i0 = blockIdx.x * QB;
+  const int hoff = h * DH;
+  const int qoff = p.Tk - p.Tq;
+
+  // query rows of this wave in registers: lane d holds element d
+  float qu[4], qv[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int i = i0 + wave * 4 + rr;
+    float q = (i < p.Tq) ? p.Q[(size_t)i * p.ldq + hoff + lane] : 0.f;
+    if (RELPOS) {
+      qu[rr] = q + p.bias_u[hoff + lane];
+      qv[rr] = q + p.bias_v[hoff + lane];
+    } else {
+      qu[rr] = q;
+      qv[rr] = 0.f;
+    }
+  }
+
+  float m_run[4], l_run[4], acc[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) { m_run[rr] = -INFINITY; l_run[rr] = 0.f; acc[rr] = 0.f; }
+
+  // last key any row of this block may see (block-uniform loop bound)
+  int kmax = p.Tk;
+  const int ilast = min(i0 + QB, p.Tq) - 1;
+  if (p.causal) kmax = min(kmax, ilast + qoff + 1);
+  if (p.chunk > 0) kmax = min(kmax, (ilast / p.chunk + 1) * p.chunk);
+
+  for (int j0 = 0; j0 < kmax; j0 += KT) {
+    __syncthreads();  // previous tile fully consumed
+    // stage K, V tiles: 64 rows x 16 float4
+    for (int f = t; f < KT * (DH / 4); f += 256) {
+      const int row = f >> 4, c4 = (f & 15) * 4;
+      const int j = j0 + row;
+      float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+      if (j < p.Tk) {
+        kv = *reinterpret_cast<const float4*>(p.K + (size_t)j * p.ldk + hoff + c4);
+        vv = *reinterpret_cast<const float4*>(p.V + (size_t)j * p.ldv + hoff + c4);
+      }
+      float* kd = Ks + row * LDKS + c4;
+      kd[0] = kv.x; kd[1] = kv.y; kd[2] = kv.z; kd[3] = kv.w;
+      *reinterpret_cast<float4*>(Vs + row * DH + c4) = vv;
+    }
+    if (RELPOS) {
+      // local row lr <-> table row pbase + lr, pbase = j0 - (i0 + QB - 1) + Tk - 1
+      const int pbase = j0 - (i0 + QB - 1) + p.Tk - 1;
+      for (int f = t; f < (KT + QB - 1) * (DH / 4); f += 256) {
+        const int row = f >> 4, c4 = (f & 15) * 4;
+        const int pr = pbase + row;
+        float4 pv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pr >= 0 && pr < 2 * p.Tk - 1)
+          pv = *reinterpret_cast<const float4*>(p.P + (size_t)pr * p.ldp + hoff + c4);
+        float* pd = Ps + row * LDKS + c4;
+        pd[0] = pv.x; pd[1] = pv.y; pd[2] = pv.z; pd[3] = pv.w;
+      }
+    }
+    __syncthreads();
+
+    // scores: lane = key
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* krow = Ks + lane * LDKS;
+#pragma unroll 16
+    for (int d = 0; d < DH; ++d) {
+      const float kd = krow[d];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) s[rr] = fmaf(rdlane(qu[rr], d), kd, s[rr]);
+    }
+    if (RELPOS) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        // table row for (i, j): j - i + Tk - 1  ->  local row lane + (QB-1) - (wave*4+rr)
+        const float* prow = Ps + (lane + (QB - 1) - (wave * 4 + rr)) * LDKS;
+        float b = 0.f;
+#pragma unroll 16
+        for (int d = 0; d < DH; ++d) b = fmaf(rdlane(qv[rr], d), prow[d], b);
+        s[rr] += b;
+      }
+    }
+
+    const int j = j0 + lane;
+    float pr[4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int i = i0 + wave * 4 + rr;
+      bool vis = (j < p.Tk) && (i < p.Tq);
+      if (p.causal) vis = vis && (j <= i + qoff);
+      if (p.chunk > 0) vis = vis && (j < (i / p.chunk + 1) * p.chunk);
+      const float sv = vis ? s[rr] * p.scale : -INFINITY;
+      const float mt = wave_max(sv);
+      const float mn = fmaxf(m_run[rr], mt);
+      float pe = 0.f, corr = 1.f;
+      if (mn > -INFINITY) {
+        pe = vis ? expf(sv - mn) : 0.f;
+        corr = (m_run[rr] > -INFINITY) ? expf(m_run[rr] - mn) : 0.f;
+      }
+      l_run[rr] = l_run[rr] * corr + wave_sum(pe);
+      acc[rr] *= corr;
+      m_run[rr] = mn;
+      pr[rr] = pe;
+    }
+    // P.V : lane = output dim
+#pragma unroll 16
+    for (int jj = 0; jj < KT; ++jj) {
+      const float vd = Vs[jj * DH + lane];
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[rr] = fmaf(rdlane(pr[rr], jj), vd, acc[rr]);
+    }
+  }
+
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int i = i0 + wave * 4 + rr;
+    if (i < p.Tq) p.O[(size_t)i * p.ldo + hoff + lane] = acc[rr] / l_run[rr];
+  }
+}
+
+int launch_attention(const AttnArgs& a, hipStream_t stream) {
+  if (a.Tq <= 0 || a.Tk <= 0) return SS_OK;
+  if ((a.ldk & 3) || (a.ldv & 3)) return SS_ERR_ARG;
+  dim3 grid(cdiv(a.Tq, QB), a.H);
+  if (a.P) {
+    if (a.Tq != a.Tk || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
+    hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, stream, a);
+  } else {
+    hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, stream, a);
+  }
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+}  // namespace ss

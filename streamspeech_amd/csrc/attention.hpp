@@ -1,0 +1,28 @@
+// Multi-head attention kernels (head_dim = 64) for the S2ST path.
+//  * rel-pos (Transformer-XL style) chunk-masked self-attention of the Conformer encoder:
+//    reference researches/uni_unity/modules/espnet_multihead_attention.py:154-209,
+//    score[i,j] = ((q_i+u).k_j + (q_i+v).p[j-i+T-1]) / sqrt(64), key j hidden iff j >= (i/c+1)*c
+//    (chunk_unity/models/s2t_conformer.py:195-213).
+//  * fairseq MHA (MT decoder, T2U encoder, unit decoder): reference
+//    researches/ctc_unity/modules/multihead_attention.py:544-760, q pre-scaled by d_h^-0.5,
+//    optional causal triu(-inf, 1) mask, softmax in fp32.
+#pragma once
+#include "common.hpp"
+
+namespace ss {
+
+struct AttnArgs {
+  const float* Q = nullptr; const float* K = nullptr; const float* V = nullptr; float* O = nullptr;
+  int ldq = 0, ldk = 0, ldv = 0, ldo = 0;  // row strides in floats; head h occupies cols [64h, 64h+64)
+  int Tq = 0, Tk = 0, H = 0;
+  float scale = 1.0f;        // scores *= scale
+  int causal = 0;            // key j visible iff j <= i + (Tk - Tq)
+  int chunk = 0;             // > 0: key j visible iff j < (i/chunk + 1)*chunk
+  // rel-pos extras (null => plain attention); requires Tq == Tk
+  const float* P = nullptr; int ldp = 0;   // projected positional table [2*Tk-1, H*64]
+  const float* bias_u = nullptr; const float* bias_v = nullptr;  // [H*64]
+};
+
+int launch_attention(const AttnArgs& a, hipStream_t stream);
+
+}  // namespace ss

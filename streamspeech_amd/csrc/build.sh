@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build libstreamspeech_hip.so for gfx950 (in-tree; the .so travels to the GPU box with the snapshot).
+set -e
+cd "$(dirname "$0")"
+HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result"
+mkdir -p build
+for f in gemm attention elementwise fbank model; do
+  if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer build/$f.o)" ] \
+     || [ ../../include/streamspeech_hip.h -nt build/$f.o ]; then
+    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+  fi
+done
+wait
+$HIPCC --offload-arch=gfx950 -shared -fPIC build/gemm.o build/attention.o build/elementwise.o build/fbank.o build/model.o \
+  -o ../libstreamspeech_hip.so
+echo "built $(realpath ../libstreamspeech_hip.so)"

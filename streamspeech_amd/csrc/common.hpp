@@ -1,0 +1,48 @@
+// Shared definitions for the StreamSpeech gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#define SS_OK 0
+#define SS_ERR_HIP 1
+#define SS_ERR_ARG 2
+#define SS_ERR_MISSING_WEIGHT 3
+#define SS_ERR_CAPACITY 4
+
+#define SS_HIP_CHECK(expr)                                                              \
+  do {                                                                                  \
+    hipError_t _e = (expr);                                                             \
+    if (_e != hipSuccess) {                                                             \
+      fprintf(stderr, "[streamspeech_hip] %s failed: %s (%s:%d)\n", #expr,              \
+              hipGetErrorString(_e), __FILE__, __LINE__);                               \
+      return SS_ERR_HIP;                                                                \
+    }                                                                                   \
+  } while (0)
+
+#define SS_LAUNCH_CHECK() SS_HIP_CHECK(hipGetLastError())
+
+namespace ss {
+
+constexpr int WAVE = 64;
+
+// activation codes shared by kernels and the C ABI
+enum Act : int { ACT_NONE = 0, ACT_SILU = 1, ACT_RELU = 2, ACT_LRELU = 3, ACT_TANH = 4 };
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+}  // namespace ss

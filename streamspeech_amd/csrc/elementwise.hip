@@ -1,0 +1,312 @@
+// Row-wise / pointwise kernels (see elementwise.hpp for the reference citations).
+#include "elementwise.hpp"
+
+namespace ss {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave64 per row, values kept in registers (D/64 per lane), two-pass statistics.
+// ---------------------------------------------------------------------------------------------
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int ldx, float* y,
+                                                        int ldy, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int M, float eps) {
+  constexpr int D = PER_LANE * 64;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * ldx;
+  float v[PER_LANE];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) { v[i] = xr[lane + 64 * i]; s += v[i]; }
+  const float mean = wave_sum(s) / (float)D;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) { const float d = v[i] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+  float* yr = y + (size_t)row * ldy;
+#pragma unroll
+  for (int i = 0; i < PER_LANE; ++i) {
+    const int c = lane + 64 * i;
+    yr[c] = (v[i] - mean) * rstd * gamma[c] + beta[c];
+  }
+}
+
+int launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* gamma, const float* beta,
+                     int M, int D, float eps, hipStream_t stream) {
+  if (M <= 0) return SS_OK;
+  dim3 grid(cdiv(M, 4)), block(256);
+  switch (D) {
+    case 64: hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, stream, x, ldx, y, ldy, gamma, beta, M, eps); break;
+    case 128: hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, ldx, y, ldy, gamma, beta, M, eps); break;
+    case 256: hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, stream, x, ldx, y, ldy, gamma, beta, M, eps); break;
+    case 512: hipLaunchKernelGGL(layernorm_kernel<8>, grid, block, 0, stream, x, ldx, y, ldy, gamma, beta, M, eps); break;
+    case 1024: hipLaunchKernelGGL(layernorm_kernel<16>, grid, block, 0, stream, x, ldx, y, ldy, gamma, beta, M, eps); break;
+    default: return SS_ERR_ARG;
+  }
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Chunk-causal depthwise conv + BatchNorm(eval) + SiLU.  Thread = (t, c); lanes run along c so
+// every tap is one coalesced row read (the [T,C] tile stays in L1/L2: T'*C*4 = 128 KB at 5 s).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
+    const float* __restrict__ x, int ldx, float* y, int ldy, const float* __restrict__ wt, int K,
+    const float* __restrict__ bn_mean, const float* __restrict__ bn_var, const float* __restrict__ bn_gamma,
+    const float* __restrict__ bn_beta, float bn_eps, int T, int C, int chunk) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int t = blockIdx.y;
+  if (c >= C) return;
+  const int half = K / 2;
+  int lo = t - half, hi = t + half;            // inclusive tap window in input positions
+  if (lo < 0) lo = 0;
+  int lim = T;
+  if (chunk > 0) { const int cl = (t / chunk + 1) * chunk; if (cl < lim) lim = cl; }
+  if (hi > lim - 1) hi = lim - 1;
+  float acc = 0.f;
+  for (int pos = lo; pos <= hi; ++pos) acc = fmaf(wt[(pos - t + half) * C + c], x[(size_t)pos * ldx + c], acc);
+  float v = (acc - bn_mean[c]) / sqrtf(bn_var[c] + bn_eps) * bn_gamma[c] + bn_beta[c];
+  y[(size_t)t * ldy + c] = v / (1.0f + expf(-v));
+}
+
+int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const float* wt, int K,
+                          const float* bn_mean, const float* bn_var, const float* bn_gamma,
+                          const float* bn_beta, float bn_eps, int T, int C, int chunk, hipStream_t stream) {
+  if (T <= 0) return SS_OK;
+  dim3 grid(cdiv(C, 256), T);
+  hipLaunchKernelGGL(dwconv_bn_silu_kernel, grid, dim3(256), 0, stream, x, ldx, y, ldy, wt, K, bn_mean,
+                     bn_var, bn_gamma, bn_beta, bn_eps, T, C, chunk);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Embeddings
+// ---------------------------------------------------------------------------------------------
+__global__ void embed_tokens_kernel(const int* __restrict__ tok, const float* __restrict__ emb,
+                                    const float* __restrict__ pos_table, float scale, int pos0, float* out,
+                                    int n, int D) {
+  const int i = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  out[(size_t)i * D + c] = scale * emb[(size_t)tok[i] * D + c] + pos_table[(size_t)(pos0 + i) * D + c];
+}
+
+int launch_embed_tokens(const int* tok, const float* emb, const float* pos_table, float scale, int pos0,
+                        float* out, int n, int D, hipStream_t stream) {
+  if (n <= 0) return SS_OK;
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, stream, tok, emb, pos_table,
+                     scale, pos0, out, n, D);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+__global__ void upsample_add_pos_kernel(const float* __restrict__ src, int up, const float* __restrict__ pos_row,
+                                        float pad_value, float* out, int D) {
+  const int u = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  const float* s = src + (size_t)(u / up) * D;
+  const float add = (s[0] != pad_value) ? pos_row[c] : 0.f;
+  out[(size_t)u * D + c] = s[c] + add;
+}
+
+int launch_upsample_add_pos(const float* src, int n, int up, const float* pos_row, float pad_value,
+                            float* out, int D, hipStream_t stream) {
+  if (n <= 0) return SS_OK;
+  hipLaunchKernelGGL(upsample_add_pos_kernel, dim3(cdiv(D, 256), n * up), dim3(256), 0, stream, src, up,
+                     pos_row, pad_value, out, D);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+__global__ void gather_rows_kernel(const int* __restrict__ idx, const float* __restrict__ table, int D,
+                                   float* out) {
+  const int i = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= D) return;
+  out[(size_t)i * D + c] = table[(size_t)idx[i] * D + c];
+}
+
+int launch_gather_rows(const int* idx, const float* table, int D, float* out, int n, hipStream_t stream) {
+  if (n <= 0) return SS_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, stream, idx, table, D, out);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Masked argmax over a row (CTC heads, unit head, MT next-token).  log_softmax is monotone, so the
+// reference's log_softmax -> set -inf -> max (agent/ctc_decoder.py:52-60) equals an argmax of the
+// logits with those indices skipped; ties resolve to the lowest index like torch.max / topk.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void masked_argmax_kernel(const float* __restrict__ logits, int ld, int M, int N,
+                                                            int mask0, int mask1, int mask2, int force, int* ids) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  if (force >= 0) { if (lane == 0) ids[row] = force; return; }
+  const float* r = logits + (size_t)row * ld;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int n = lane; n < N; n += 64) {
+    if (n == mask0 || n == mask1 || n == mask2) continue;
+    const float v = r[n];
+    if (v != v) continue;  // NaN -> -inf (agent/sequence_generator.py:350)
+    if (bi == 0x7fffffff || v > best) { best = v; bi = n; }  // n ascends per lane: first max wins
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+  }
+  if (lane == 0) ids[row] = bi;
+}
+
+int launch_masked_argmax(const float* logits, int ld, int M, int N, int mask0, int mask1, int mask2,
+                         int force, int* ids, hipStream_t stream) {
+  if (M <= 0) return SS_OK;
+  hipLaunchKernelGGL(masked_argmax_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, logits, ld, M, N, mask0,
+                     mask1, mask2, force, ids);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CTC collapse: single workgroup, chunks of 1024 frames with a running output offset.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int* __restrict__ raw, int T, int blank, int pad,
+                                                            int* tokens, int* index, int* count) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) base_s = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < T; c0 += 1024) {
+    const int i = c0 + t;
+    int v = 0;
+    bool keep = false;
+    if (i < T) {
+      v = raw[i];
+      keep = (i == 0 || v != raw[i - 1]) && v != blank && v != pad;
+    }
+    const unsigned long long bal = __ballot(keep);
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (keep) { tokens[off + pre] = v; index[off + pre] = i; }
+    __syncthreads();
+    if (t == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wave_tot[w]; base_s += s; }
+    __syncthreads();
+  }
+  if (t == 0) *count = base_s;
+}
+
+int launch_ctc_collapse(const int* raw, int T, int blank, int pad, int* tokens, int* index, int* count,
+                        hipStream_t stream) {
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(1), dim3(1024), 0, stream, raw, T, blank, pad, tokens, index, count);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Duration predictor tail + repeat_interleave
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void dur_predict_kernel(const float* __restrict__ logdur,
+                                                           const int* __restrict__ forced, int K, int* dur, int* cum) {
+  __shared__ int wave_tot[16];
+  __shared__ int base_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (t == 0) { base_s = 0; cum[0] = 0; }
+  __syncthreads();
+  for (int c0 = 0; c0 < K; c0 += 1024) {
+    const int k = c0 + t;
+    int d = 0;
+    if (k < K) {
+      if (forced) d = forced[k];
+      else {
+        // torch.round is round-half-to-even == rintf in the default rounding mode
+        const float r = rintf(expf(logdur[k]) - 1.0f);
+        d = (int)fmaxf(r, 1.0f);
+      }
+      dur[k] = d;
+    }
+    int incl = d;  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int n = __shfl_up(incl, o, 64); if (lane >= o) incl += n; }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = base_s;
+    for (int w = 0; w < wave; ++w) off += wave_tot[w];
+    if (k < K) cum[k + 1] = off + incl;
+    __syncthreads();
+    if (t == 0) { int s = 0; for (int w = 0; w < 16; ++w) s += wave_tot[w]; base_s += s; }
+    __syncthreads();
+  }
+}
+
+int launch_dur_predict(const float* logdur, const int* forced, int K, int* dur, int* cum, hipStream_t stream) {
+  if (K <= 0) return SS_ERR_ARG;
+  hipLaunchKernelGGL(dur_predict_kernel, dim3(1), dim3(1024), 0, stream, logdur, forced, K, dur, cum);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+__global__ void repeat_rows_kernel(const float* __restrict__ emb, const int* __restrict__ cum, int K, int D,
+                                   float* out) {
+  const int f = blockIdx.y;
+  // largest k with cum[k] <= f
+  int lo = 0, hi = K - 1;
+  while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cum[mid] <= f) lo = mid; else hi = mid - 1; }
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < D) out[(size_t)f * D + c] = emb[(size_t)lo * D + c];
+}
+
+int launch_repeat_rows(const float* emb, const int* cum, int K, int D, float* out, int F, hipStream_t stream) {
+  if (F <= 0) return SS_OK;
+  hipLaunchKernelGGL(repeat_rows_kernel, dim3(cdiv(D, 256), F), dim3(256), 0, stream, emb, cum, K, D, out);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HiFi-GAN conv_post (C -> 1, k = 7) + tanh.  HBM/L2-bound: thread = output sample, reads a
+// contiguous 7*C window of the channels-last input.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __restrict__ x, int T, int C,
+                                                             const float* __restrict__ w, const float* __restrict__ bias,
+                                                             float slope, float* wav) {
+  extern __shared__ float ws[];  // 7*C weights
+  for (int i = threadIdx.x; i < 7 * C; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  float acc = 0.f;
+  for (int j = 0; j < 7; ++j) {
+    const int pos = t + j - 3;
+    if (pos < 0 || pos >= T) continue;
+    const float* xr = x + (size_t)pos * C;
+    for (int c = 0; c < C; ++c) {
+      float v = xr[c];
+      v = v > 0.f ? v : v * slope;
+      acc = fmaf(ws[j * C + c], v, acc);
+    }
+  }
+  wav[t] = tanhf(acc + bias[0]);
+}
+
+int launch_conv_post_tanh(const float* x, int T, int C, const float* w, const float* bias, float slope,
+                          float* wav, hipStream_t stream) {
+  if (T <= 0) return SS_OK;
+  hipLaunchKernelGGL(conv_post_tanh_kernel, dim3(cdiv(T, 256)), dim3(256), 7 * C * sizeof(float), stream, x, T,
+                     C, w, bias, slope, wav);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+}  // namespace ss

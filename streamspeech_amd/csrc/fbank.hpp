@@ -1,0 +1,15 @@
+// Fused fbank + CMVN front-end kernel (see fbank.hip).
+#pragma once
+#include "common.hpp"
+
+namespace ss {
+
+// pcm: mono 16 kHz float samples on the device; each sample is multiplied by pcm_scale (2^15 for
+// [-1,1] input, reference fairseq/examples/speech_to_text/data_utils.py:85).  window [400] and
+// melw [80][257] are host-built constants living in the weight blob.  Writes feat [T,80] and
+// returns T = 1 + (n-400)/160 (snip_edges) through n_frames (host int).
+int launch_fbank_cmvn(const float* pcm, int n_samples, float pcm_scale, const float* window,
+                      const float* melw, const float* cmvn_mean, const float* cmvn_std, float* feat,
+                      int* n_frames, hipStream_t stream);
+
+}  // namespace ss

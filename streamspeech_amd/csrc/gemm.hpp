@@ -1,0 +1,43 @@
+// Implicit-GEMM Conv1d / Linear on the f32 matrix cores (v_mfma_f32_16x16x4_f32).
+//
+// One kernel family serves every dense contraction on the S2ST path (SURVEY.md §8a rows
+// a2,a4,a5,a6,a8,a9,a11,a12,a14,a15): activations are time-major channels-last [rows, C];
+//   out[m, n] = epi( sum_{j<taps} sum_{c<Cin} act_in(A[m*stride + j*dil - pad, c]) * W[n, j*Cin + c] )
+// Linear layers are taps=1.  Conv1d weights are re-laid out tap-major [Cout][k][Cin] at pack
+// time; ConvTranspose1d is packed as a 3-tap polyphase conv with N = stride*Cout
+// (streamspeech_amd/weights.py).  Rows outside [0, in_len) read as zero ("same" padding); with
+// chunk > 0 rows at or beyond ((m*stride)/chunk + 1)*chunk also read as zero, which is the
+// closed form of the reference ChunkCausalConv1d (chunk_unity/modules/chunk_causal_conv1d.py:39-68).
+#pragma once
+#include "common.hpp"
+
+namespace ss {
+
+struct GemmArgs {
+  const float* A = nullptr;   // input rows, row stride lda
+  const float* W = nullptr;   // [N][taps*Cin]
+  const float* bias = nullptr;  // [N] or null
+  const float* R = nullptr;   // residual [M][ldr] or null
+  const float* R2 = nullptr;  // second residual (MRF accumulate) or null
+  float* C = nullptr;         // [M][ldc]
+  int lda = 0, ldc = 0, ldr = 0, ldr2 = 0;
+  int M = 0, N = 0, Cin = 0;
+  int taps = 1, dil = 1, stride = 1, pad = 0;
+  int in_len = 0;             // valid input rows
+  int chunk = 0;              // chunk-causal visibility (0 = off)
+  int in_act = ACT_NONE;      // ACT_NONE or ACT_LRELU applied to A while staging
+  float in_slope = 0.1f;
+  int act = ACT_NONE;         // epilogue activation on (acc + bias)
+  float alpha = 1.0f;         // v *= alpha (after activation)
+  float div = 0.0f;           // if > 0: v /= div at the very end (MRF mean)
+  int glu = 0;                // 1: W rows are interleaved [16 value | 16 gate] blocks, out has N/2 cols
+  // ragged batch: nseg > 0 -> segs[4*s] = {out_start, out_len, in_start, in_len}; M/in_len ignored
+  const int* segs = nullptr;
+  int nseg = 0;
+  int max_seg_out = 0;        // max out_len over segments (grid sizing)
+};
+
+// Launches on `stream`; returns SS_OK / SS_ERR_*.
+int launch_conv_gemm(const GemmArgs& a, hipStream_t stream);
+
+}  // namespace ss

@@ -1,0 +1,661 @@
+// Stage orchestration + C ABI for the StreamSpeech S2ST path (include/streamspeech_hip.h).
+// Host code only queues kernels on the caller's stream; the only device->host syncs are the
+// frame count in the vocoder and whatever the caller does with the returned ids.
+#include <algorithm>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/streamspeech_hip.h"
+#include "attention.hpp"
+#include "common.hpp"
+#include "elementwise.hpp"
+#include "fbank.hpp"
+#include "gemm.hpp"
+
+using namespace ss;
+
+namespace {
+
+struct Slot { const float* p = nullptr; int64_t n = 0; };
+
+struct WeightTable {
+  std::unordered_map<std::string, Slot> map;
+  std::string missing;
+  int build(const float* blob, size_t blob_floats, const char* const* names, const int64_t* offs,
+            const int64_t* numels, int n) {
+    for (int i = 0; i < n; ++i) {
+      if (offs[i] < 0 || (size_t)(offs[i] + numels[i]) > blob_floats) return SS_ERR_ARG;
+      map[names[i]] = Slot{blob + offs[i], numels[i]};
+    }
+    return SS_OK;
+  }
+  const float* get(const std::string& name, int64_t expect) {
+    auto it = map.find(name);
+    if (it == map.end() || (expect > 0 && it->second.n != expect)) {
+      if (missing.empty()) {
+        missing = name;
+        fprintf(stderr, "[streamspeech_hip] weight slot '%s' missing or wrong size (want %lld, have %lld)\n",
+                name.c_str(), (long long)expect, it == map.end() ? -1LL : (long long)it->second.n);
+      }
+      return nullptr;
+    }
+    return it->second.p;
+  }
+};
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+  int ensure(size_t need) {
+    if (need <= bytes) return SS_OK;
+    if (p) { SS_HIP_CHECK(hipDeviceSynchronize()); SS_HIP_CHECK(hipFree(p)); p = nullptr; bytes = 0; }
+    size_t cap = need + need / 4 + 4096;
+    SS_HIP_CHECK(hipMalloc(&p, cap));
+    bytes = cap;
+    return SS_OK;
+  }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  float* f() const { return reinterpret_cast<float*>(p); }
+};
+
+struct Lin { const float* w = nullptr; const float* b = nullptr; };
+struct LN { const float* g = nullptr; const float* b = nullptr; };
+
+#define RET(x) do { int _r = (x); if (_r != SS_OK) return _r; } while (0)
+
+int linear(hipStream_t s, const float* A, int lda, int M, const Lin& l, int N, int K, float* C, int ldc,
+           int act = ACT_NONE, float alpha = 1.f, const float* R = nullptr, int ldr = 0, int glu = 0) {
+  GemmArgs a;
+  a.A = A; a.lda = lda; a.W = l.w; a.bias = l.b; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldr;
+  a.M = M; a.N = N; a.Cin = K; a.in_len = M; a.act = act; a.alpha = alpha; a.glu = glu;
+  return launch_conv_gemm(a, s);
+}
+
+int layernorm(hipStream_t s, const float* x, float* y, const LN& ln, int M, int D) {
+  return launch_layernorm(x, D, y, D, ln.g, ln.b, M, D, 1e-5f, s);
+}
+
+}  // namespace
+
+// =================================================================================================
+// model
+// =================================================================================================
+struct EncLayer {
+  LN ffn1_ln, attn_ln, conv_ln, ffn2_ln, final_ln;
+  Lin ffn1_w1, ffn1_w2, ffn2_w1, ffn2_w2, qkv, out, pw1, pw2;
+  const float *u, *v, *dw_wt, *bn_mean, *bn_var, *bn_g, *bn_b;
+};
+struct DecLayer {
+  LN self_ln, cross_ln, ffn_ln;
+  Lin self_qkv, self_out, cross_q, cross_kv, cross_out, fc1, fc2;
+  bool has_cross = false;
+};
+
+struct ss_model {
+  ss_config cfg;
+  WeightTable wt;
+  // encoder
+  Lin sub0, sub1, enc_linear, ctc_asr, ctc_st;
+  std::vector<EncLayer> enc;
+  const float* pos_table = nullptr;  // [2*Tmax-1, d]
+  const float* pos_w = nullptr;      // [L*d, d]
+  DevBuf pos_proj;                   // [2*Tmax-1, L*d]
+  // front-end
+  const float *fe_window = nullptr, *fe_melw = nullptr, *fe_mean = nullptr, *fe_std = nullptr;
+  // decoders
+  const float* mt_emb = nullptr; const float* mt_pos = nullptr; LN mt_ln;
+  std::vector<DecLayer> mt, t2u, unit;
+  LN t2u_ln, unit_ln;
+  Lin unit_out;
+  const float* unit_pos_row = nullptr;
+  // scratch
+  DevBuf ws;            // encoder / t2u / unit scratch
+  DevBuf mt_cross;      // [mt_layers][Tp][2*D]
+  DevBuf mt_self;       // [mt_layers][max_tgt_pos][3*D]
+  DevBuf mt_ws;         // per-append scratch
+  int mt_Tp = 0;
+  int mt_len = 0;
+  const float* mt_enc = nullptr;
+};
+
+static int load_dec_layers(ss_model* m, std::vector<DecLayer>& v, const std::string& pfx, int n, int D, int F,
+                           int kv_in, bool cross) {
+  WeightTable& w = m->wt;
+  v.resize(n);
+  for (int l = 0; l < n; ++l) {
+    const std::string p = pfx + ".L" + std::to_string(l) + ".";
+    DecLayer& d = v[l];
+    d.has_cross = cross;
+    d.self_ln = {w.get(p + "self.ln.g", D), w.get(p + "self.ln.b", D)};
+    d.self_qkv = {w.get(p + "self.qkv.w", 3LL * D * D), w.get(p + "self.qkv.b", 3LL * D)};
+    d.self_out = {w.get(p + "self.out.w", (int64_t)D * D), w.get(p + "self.out.b", D)};
+    if (cross) {
+      d.cross_ln = {w.get(p + "cross.ln.g", D), w.get(p + "cross.ln.b", D)};
+      d.cross_q = {w.get(p + "cross.q.w", (int64_t)D * D), w.get(p + "cross.q.b", D)};
+      d.cross_kv = {w.get(p + "cross.kv.w", 2LL * D * kv_in), w.get(p + "cross.kv.b", 2LL * D)};
+      d.cross_out = {w.get(p + "cross.out.w", (int64_t)D * D), w.get(p + "cross.out.b", D)};
+    }
+    d.ffn_ln = {w.get(p + "ffn.ln.g", D), w.get(p + "ffn.ln.b", D)};
+    d.fc1 = {w.get(p + "fc1.w", (int64_t)F * D), w.get(p + "fc1.b", F)};
+    d.fc2 = {w.get(p + "fc2.w", (int64_t)D * F), w.get(p + "fc2.b", D)};
+  }
+  return SS_OK;
+}
+
+extern "C" int ss_abi_version(void) { return SS_ABI_VERSION; }
+
+extern "C" const char* ss_error_string(int code) {
+  switch (code) {
+    case SS_OK: return "ok";
+    case SS_ERR_HIP: return "HIP runtime error";
+    case SS_ERR_ARG: return "invalid argument";
+    case SS_ERR_MISSING_WEIGHT: return "weight slot missing or wrong size";
+    case SS_ERR_CAPACITY: return "output capacity too small";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t blob_floats,
+                               const char* const* names, const int64_t* offsets, const int64_t* numels,
+                               int n_slots, ss_model** out) {
+  if (!cfg || !d_blob || !out) return SS_ERR_ARG;
+  if (cfg->enc_dim / cfg->enc_heads != 64 || cfg->dec_dim / cfg->dec_heads != 64) return SS_ERR_ARG;
+  ss_model* m = new ss_model();
+  m->cfg = *cfg;
+  int rc = m->wt.build(d_blob, blob_floats, names, offsets, numels, n_slots);
+  if (rc != SS_OK) { delete m; return rc; }
+  WeightTable& w = m->wt;
+  const int d = cfg->enc_dim, f = cfg->enc_ffn, D = cfg->dec_dim, F = cfg->dec_ffn, k = cfg->conv_kernel;
+  const int Tm = cfg->max_rel_pos;
+  m->sub0 = {w.get("enc.sub0.w", (int64_t)cfg->conv_channels * k * cfg->input_feat), w.get("enc.sub0.b", cfg->conv_channels)};
+  m->sub1 = {w.get("enc.sub1.w", (int64_t)2 * d * k * (cfg->conv_channels / 2)), w.get("enc.sub1.b", 2 * d)};
+  m->enc_linear = {w.get("enc.linear.w", (int64_t)d * d), w.get("enc.linear.b", d)};
+  m->pos_table = w.get("enc.pos_table", (int64_t)(2 * Tm - 1) * d);
+  m->pos_w = w.get("enc.pos_w", (int64_t)cfg->enc_layers * d * d);
+  m->enc.resize(cfg->enc_layers);
+  for (int l = 0; l < cfg->enc_layers; ++l) {
+    const std::string p = "enc.L" + std::to_string(l) + ".";
+    EncLayer& e = m->enc[l];
+    e.ffn1_ln = {w.get(p + "ffn1.ln.g", d), w.get(p + "ffn1.ln.b", d)};
+    e.ffn1_w1 = {w.get(p + "ffn1.w1.w", (int64_t)f * d), w.get(p + "ffn1.w1.b", f)};
+    e.ffn1_w2 = {w.get(p + "ffn1.w2.w", (int64_t)d * f), w.get(p + "ffn1.w2.b", d)};
+    e.attn_ln = {w.get(p + "attn.ln.g", d), w.get(p + "attn.ln.b", d)};
+    e.qkv = {w.get(p + "attn.qkv.w", 3LL * d * d), w.get(p + "attn.qkv.b", 3LL * d)};
+    e.out = {w.get(p + "attn.out.w", (int64_t)d * d), w.get(p + "attn.out.b", d)};
+    e.u = w.get(p + "attn.u", d);
+    e.v = w.get(p + "attn.v", d);
+    e.conv_ln = {w.get(p + "conv.ln.g", d), w.get(p + "conv.ln.b", d)};
+    e.pw1 = {w.get(p + "conv.pw1.w", 2LL * d * d), nullptr};
+    e.dw_wt = w.get(p + "conv.dw.wt", (int64_t)cfg->dw_kernel * d);
+    e.bn_mean = w.get(p + "conv.bn.mean", d);
+    e.bn_var = w.get(p + "conv.bn.var", d);
+    e.bn_g = w.get(p + "conv.bn.g", d);
+    e.bn_b = w.get(p + "conv.bn.b", d);
+    e.pw2 = {w.get(p + "conv.pw2.w", (int64_t)d * d), nullptr};
+    e.ffn2_ln = {w.get(p + "ffn2.ln.g", d), w.get(p + "ffn2.ln.b", d)};
+    e.ffn2_w1 = {w.get(p + "ffn2.w1.w", (int64_t)f * d), w.get(p + "ffn2.w1.b", f)};
+    e.ffn2_w2 = {w.get(p + "ffn2.w2.w", (int64_t)d * f), w.get(p + "ffn2.w2.b", d)};
+    e.final_ln = {w.get(p + "final_ln.g", d), w.get(p + "final_ln.b", d)};
+  }
+  m->ctc_asr = {w.get("ctc.asr.w", (int64_t)cfg->src_vocab * d), w.get("ctc.asr.b", cfg->src_vocab)};
+  m->ctc_st = {w.get("ctc.st.w", (int64_t)cfg->tgt_vocab * d), w.get("ctc.st.b", cfg->tgt_vocab)};
+  m->fe_window = w.get("fe.window", 400);
+  m->fe_melw = w.get("fe.melw", 80 * 257);
+  m->fe_mean = w.get("fe.cmvn_mean", 80);
+  m->fe_std = w.get("fe.cmvn_std", 80);
+  m->mt_emb = w.get("mt.emb", (int64_t)cfg->tgt_vocab * D);
+  m->mt_pos = w.get("mt.pos_table", (int64_t)cfg->max_tgt_pos * D);
+  m->mt_ln = {w.get("mt.ln.g", D), w.get("mt.ln.b", D)};
+  load_dec_layers(m, m->mt, "mt", cfg->mt_layers, D, F, d, true);
+  load_dec_layers(m, m->t2u, "t2u", cfg->t2u_layers, D, F, D, false);
+  m->t2u_ln = {w.get("t2u.ln.g", D), w.get("t2u.ln.b", D)};
+  load_dec_layers(m, m->unit, "unit", cfg->unit_layers, D, F, D, true);
+  m->unit_ln = {w.get("unit.ln.g", D), w.get("unit.ln.b", D)};
+  m->unit_out = {w.get("unit.out.w", (int64_t)cfg->unit_vocab * D), nullptr};
+  m->unit_pos_row = w.get("unit.pos_row", D);
+  if (!w.missing.empty()) { delete m; return SS_ERR_MISSING_WEIGHT; }
+
+  // projected rel-pos table for every layer at once: [2Tm-1, d] x [L*d, d]^T (linear_pos has no
+  // bias, espnet_multihead_attention.py:125).  Depends only on the relative offset, so it is
+  // computed once here and sliced per utterance.
+  const int rows = 2 * Tm - 1, Ld = cfg->enc_layers * d;
+  rc = m->pos_proj.ensure((size_t)rows * Ld * sizeof(float));
+  if (rc == SS_OK) {
+    Lin lp{m->pos_w, nullptr};
+    rc = linear(nullptr, m->pos_table, d, rows, lp, Ld, d, m->pos_proj.f(), Ld);
+  }
+  if (rc == SS_OK && hipDeviceSynchronize() != hipSuccess) rc = SS_ERR_HIP;
+  if (rc == SS_OK) rc = m->mt_self.ensure((size_t)cfg->mt_layers * cfg->max_tgt_pos * 3 * D * sizeof(float));
+  if (rc != SS_OK) { ss_model_destroy(m); return rc; }
+  *out = m;
+  return SS_OK;
+}
+
+extern "C" void ss_model_destroy(ss_model* m) {
+  if (!m) return;
+  m->pos_proj.release(); m->ws.release(); m->mt_cross.release(); m->mt_self.release(); m->mt_ws.release();
+  delete m;
+}
+
+// ---- front-end ---------------------------------------------------------------------------------
+extern "C" int ss_fbank_num_frames(int n) { return n < 400 ? 0 : 1 + (n - 400) / 160; }
+
+extern "C" int ss_fbank_cmvn(ss_model* m, void* stream, const float* d_pcm, int n_samples, float pcm_scale,
+                             float* d_feat, int* h_n_frames) {
+  if (!m) return SS_ERR_ARG;
+  return launch_fbank_cmvn(d_pcm, n_samples, pcm_scale, m->fe_window, m->fe_melw, m->fe_mean, m->fe_std,
+                           d_feat, h_n_frames, (hipStream_t)stream);
+}
+
+// ---- encoder -----------------------------------------------------------------------------------
+static int conv_out_len(int L, int k, int stride) { return (L + 2 * (k / 2) - k) / stride + 1; }
+
+extern "C" int ss_encoder_out_len(int T) {
+  const int t1 = conv_out_len(T, 5, 2);
+  return conv_out_len(t1, 5, 2);
+}
+
+extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
+                                  int conv_chunk, float* d_enc_out) {
+  if (!m || T <= 0) return SS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const ss_config& c = m->cfg;
+  const int d = c.enc_dim, f = c.enc_ffn, k = c.conv_kernel, Ld = c.enc_layers * d;
+  const int T1 = conv_out_len(T, k, 2), T2 = conv_out_len(T1, k, 2);
+  if (T2 <= 0 || T2 > c.max_rel_pos) return SS_ERR_CAPACITY;
+  const int cchunk = (conv_chunk > 0 && conv_chunk < 999) ? conv_chunk : 0;   // chunk_causal_conv1d.py:40
+  const int achunk = (attn_chunk > 0 && attn_chunk < T2) ? attn_chunk : 0;
+
+  // scratch layout (floats)
+  const size_t n_h1 = (size_t)T1 * (c.conv_channels / 2);
+  const size_t n_x = (size_t)T2 * d, n_f = (size_t)T2 * f, n_qkv = (size_t)T2 * 3 * d;
+  RET(m->ws.ensure((n_h1 + 3 * n_x + n_f + n_qkv) * sizeof(float)));
+  float* h1 = m->ws.f();
+  float* x = d_enc_out;                 // running activations live in the output buffer
+  float* h = h1 + n_h1;                 // LN output / attention context
+  float* g = h + n_x;                   // GLU output / misc
+  float* g2 = g + n_x;                  // depthwise output
+  float* ff = g2 + n_x;                 // FFN hidden
+  float* qkv = ff + n_f;
+
+  // Conv1dSubsampler: (stride-2 k5 chunk-causal conv -> GLU) x 2   (convolution.py:81-89)
+  {
+    GemmArgs a;
+    a.A = d_fbank; a.lda = c.input_feat; a.W = m->sub0.w; a.bias = m->sub0.b; a.C = h1; a.ldc = c.conv_channels / 2;
+    a.M = T1; a.N = c.conv_channels; a.Cin = c.input_feat; a.taps = k; a.stride = 2; a.pad = k / 2;
+    a.in_len = T; a.chunk = cchunk; a.glu = 1;
+    RET(launch_conv_gemm(a, s));
+    GemmArgs b;
+    b.A = h1; b.lda = c.conv_channels / 2; b.W = m->sub1.w; b.bias = m->sub1.b; b.C = g; b.ldc = d;
+    b.M = T2; b.N = 2 * d; b.Cin = c.conv_channels / 2; b.taps = k; b.stride = 2; b.pad = k / 2;
+    b.in_len = T1; b.chunk = cchunk; b.glu = 1;
+    RET(launch_conv_gemm(b, s));
+  }
+  // x = Linear(sqrt(d) * x)  -- the sqrt(d)=16 scale is folded (exactly) into enc.linear.w
+  RET(linear(s, g, d, T2, m->enc_linear, d, d, x, d));
+  const float* P = m->pos_proj.f() + (size_t)(c.max_rel_pos - T2) * Ld;
+
+  for (int l = 0; l < c.enc_layers; ++l) {
+    const EncLayer& e = m->enc[l];
+    // x = x + 0.5 * FFN1(x)
+    RET(layernorm(s, x, h, e.ffn1_ln, T2, d));
+    RET(linear(s, h, d, T2, e.ffn1_w1, f, d, ff, f, ACT_SILU));
+    RET(linear(s, ff, f, T2, e.ffn1_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
+    // x = x + RelPosMHA(LN(x))
+    RET(layernorm(s, x, h, e.attn_ln, T2, d));
+    RET(linear(s, h, d, T2, e.qkv, 3 * d, d, qkv, 3 * d));
+    AttnArgs at;
+    at.Q = qkv; at.K = qkv + d; at.V = qkv + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
+    at.O = h; at.ldo = d; at.Tq = T2; at.Tk = T2; at.H = c.enc_heads; at.scale = 0.125f;
+    at.chunk = achunk; at.P = P + (size_t)l * d; at.ldp = Ld; at.bias_u = e.u; at.bias_v = e.v;
+    RET(launch_attention(at, s));
+    RET(linear(s, h, d, T2, e.out, d, d, x, d, ACT_NONE, 1.f, x, d));
+    // x = x + ConvModule(x)
+    RET(layernorm(s, x, h, e.conv_ln, T2, d));
+    RET(linear(s, h, d, T2, e.pw1, 2 * d, d, g, d, ACT_NONE, 1.f, nullptr, 0, 1));
+    RET(launch_dwconv_bn_silu(g, d, g2, d, e.dw_wt, c.dw_kernel, e.bn_mean, e.bn_var, e.bn_g, e.bn_b, 1e-5f,
+                              T2, d, cchunk, s));
+    RET(linear(s, g2, d, T2, e.pw2, d, d, x, d, ACT_NONE, 1.f, x, d));
+    // x = LN(x + 0.5 * FFN2(x))
+    RET(layernorm(s, x, h, e.ffn2_ln, T2, d));
+    RET(linear(s, h, d, T2, e.ffn2_w1, f, d, ff, f, ACT_SILU));
+    RET(linear(s, ff, f, T2, e.ffn2_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
+    RET(layernorm(s, x, x, e.final_ln, T2, d));
+  }
+  return SS_OK;
+}
+
+// ---- CTC heads ---------------------------------------------------------------------------------
+extern "C" int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d_enc_out, int Tp,
+                             int32_t* d_raw, int32_t* d_tokens, int32_t* d_index, int32_t* d_count,
+                             float* d_logits) {
+  if (!m || Tp <= 0 || head < 0 || head > 1) return SS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const ss_config& c = m->cfg;
+  const int V = head == 0 ? c.src_vocab : c.tgt_vocab;
+  float* logits = d_logits;
+  if (!logits) {
+    RET(m->mt_ws.ensure((size_t)Tp * V * sizeof(float)));
+    logits = m->mt_ws.f();
+  }
+  RET(linear(s, d_enc_out, c.enc_dim, Tp, head == 0 ? m->ctc_asr : m->ctc_st, V, c.enc_dim, logits, V));
+  RET(launch_masked_argmax(logits, V, Tp, V, c.pad, c.unk, -1, -1, d_raw, s));
+  return launch_ctc_collapse(d_raw, Tp, 0, c.pad, d_tokens, d_index, d_count, s);
+}
+
+// ---- transformer layers shared by MT decoder / T2U encoder / unit decoder ----------------------
+// x [n, D] in place.  self K/V cache rows live in `selfbuf` ([*, 3D], row = absolute position).
+static int dec_layer(hipStream_t s, const ss_config& c, const DecLayer& L, float* x, int n, int pos0,
+                     float* selfbuf, bool causal, const float* crossKV, int Tk_cross, float* h, float* q2,
+                     float* ff) {
+  const int D = c.dec_dim, F = c.dec_ffn, H = c.dec_heads;
+  RET(layernorm(s, x, h, L.self_ln, n, D));
+  float* rows = selfbuf + (size_t)pos0 * 3 * D;
+  RET(linear(s, h, D, n, L.self_qkv, 3 * D, D, rows, 3 * D));   // q (pre-scaled at pack time), k, v
+  AttnArgs at;
+  at.Q = rows; at.ldq = 3 * D; at.K = selfbuf + D; at.V = selfbuf + 2 * D; at.ldk = at.ldv = 3 * D;
+  at.O = h; at.ldo = D; at.Tq = n; at.Tk = pos0 + n; at.H = H; at.scale = 1.f; at.causal = causal ? 1 : 0;
+  RET(launch_attention(at, s));
+  RET(linear(s, h, D, n, L.self_out, D, D, x, D, ACT_NONE, 1.f, x, D));
+  if (L.has_cross) {
+    RET(layernorm(s, x, h, L.cross_ln, n, D));
+    RET(linear(s, h, D, n, L.cross_q, D, D, q2, D));
+    AttnArgs ac;
+    ac.Q = q2; ac.ldq = D; ac.K = crossKV; ac.V = crossKV + D; ac.ldk = ac.ldv = 2 * D;
+    ac.O = h; ac.ldo = D; ac.Tq = n; ac.Tk = Tk_cross; ac.H = H; ac.scale = 1.f;
+    RET(launch_attention(ac, s));
+    RET(linear(s, h, D, n, L.cross_out, D, D, x, D, ACT_NONE, 1.f, x, D));
+  }
+  RET(layernorm(s, x, h, L.ffn_ln, n, D));
+  RET(linear(s, h, D, n, L.fc1, F, D, ff, F, ACT_RELU));
+  RET(linear(s, ff, F, n, L.fc2, D, F, x, D, ACT_NONE, 1.f, x, D));
+  return SS_OK;
+}
+
+extern "C" int ss_mt_begin(ss_model* m, void* stream, const float* d_enc_out, int Tp) {
+  if (!m || Tp <= 0) return SS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const ss_config& c = m->cfg;
+  const int D = c.dec_dim;
+  RET(m->mt_cross.ensure((size_t)c.mt_layers * Tp * 2 * D * sizeof(float)));
+  for (int l = 0; l < c.mt_layers; ++l)
+    RET(linear(s, d_enc_out, c.enc_dim, Tp, m->mt[l].cross_kv, 2 * D, c.enc_dim,
+               m->mt_cross.f() + (size_t)l * Tp * 2 * D, 2 * D));
+  m->mt_Tp = Tp;
+  m->mt_len = 0;
+  m->mt_enc = d_enc_out;
+  return SS_OK;
+}
+
+extern "C" int ss_mt_truncate(ss_model* m, int len) {
+  if (!m || len < 0 || len > m->mt_len) return SS_ERR_ARG;
+  m->mt_len = len;
+  return SS_OK;
+}
+
+extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, int n, int pos0, int ban_eos,
+                            int force_eos, float* d_feats, int32_t* d_next) {
+  if (!m || n <= 0 || pos0 < 0 || pos0 > m->mt_len || m->mt_Tp <= 0) return SS_ERR_ARG;
+  const ss_config& c = m->cfg;
+  if (pos0 + n + 2 > c.max_tgt_pos) return SS_ERR_CAPACITY;
+  hipStream_t s = (hipStream_t)stream;
+  const int D = c.dec_dim, F = c.dec_ffn, V = c.tgt_vocab;
+  RET(m->mt_ws.ensure(((size_t)n * (4 * D + F) + V) * sizeof(float)));
+  float* x = m->mt_ws.f();
+  float* h = x + (size_t)n * D;
+  float* q2 = h + (size_t)n * D;
+  float* feats = q2 + (size_t)n * D;
+  float* ff = feats + (size_t)n * D;
+  float* logits = ff + (size_t)n * F;
+  // sqrt(D) * E[tok] + sinusoid(position), positions start at padding_idx + 1 (transformer_decoder.py:297-326)
+  RET(launch_embed_tokens(d_tokens, m->mt_emb, m->mt_pos, sqrtf((float)D), pos0 + c.pad + 1, x, n, D, s));
+  for (int l = 0; l < c.mt_layers; ++l) {
+    float* selfbuf = m->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
+    const float* cross = m->mt_cross.f() + (size_t)l * m->mt_Tp * 2 * D;
+    RET(dec_layer(s, c, m->mt[l], x, n, pos0, selfbuf, true, cross, m->mt_Tp, h, q2, ff));
+  }
+  float* fo = d_feats ? d_feats : feats;
+  RET(launch_layernorm(x, D, fo, D, m->mt_ln.g, m->mt_ln.b, n, D, 1e-5f, s));
+  m->mt_len = pos0 + n;
+  if (d_next) {
+    Lin proj{m->mt_emb, nullptr};  // tied output projection, no bias
+    RET(linear(s, fo + (size_t)(n - 1) * D, D, 1, proj, V, D, logits, V));
+    RET(launch_masked_argmax(logits, V, 1, V, c.pad, ban_eos ? c.eos : -1, -1, force_eos ? c.eos : -1, d_next, s));
+  }
+  return SS_OK;
+}
+
+// ---- T2U encoder + CTC unit decoder ------------------------------------------------------------
+extern "C" int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, int n, int t2u_causal,
+                            int mask_eos, int32_t* d_raw, int32_t* d_tokens, int32_t* d_count, float* d_logits) {
+  if (!m || n <= 0) return SS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const ss_config& c = m->cfg;
+  const int D = c.dec_dim, F = c.dec_ffn, U = n * c.ctc_upsample, V = c.unit_vocab;
+  const size_t nx = (size_t)U * D;
+  // t2u: x,h,self(3D) on n rows; unit: x,h,q2 on U rows, self 3D on U rows, ff U*F, cross kv n*2D, logits U*V
+  const size_t total = 3 * nx + (size_t)U * 3 * D + (size_t)U * F + (size_t)n * 2 * D + (size_t)n * D +
+                       (d_logits ? 0 : (size_t)U * V) + (size_t)U;
+  RET(m->ws.ensure(total * sizeof(float)));
+  float* x = m->ws.f();
+  float* h = x + nx;
+  float* q2 = h + nx;
+  float* selfbuf = q2 + nx;
+  float* ff = selfbuf + (size_t)U * 3 * D;
+  float* crosskv = ff + (size_t)U * F;
+  float* t2u_out = crosskv + (size_t)n * 2 * D;
+  float* logits = d_logits ? d_logits : t2u_out + (size_t)n * D;
+  int32_t* idx_scratch = reinterpret_cast<int32_t*>((d_logits ? t2u_out + (size_t)n * D : logits + (size_t)U * V));
+
+  // T2U encoder (transformer_encoder.py:32-77): 2 pre-LN layers + final LN
+  SS_HIP_CHECK(hipMemcpyAsync(x, d_mt_feats, (size_t)n * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+  for (int l = 0; l < c.t2u_layers; ++l)
+    RET(dec_layer(s, c, m->t2u[l], x, n, 0, selfbuf, t2u_causal != 0, nullptr, 0, h, q2, ff));
+  RET(launch_layernorm(x, D, t2u_out, D, m->t2u_ln.g, m->t2u_ln.b, n, D, 1e-5f, s));
+  // unit decoder input: each T2U state 25x + the (quirky) positional row
+  RET(launch_upsample_add_pos(t2u_out, n, c.ctc_upsample, m->unit_pos_row, (float)c.pad, x, D, s));
+  for (int l = 0; l < c.unit_layers; ++l) {
+    RET(linear(s, t2u_out, D, n, m->unit[l].cross_kv, 2 * D, D, crosskv, 2 * D));
+    RET(dec_layer(s, c, m->unit[l], x, U, 0, selfbuf, true, crosskv, n, h, q2, ff));
+  }
+  RET(launch_layernorm(x, D, h, D, m->unit_ln.g, m->unit_ln.b, U, D, 1e-5f, s));
+  RET(linear(s, h, D, U, m->unit_out, V, D, logits, V));
+  RET(launch_masked_argmax(logits, V, U, V, c.pad, c.unk, mask_eos ? c.eos : -1, -1, d_raw, s));
+  return launch_ctc_collapse(d_raw, U, V - 1, c.pad, d_tokens, idx_scratch, d_count, s);
+}
+
+// =================================================================================================
+// vocoder
+// =================================================================================================
+struct ConvW { const float* w = nullptr; const float* b = nullptr; };
+struct ss_vocoder {
+  ss_vocoder_config cfg;
+  WeightTable wt;
+  const float* dict = nullptr;
+  ConvW dur_c1, dur_c2, dur_proj, pre, post;
+  LN dur_ln1, dur_ln2;
+  std::vector<ConvW> ups;
+  std::vector<ConvW> rb_c1, rb_c2;  // [(stage*n_res + j)*3 + d]
+  DevBuf ws, small;
+};
+
+extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_blob, size_t blob_floats,
+                                 const char* const* names, const int64_t* offsets, const int64_t* numels,
+                                 int n_slots, ss_vocoder** out) {
+  if (!cfg || !d_blob || !out || cfg->n_up > 8 || cfg->n_res > 4) return SS_ERR_ARG;
+  ss_vocoder* v = new ss_vocoder();
+  v->cfg = *cfg;
+  int rc = v->wt.build(d_blob, blob_floats, names, offsets, numels, n_slots);
+  if (rc != SS_OK) { delete v; return rc; }
+  WeightTable& w = v->wt;
+  const int E = cfg->embedding_dim, Hd = cfg->dur_hidden, kd = cfg->dur_kernel;
+  v->dict = w.get("voc.dict", (int64_t)cfg->num_embeddings * E);
+  v->dur_c1 = {w.get("voc.dur.conv1.w", (int64_t)Hd * kd * E), w.get("voc.dur.conv1.b", Hd)};
+  v->dur_ln1 = {w.get("voc.dur.ln1.g", Hd), w.get("voc.dur.ln1.b", Hd)};
+  v->dur_c2 = {w.get("voc.dur.conv2.w", (int64_t)Hd * kd * Hd), w.get("voc.dur.conv2.b", Hd)};
+  v->dur_ln2 = {w.get("voc.dur.ln2.g", Hd), w.get("voc.dur.ln2.b", Hd)};
+  v->dur_proj = {w.get("voc.dur.proj.w", Hd), w.get("voc.dur.proj.b", 1)};
+  const int C0 = cfg->upsample_initial_channel;
+  v->pre = {w.get("voc.pre.w", (int64_t)C0 * 7 * cfg->model_in_dim), w.get("voc.pre.b", C0)};
+  int C = C0;
+  for (int i = 0; i < cfg->n_up; ++i) {
+    const int Co = C / 2, st = cfg->upsample_rates[i];
+    v->ups.push_back({w.get("voc.up" + std::to_string(i) + ".w", (int64_t)st * Co * 3 * C),
+                      w.get("voc.up" + std::to_string(i) + ".b", (int64_t)st * Co)});
+    for (int j = 0; j < cfg->n_res; ++j) {
+      const int kr = cfg->resblock_kernel_sizes[j];
+      for (int dd = 0; dd < 3; ++dd) {
+        const std::string p = "voc.rb" + std::to_string(i * cfg->n_res + j);
+        v->rb_c1.push_back({w.get(p + ".c1." + std::to_string(dd) + ".w", (int64_t)Co * kr * Co),
+                            w.get(p + ".c1." + std::to_string(dd) + ".b", Co)});
+        v->rb_c2.push_back({w.get(p + ".c2." + std::to_string(dd) + ".w", (int64_t)Co * kr * Co),
+                            w.get(p + ".c2." + std::to_string(dd) + ".b", Co)});
+      }
+    }
+    C = Co;
+  }
+  v->post = {w.get("voc.post.w", (int64_t)7 * C), w.get("voc.post.b", 1)};
+  if (!w.missing.empty()) { delete v; return SS_ERR_MISSING_WEIGHT; }
+  *out = v;
+  return SS_OK;
+}
+
+extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
+  if (!v) return;
+  v->ws.release(); v->small.release();
+  delete v;
+}
+
+static int conv1d(hipStream_t s, const float* A, int T, int Cin, const ConvW& cw, int Cout, int k, int dil,
+                  float* C, int in_act, float slope, int act, const float* R, const float* R2, float div) {
+  GemmArgs a;
+  a.A = A; a.lda = Cin; a.W = cw.w; a.bias = cw.b; a.C = C; a.ldc = Cout; a.R = R; a.ldr = Cout; a.R2 = R2; a.ldr2 = Cout;
+  a.M = T; a.N = Cout; a.Cin = Cin; a.taps = k; a.dil = dil; a.stride = 1; a.pad = dil * (k - 1) / 2; a.in_len = T;
+  a.in_act = in_act; a.in_slope = slope; a.act = act; a.div = div;
+  return launch_conv_gemm(a, s);
+}
+
+extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_codes, int K, int dur_prediction,
+                                  const int32_t* d_forced_dur, float* d_wav, int64_t wav_capacity,
+                                  int32_t* d_dur, int64_t* h_n_samples) {
+  if (!v || K <= 0 || !d_codes || !d_wav || !d_dur) return SS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const ss_vocoder_config& c = v->cfg;
+  const int E = c.embedding_dim, Hd = c.dur_hidden;
+  // --- embedding + duration predictor (codehifigan.py:56-66, fastspeech2.py:117-151) ---
+  RET(v->small.ensure(((size_t)K * (E + 2 * Hd + 1) + 2 * (K + 2)) * sizeof(float)));
+  float* emb = v->small.f();
+  float* t1 = emb + (size_t)K * E;
+  float* t2 = t1 + (size_t)K * Hd;
+  float* logdur = t2 + (size_t)K * Hd;
+  int* cum = reinterpret_cast<int*>(logdur + K);
+  int* ones = cum + K + 1;
+  RET(launch_gather_rows(d_codes, v->dict, E, emb, K, s));
+  const int* forced = d_forced_dur;
+  if (!forced && dur_prediction) {
+    RET(conv1d(s, emb, K, E, v->dur_c1, Hd, c.dur_kernel, 1, t1, ACT_NONE, 0.f, ACT_RELU, nullptr, nullptr, 0.f));
+    RET(launch_layernorm(t1, Hd, t1, Hd, v->dur_ln1.g, v->dur_ln1.b, K, Hd, 1e-5f, s));
+    RET(conv1d(s, t1, K, Hd, v->dur_c2, Hd, c.dur_kernel, 1, t2, ACT_NONE, 0.f, ACT_RELU, nullptr, nullptr, 0.f));
+    RET(launch_layernorm(t2, Hd, t2, Hd, v->dur_ln2.g, v->dur_ln2.b, K, Hd, 1e-5f, s));
+    RET(conv1d(s, t2, K, Hd, v->dur_proj, 1, 1, 1, logdur, ACT_NONE, 0.f, ACT_NONE, nullptr, nullptr, 0.f));
+  } else if (!forced) {
+    std::vector<int> one(K, 1);
+    SS_HIP_CHECK(hipMemcpyAsync(ones, one.data(), K * sizeof(int), hipMemcpyHostToDevice, s));
+    SS_HIP_CHECK(hipStreamSynchronize(s));  // `one` must outlive the copy
+    forced = ones;
+  }
+  RET(launch_dur_predict(logdur, forced, K, d_dur, cum, s));
+  int total = 0;
+  SS_HIP_CHECK(hipMemcpyAsync(&total, cum + K, sizeof(int), hipMemcpyDeviceToHost, s));
+  SS_HIP_CHECK(hipStreamSynchronize(s));
+  const int Fr = total;
+  int hop = 1;
+  for (int i = 0; i < c.n_up; ++i) hop *= c.upsample_rates[i];
+  const int64_t S = (int64_t)Fr * hop;
+  if (h_n_samples) *h_n_samples = S;
+  if (S > wav_capacity) return SS_ERR_CAPACITY;
+  if (Fr <= 0) return SS_OK;
+
+  // --- generator (hifigan.py:154-170).  Every stage holds T_i * C_i = Fr * hop_i * C0 / 2^(i+1) floats.
+  size_t stage_max = (size_t)Fr * c.upsample_initial_channel;  // conv_pre output
+  {
+    int T = Fr, C = c.upsample_initial_channel;
+    for (int i = 0; i < c.n_up; ++i) { T *= c.upsample_rates[i]; C /= 2; stage_max = std::max(stage_max, (size_t)T * C); }
+  }
+  RET(v->ws.ensure((4 * stage_max + (size_t)Fr * E) * sizeof(float)));
+  float* frames = v->ws.f();
+  float* bx = frames + (size_t)Fr * E;   // stage input / MRF accumulator ping-pong
+  float* bt = bx + stage_max;            // conv1 output
+  float* br = bt + stage_max;            // running resblock state
+  float* bs = br + stage_max;            // x after the transposed conv
+  RET(launch_repeat_rows(emb, cum, K, E, frames, Fr, s));
+  RET(conv1d(s, frames, Fr, c.model_in_dim, v->pre, c.upsample_initial_channel, 7, 1, bx, ACT_NONE, 0.f, ACT_NONE,
+             nullptr, nullptr, 0.f));
+  int T = Fr, C = c.upsample_initial_channel;
+  for (int i = 0; i < c.n_up; ++i) {
+    const int st = c.upsample_rates[i], Co = C / 2;
+    // leaky_relu(0.1) -> ConvTranspose1d as a 3-tap polyphase conv with N = st*Co: row q of the
+    // [T, st*Co] result is rows q*st .. q*st+st-1 of the [T*st, Co] signal.
+    GemmArgs a;
+    a.A = bx; a.lda = C; a.W = v->ups[i].w; a.bias = v->ups[i].b; a.C = bs; a.ldc = st * Co;
+    a.M = T; a.N = st * Co; a.Cin = C; a.taps = 3; a.dil = 1; a.stride = 1; a.pad = 1; a.in_len = T;
+    a.in_act = ACT_LRELU; a.in_slope = 0.1f;
+    RET(launch_conv_gemm(a, s));
+    T *= st; C = Co;
+    for (int j = 0; j < c.n_res; ++j) {
+      const int kr = c.resblock_kernel_sizes[j];
+      for (int dd = 0; dd < 3; ++dd) {
+        const int idx = (i * c.n_res + j) * 3 + dd;
+        const float* rin = dd == 0 ? bs : br;
+        RET(conv1d(s, rin, T, C, v->rb_c1[idx], C, kr, c.resblock_dilations[j][dd], bt, ACT_LRELU, 0.1f, ACT_NONE,
+                   nullptr, nullptr, 0.f));
+        if (dd < 2) {
+          RET(conv1d(s, bt, T, C, v->rb_c2[idx], C, kr, 1, br, ACT_LRELU, 0.1f, ACT_NONE, rin, nullptr, 0.f));
+        } else {
+          // last conv of the resblock also folds the MRF sum: xs (+)= resblock_j(x); x = xs / n_res
+          const float* R2 = j == 0 ? nullptr : bx;
+          const float div = (j == c.n_res - 1) ? (float)c.n_res : 0.f;
+          RET(conv1d(s, bt, T, C, v->rb_c2[idx], C, kr, 1, bx, ACT_LRELU, 0.1f, ACT_NONE, rin, R2, div));
+        }
+      }
+    }
+  }
+  // leaky_relu (default slope 0.01, hifigan.py:166) -> conv_post -> tanh
+  return launch_conv_post_tanh(bx, T, C, v->post.w, v->post.b, 0.01f, d_wav, s);
+}
+
+// =================================================================================================
+// op-level entry points
+// =================================================================================================
+extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const float* dW, const float* dbias,
+                               const float* dR, int ldr, const float* dR2, int ldr2, float* dC, int ldc, int M,
+                               int N, int Cin, int taps, int dil, int stride, int pad, int in_len, int chunk,
+                               int in_act, float in_slope, int act, float alpha, float div, int glu) {
+  GemmArgs a;
+  a.A = dA; a.lda = lda; a.W = dW; a.bias = dbias; a.R = dR; a.ldr = ldr; a.R2 = dR2; a.ldr2 = ldr2; a.C = dC; a.ldc = ldc;
+  a.M = M; a.N = N; a.Cin = Cin; a.taps = taps; a.dil = dil; a.stride = stride; a.pad = pad; a.in_len = in_len;
+  a.chunk = chunk; a.in_act = in_act; a.in_slope = in_slope; a.act = act; a.alpha = alpha; a.div = div; a.glu = glu;
+  return launch_conv_gemm(a, (hipStream_t)stream);
+}
+
+extern "C" int ss_op_layernorm(void* stream, const float* dx, int ldx, float* dy, int ldy, const float* dg,
+                               const float* db, int M, int D, float eps) {
+  return launch_layernorm(dx, ldx, dy, ldy, dg, db, M, D, eps, (hipStream_t)stream);
+}
+
+extern "C" int ss_op_attention(void* stream, const float* dQ, int ldq, const float* dK, int ldk, const float* dV,
+                               int ldv, float* dO, int ldo, int Tq, int Tk, int H, float scale, int causal, int chunk,
+                               const float* dP, int ldp, const float* du, const float* dv) {
+  AttnArgs a;
+  a.Q = dQ; a.ldq = ldq; a.K = dK; a.ldk = ldk; a.V = dV; a.ldv = ldv; a.O = dO; a.ldo = ldo;
+  a.Tq = Tq; a.Tk = Tk; a.H = H; a.scale = scale; a.causal = causal; a.chunk = chunk;
+  a.P = dP; a.ldp = ldp; a.bias_u = du; a.bias_v = dv;
+  return launch_attention(a, (hipStream_t)stream);
+}
+
+extern "C" int ss_op_dwconv_bn_silu(void* stream, const float* dx, int ldx, float* dy, int ldy, const float* dwt,
+                                    int K, const float* mean, const float* var, const float* gamma,
+                                    const float* beta, float eps, int T, int C, int chunk) {
+  return launch_dwconv_bn_silu(dx, ldx, dy, ldy, dwt, K, mean, var, gamma, beta, eps, T, C, chunk, (hipStream_t)stream);
+}

@@ -1,0 +1,197 @@
+"""Python host side of the HIP library: owns device memory (torch tensors), hands raw pointers
+to the C ABI.  Torch is plumbing here (allocation, streams, H2D/D2H copies) -- every FLOP of the
+S2ST path runs in libstreamspeech_hip.so.
+"""
+import ctypes as C
+from typing import List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import lib as L
+from .config import ModelConfig, VocoderConfig
+from .weights import pack_model, pack_vocoder
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_gpu(device):
+    if not torch.cuda.is_available():
+        raise L.StreamSpeechHipError(
+            "streamspeech_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+            "there is no CPU fallback for the product path")
+    return torch.device(device)
+
+
+def _slots(names, offsets, numels):
+    n = len(names)
+    c_names = (C.c_char_p * n)(*[s.encode() for s in names])
+    c_off = (C.c_int64 * n)(*offsets)
+    c_num = (C.c_int64 * n)(*numels)
+    return c_names, c_off, c_num, n
+
+
+class HipModel:
+    """ss_model handle + packed weights (StreamSpeechModel replacement)."""
+
+    def __init__(self, state_dict, cfg: ModelConfig = None, device="cuda:0", cmvn_mean=None, cmvn_std=None,
+                 max_rel_pos: int = 2048, max_tgt_pos: int = 1026):
+        self.lib = L.load()
+        self.cfg = cfg or ModelConfig()
+        self.device = _require_gpu(device)
+        names, offsets, numels, blob = pack_model(state_dict, self.cfg, cmvn_mean, cmvn_std, max_rel_pos, max_tgt_pos)
+        self.blob = blob.to(self.device)
+        c = self.cfg
+        self.c_cfg = L.SSConfig(
+            c.input_feat, c.conv_channels, c.conv_kernel, c.enc_dim, c.enc_ffn, c.enc_heads, c.enc_layers,
+            c.dw_kernel, c.src_vocab, c.tgt_vocab, c.mt_layers, c.dec_dim, c.dec_ffn, c.dec_heads, c.t2u_layers,
+            c.unit_layers, c.unit_vocab, c.ctc_upsample, c.pad, c.eos, c.unk, max_rel_pos, max_tgt_pos)
+        cn, co, cm, n = _slots(names, offsets, numels)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ss_model_create(C.byref(self.c_cfg), _ptr(self.blob), self.blob.numel(), cn, co, cm, n,
+                                             C.byref(h)), "ss_model_create")
+        self.h = h
+        self.max_tgt_pos = max_tgt_pos
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ss_model_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # ---- a1 -------------------------------------------------------------------------------
+    def fbank_cmvn(self, pcm16k: torch.Tensor, pcm_scale: float = 32768.0) -> torch.Tensor:
+        """pcm16k: float32 [n] on the device -> [T, 80]."""
+        n = pcm16k.numel()
+        T = self.lib.ss_fbank_num_frames(n)
+        feat = torch.empty((T, 80), dtype=torch.float32, device=self.device)
+        nf = C.c_int(0)
+        L.check(self.lib.ss_fbank_cmvn(self.h, _stream(), _ptr(pcm16k), n, pcm_scale, _ptr(feat), C.byref(nf)),
+                "ss_fbank_cmvn")
+        return feat
+
+    # ---- a2-a7 ----------------------------------------------------------------------------
+    def encoder_out_len(self, T: int) -> int:
+        return self.lib.ss_encoder_out_len(T)
+
+    def encoder_forward(self, fbank: torch.Tensor, attn_chunk: int = 999999, conv_chunk: int = 999999) -> torch.Tensor:
+        """fbank [T,80] (device, contiguous) -> [T',256]."""
+        assert fbank.is_cuda and fbank.dtype == torch.float32 and fbank.is_contiguous()
+        T = fbank.shape[0]
+        Tp = self.lib.ss_encoder_out_len(T)
+        out = torch.empty((Tp, self.cfg.enc_dim), dtype=torch.float32, device=self.device)
+        L.check(self.lib.ss_encoder_forward(self.h, _stream(), _ptr(fbank), T, int(min(attn_chunk, 1 << 30)),
+                                            int(min(conv_chunk, 1 << 30)), _ptr(out)), "ss_encoder_forward")
+        return out
+
+    # ---- a8 -------------------------------------------------------------------------------
+    def ctc_greedy(self, head: int, enc_out: torch.Tensor, want_logits: bool = False):
+        """-> (tokens list, frame index list, raw argmax tensor, logits or None)."""
+        Tp = enc_out.shape[0]
+        V = self.cfg.src_vocab if head == 0 else self.cfg.tgt_vocab
+        ibuf = torch.empty((3 * Tp + 1,), dtype=torch.int32, device=self.device)
+        raw, toks, idx, cnt = ibuf[:Tp], ibuf[Tp:2 * Tp], ibuf[2 * Tp:3 * Tp], ibuf[3 * Tp:]
+        logits = torch.empty((Tp, V), dtype=torch.float32, device=self.device) if want_logits else None
+        L.check(self.lib.ss_ctc_greedy(self.h, _stream(), head, _ptr(enc_out), Tp, _ptr(raw), _ptr(toks), _ptr(idx),
+                                       _ptr(cnt), _ptr(logits)), "ss_ctc_greedy")
+        host = ibuf.cpu()
+        n = int(host[3 * Tp])
+        return host[Tp:Tp + n].tolist(), host[2 * Tp:2 * Tp + n].tolist(), host[:Tp], logits
+
+    # ---- a9-a10 ---------------------------------------------------------------------------
+    def mt_begin(self, enc_out: torch.Tensor):
+        self._mt_enc = enc_out  # keep alive
+        L.check(self.lib.ss_mt_begin(self.h, _stream(), _ptr(enc_out), enc_out.shape[0]), "ss_mt_begin")
+
+    def mt_append(self, tokens: List[int], pos0: int, ban_eos: bool, force_eos: bool,
+                  want_feats: bool = True, want_next: bool = True) -> Tuple[Optional[torch.Tensor], Optional[int]]:
+        n = len(tokens)
+        tok = torch.tensor(tokens, dtype=torch.int32).to(self.device)
+        feats = torch.empty((n, self.cfg.dec_dim), dtype=torch.float32, device=self.device) if want_feats else None
+        nxt = torch.empty((1,), dtype=torch.int32, device=self.device) if want_next else None
+        L.check(self.lib.ss_mt_append(self.h, _stream(), _ptr(tok), n, pos0, int(ban_eos), int(force_eos),
+                                      _ptr(feats), _ptr(nxt)), "ss_mt_append")
+        return feats, (int(nxt.item()) if want_next else None)
+
+    def mt_truncate(self, length: int):
+        L.check(self.lib.ss_mt_truncate(self.h, length), "ss_mt_truncate")
+
+    # ---- a11-a13 --------------------------------------------------------------------------
+    def t2u_units(self, mt_feats: torch.Tensor, t2u_causal: bool = False, mask_eos: bool = False,
+                  want_logits: bool = False):
+        """mt_feats [n,512] -> (collapsed unit-vocab tokens list, raw argmax tensor(host), logits or None)."""
+        n = mt_feats.shape[0]
+        U = n * self.cfg.ctc_upsample
+        ibuf = torch.empty((2 * U + 1,), dtype=torch.int32, device=self.device)
+        raw, toks, cnt = ibuf[:U], ibuf[U:2 * U], ibuf[2 * U:]
+        logits = torch.empty((U, self.cfg.unit_vocab), dtype=torch.float32, device=self.device) if want_logits else None
+        L.check(self.lib.ss_t2u_units(self.h, _stream(), _ptr(mt_feats.contiguous()), n, int(t2u_causal),
+                                      int(mask_eos), _ptr(raw), _ptr(toks), _ptr(cnt), _ptr(logits)), "ss_t2u_units")
+        host = ibuf.cpu()
+        k = int(host[2 * U])
+        return host[U:U + k].tolist(), host[:U], logits
+
+
+class HipVocoder:
+    """ss_vocoder handle (CodeHiFiGANVocoderWithDur replacement)."""
+
+    def __init__(self, generator_state_dict, cfg: VocoderConfig = None, device="cuda:0"):
+        self.lib = L.load()
+        self.cfg = cfg or VocoderConfig()
+        self.device = _require_gpu(device)
+        names, offsets, numels, blob = pack_vocoder(generator_state_dict, self.cfg)
+        self.blob = blob.to(self.device)
+        c = self.cfg
+        cc = L.SSVocoderConfig()
+        cc.num_embeddings, cc.embedding_dim, cc.model_in_dim = c.num_embeddings, c.embedding_dim, c.model_in_dim
+        cc.upsample_initial_channel = c.upsample_initial_channel
+        cc.n_up = len(c.upsample_rates)
+        for i, (u, k) in enumerate(zip(c.upsample_rates, c.upsample_kernel_sizes)):
+            cc.upsample_rates[i] = u
+            cc.upsample_kernel_sizes[i] = k
+        cc.n_res = len(c.resblock_kernel_sizes)
+        for j, (k, dil) in enumerate(zip(c.resblock_kernel_sizes, c.resblock_dilation_sizes)):
+            cc.resblock_kernel_sizes[j] = k
+            for t, dv in enumerate(dil):
+                cc.resblock_dilations[j][t] = dv
+        cc.dur_hidden, cc.dur_kernel = c.dur_hidden, c.dur_kernel
+        self.c_cfg = cc
+        cn, co, cm, n = _slots(names, offsets, numels)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ss_vocoder_create(C.byref(cc), _ptr(self.blob), self.blob.numel(), cn, co, cm, n,
+                                               C.byref(h)), "ss_vocoder_create")
+        self.h = h
+        self.hop = int(np.prod(c.upsample_rates))
+        self.max_dur = 64
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ss_vocoder_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def forward(self, codes, dur_prediction: bool = True, forced_dur=None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """codes: list/array/tensor of unit ids -> (wav [S] float32 device, dur [K] int32 device)."""
+        codes_t = torch.as_tensor(codes, dtype=torch.int32).reshape(-1).to(self.device)
+        K = codes_t.numel()
+        fd = None if forced_dur is None else torch.as_tensor(forced_dur, dtype=torch.int32).reshape(-1).to(self.device)
+        cap = K * self.max_dur * self.hop
+        wav = torch.empty((cap,), dtype=torch.float32, device=self.device)
+        dur = torch.empty((K,), dtype=torch.int32, device=self.device)
+        ns = C.c_int64(0)
+        rc = self.lib.ss_vocoder_forward(self.h, _stream(), _ptr(codes_t), K, int(dur_prediction), _ptr(fd),
+                                         _ptr(wav), cap, _ptr(dur), C.byref(ns))
+        L.check(rc, "ss_vocoder_forward")
+        return wav[: ns.value], dur

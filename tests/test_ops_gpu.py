@@ -1,0 +1,215 @@
+"""GPU parity of single HIP kernels (through the C ABI's ss_op_* entry points) against plain
+torch-fp32 CPU references of the same op.  Tolerances are absolute on O(1)-scaled data; the
+kernels accumulate in exact FP32 (v_mfma_f32_16x16x4_f32 / v_fma_f32), so differences are
+summation-order only.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from streamspeech_amd import lib as L
+    return L.load()
+
+
+def P(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def S():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def run_conv_gemm(lib, A, Wp, bias, M, N, Cin, taps=1, dil=1, stride=1, pad=0, in_len=None, chunk=0,
+                  in_act=0, slope=0.1, act=0, alpha=1.0, div=0.0, glu=0, R=None, R2=None, out_cols=None):
+    from streamspeech_amd import lib as L
+    dev = "cuda:0"
+    dA, dW = A.contiguous().to(dev), Wp.contiguous().to(dev)
+    db = None if bias is None else bias.to(dev)
+    dR = None if R is None else R.contiguous().to(dev)
+    dR2 = None if R2 is None else R2.contiguous().to(dev)
+    oc = out_cols or (N // 2 if glu else N)
+    dC = torch.full((M, oc), float("nan"), device=dev)
+    L.check(lib.ss_op_conv_gemm(S(), P(dA), A.shape[1], P(dW), P(db), P(dR), oc, P(dR2), oc, P(dC), oc, M, N, Cin,
+                                taps, dil, stride, pad, in_len if in_len is not None else A.shape[0], chunk,
+                                in_act, slope, act, alpha, div, glu), "ss_op_conv_gemm")
+    torch.cuda.synchronize()
+    return dC.cpu()
+
+
+@pytest.mark.parametrize("M,N,K", [(125, 2048, 256), (125, 256, 2048), (1, 6000, 512), (7, 512, 512),
+                                   (33, 1005, 512), (500, 768, 256), (3000, 512, 256), (20000, 128, 128),
+                                   (40000, 32, 32), (80000, 16, 16), (19, 1, 128)])
+def test_linear_shapes(lib, M, N, K):
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+    got = run_conv_gemm(lib, A, W, b, M, N, K)
+    ref = F.linear(A, W, b)
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() < TOL, f"max err {(got - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("act", [1, 2])
+def test_linear_epilogues(lib, act):
+    M, N, K = 125, 2048, 256
+    A, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3, scale=0.1)
+    R = rnd(M, N, seed=4)
+    got = run_conv_gemm(lib, A, W, b, M, N, K, act=act, alpha=0.5, R=R)
+    y = F.linear(A, W, b)
+    y = F.silu(y) if act == 1 else F.relu(y)
+    ref = y * 0.5 + R
+    assert (got - ref).abs().max() < TOL
+
+
+@pytest.mark.parametrize("cin,cout,T,chunk", [(80, 1024, 83, 0), (80, 1024, 83, 8), (512, 512, 42, 16),
+                                              (512, 512, 11, 8), (80, 1024, 435, 0)])
+def test_subsampler_conv_glu(lib, cin, cout, T, chunk):
+    """stride-2 k5 chunk-causal conv + GLU vs the oracle's closed form."""
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd.weights import conv_tap_major, glu_interleave
+    x = rnd(T, cin, seed=5)
+    w = rnd(cout, cin, 5, seed=6, scale=(cin * 5) ** -0.5)
+    b = rnd(cout, seed=7, scale=0.1)
+    ref = F.glu(O.chunk_causal_conv1d(x.t().contiguous(), w, b, 2, chunk if chunk else 999999), dim=0).t()
+    M = ref.shape[0]
+    got = run_conv_gemm(lib, x, conv_tap_major(glu_interleave(w)), glu_interleave(b), M, cout, cin, taps=5, stride=2,
+                        pad=2, in_len=T, chunk=chunk, glu=1)
+    assert (got - ref).abs().max() < TOL, f"{(got - ref).abs().max()}"
+
+
+@pytest.mark.parametrize("C,k,dil,T", [(256, 11, 5, 300), (128, 7, 3, 1000), (64, 3, 1, 700), (32, 7, 3, 900),
+                                       (16, 11, 5, 2000), (16, 3, 1, 257), (512, 7, 1, 50)])
+def test_resblock_conv(lib, C, k, dil, T):
+    """leaky_relu -> dilated conv (+ residual, + MRF accumulate and mean)."""
+    from streamspeech_amd.weights import conv_tap_major
+    x = rnd(T, C, seed=8)
+    w = rnd(C, C, k, seed=9, scale=(C * k) ** -0.5)
+    b = rnd(C, seed=10, scale=0.1)
+    R, R2 = rnd(T, C, seed=11), rnd(T, C, seed=12)
+    y = F.conv1d(F.leaky_relu(x.t()[None], 0.1), w, b, dilation=dil, padding=dil * (k - 1) // 2)[0].t()
+    got = run_conv_gemm(lib, x, conv_tap_major(w), b, T, C, C, taps=k, dil=dil, pad=dil * (k - 1) // 2, in_act=3)
+    assert (got - y).abs().max() < TOL
+    got = run_conv_gemm(lib, x, conv_tap_major(w), b, T, C, C, taps=k, dil=dil, pad=dil * (k - 1) // 2, in_act=3,
+                        R=R, R2=R2, div=3.0)
+    ref = (R2 + (y + R)) / 3
+    assert (got - ref).abs().max() < TOL
+
+
+@pytest.mark.parametrize("cin,k,s,T", [(512, 11, 5, 40), (256, 8, 4, 200), (128, 8, 4, 300), (64, 4, 2, 500),
+                                       (32, 4, 2, 777)])
+def test_conv_transpose_polyphase(lib, cin, k, s, T):
+    from streamspeech_amd.weights import convT_polyphase
+    cout = cin // 2
+    x = rnd(T, cin, seed=13)
+    w = rnd(cin, cout, k, seed=14, scale=(cin * k / s) ** -0.5)
+    b = rnd(cout, seed=15, scale=0.1)
+    ref = F.conv_transpose1d(F.leaky_relu(x.t()[None], 0.1), w, b, stride=s, padding=(k - s) // 2)[0].t()
+    wp, bp = convT_polyphase(w, b, s)
+    got = run_conv_gemm(lib, x, wp, bp, T, s * cout, cin, taps=3, pad=1, in_act=3).reshape(T * s, cout)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max() < TOL
+
+
+@pytest.mark.parametrize("D", [128, 256, 512])
+def test_layernorm(lib, D):
+    from streamspeech_amd import lib as L
+    M = 131
+    x, g, b = rnd(M, D, seed=16) * 3 + 1, rnd(D, seed=17) * 0.1 + 1, rnd(D, seed=18) * 0.1
+    dx, dg, db = x.cuda(), g.cuda(), b.cuda()
+    dy = torch.empty_like(dx)
+    L.check(lib.ss_op_layernorm(S(), P(dx), D, P(dy), D, P(dg), P(db), M, D, 1e-5), "ln")
+    ref = F.layer_norm(x, (D,), g, b, 1e-5)
+    assert (dy.cpu() - ref).abs().max() < 2e-5
+
+
+def _attn_ref(q, k, v, H, scale, causal, chunk, P=None, u=None, vb=None):
+    Tq, Tk = q.shape[0], k.shape[0]
+    qh = q.view(Tq, H, 64).transpose(0, 1)
+    kh = k.view(Tk, H, 64).transpose(0, 1)
+    vh = v.view(Tk, H, 64).transpose(0, 1)
+    if P is not None:
+        ph = P.view(-1, H, 64).transpose(0, 1)
+        ac = torch.matmul(qh + u.view(H, 1, 64), kh.transpose(1, 2))
+        bd = torch.matmul(qh + vb.view(H, 1, 64), ph.transpose(1, 2))
+        i = torch.arange(Tq)[:, None]
+        j = torch.arange(Tk)[None, :]
+        bd = torch.gather(bd, 2, (j - i + Tk - 1).expand(H, Tq, Tk))
+        s = (ac + bd) * scale
+    else:
+        s = torch.matmul(qh, kh.transpose(1, 2)) * scale
+    i = torch.arange(Tq)[:, None]
+    j = torch.arange(Tk)[None, :]
+    mask = torch.zeros(Tq, Tk, dtype=torch.bool)
+    if causal:
+        mask |= j > i + (Tk - Tq)
+    if chunk > 0:
+        mask |= j >= (i // chunk + 1) * chunk
+    s = s.masked_fill(mask[None], float("-inf"))
+    return torch.matmul(torch.softmax(s, -1), vh).transpose(0, 1).reshape(Tq, H * 64)
+
+
+@pytest.mark.parametrize("T,chunk", [(21, 0), (21, 8), (125, 0), (125, 16), (200, 8), (64, 0), (65, 24)])
+def test_relpos_attention(lib, T, chunk):
+    from streamspeech_amd import lib as L
+    H = 4
+    qkv = rnd(T, 3 * 256, seed=19)
+    Pt = rnd(2 * T - 1, 3 * 256, seed=20)     # padded row stride to exercise ldp
+    u, vb = rnd(256, seed=21) * 0.3, rnd(256, seed=22) * 0.3
+    dqkv, dP, du, dv = qkv.cuda(), Pt.cuda(), u.cuda(), vb.cuda()
+    out = torch.full((T, 256), float("nan"), device="cuda")
+    L.check(lib.ss_op_attention(S(), P(dqkv), 768, C.c_void_p(dqkv.data_ptr() + 256 * 4), 768,
+                                C.c_void_p(dqkv.data_ptr() + 512 * 4), 768, P(out), 256, T, T, H, 0.125, 0, chunk,
+                                C.c_void_p(dP.data_ptr() + 256 * 4), 768, P(du), P(dv)), "attn")
+    ref = _attn_ref(qkv[:, :256], qkv[:, 256:512], qkv[:, 512:], H, 0.125, False, chunk,
+                    Pt[:, 256:512].contiguous(), u, vb)
+    err = (out.cpu() - ref).abs().max()
+    assert err < 5e-5, f"{err}"
+
+
+@pytest.mark.parametrize("Tq,Tk,causal", [(130, 130, 1), (1, 37, 1), (50, 21, 0), (525, 525, 1), (9, 9, 0), (3, 40, 1)])
+def test_plain_attention(lib, Tq, Tk, causal):
+    from streamspeech_amd import lib as L
+    H = 8
+    q, k, v = rnd(Tq, 512, seed=23) * 0.3, rnd(Tk, 512, seed=24), rnd(Tk, 512, seed=25)
+    dq, dk, dv = q.cuda(), k.cuda(), v.cuda()
+    out = torch.full((Tq, 512), float("nan"), device="cuda")
+    L.check(lib.ss_op_attention(S(), P(dq), 512, P(dk), 512, P(dv), 512, P(out), 512, Tq, Tk, H, 1.0, causal, 0,
+                                None, 0, None, None), "attn")
+    ref = _attn_ref(q, k, v, H, 1.0, bool(causal), 0)
+    err = (out.cpu() - ref).abs().max()
+    assert err < 5e-5, f"{err}"
+
+
+@pytest.mark.parametrize("T,chunk", [(21, 0), (21, 8), (125, 16), (125, 0), (7, 8)])
+def test_dwconv_bn_silu(lib, T, chunk):
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import lib as L
+    Cc, K = 256, 31
+    x, w = rnd(T, Cc, seed=26), rnd(Cc, 1, K, seed=27, scale=K ** -0.5)
+    mean, var = rnd(Cc, seed=28) * 0.1, torch.rand(Cc, generator=torch.Generator().manual_seed(29)) + 0.5
+    g, b = rnd(Cc, seed=30) * 0.1 + 1, rnd(Cc, seed=31) * 0.1
+    y = O.chunk_causal_conv1d(x.t().contiguous(), w, None, 1, chunk if chunk else 999999, groups=Cc).t()
+    ref = F.silu((y - mean) / torch.sqrt(var + 1e-5) * g + b)
+    dx, dwt = x.cuda(), w[:, 0, :].t().contiguous().cuda()
+    dm, dvar, dg, db = mean.cuda(), var.cuda(), g.cuda(), b.cuda()
+    out = torch.empty_like(dx)
+    L.check(lib.ss_op_dwconv_bn_silu(S(), P(dx), Cc, P(out), Cc, P(dwt), K, P(dm), P(dvar), P(dg), P(db), 1e-5, T, Cc,
+                                     chunk), "dw")
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 2e-5

@@ -1,0 +1,158 @@
+"""GPU parity of the HIP stages (through the C ABI) against (a) the committed golden fixtures
+produced by the REFERENCE's own modules (oracle/make_golden.py) and (b) the CPU oracle on the
+same seeded inputs.  Bars (BASELINE.json north_star): identical id sequences from the CTC / MT /
+unit decoders; vocoder waveform within 1e-3 RMS; float activations within the tolerance written
+in each test.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ENC_TOL = 5e-4       # encoder_out abs error after 12 conformer layers (values are O(1) post-LN)
+FEAT_TOL = 5e-4      # decoder feature abs error
+WAV_RMS_TOL = 1e-3   # north_star: vocoder waveform within 1e-3 RMS per sample
+
+
+def _gold(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+@pytest.mark.parametrize("tag,ac,cc", [("offline", 999999, 999999), ("c8", 8, 8), ("c16", 16, 16), ("c24", 24, 16)])
+def test_encoder_vs_reference_golden(hip_model, golden_dir, tag, ac, cc):
+    from streamspeech_amd import synth
+    g = _gold(golden_dir, "encoder.npz")
+    T = int(g["T"])
+    fbank = torch.from_numpy(synth.synth_fbank(0, T)).cuda()
+    out = hip_model.encoder_forward(fbank, ac, cc).cpu().numpy()
+    ref = g[f"enc_{tag}"]
+    assert out.shape == ref.shape
+    err = np.abs(out - ref).max()
+    assert np.isfinite(out).all() and err < ENC_TOL, f"encoder {tag}: max abs err {err}"
+
+
+@pytest.mark.parametrize("T,ac,cc", [(435, 999999, 999999), (435, 8, 8), (1203, 999999, 999999), (31, 8, 8), (9, 8, 8)])
+def test_encoder_vs_oracle(hip_model, synth_weights, T, ac, cc):
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import synth
+    cfg, _, sd, _ = synth_weights
+    fb = synth.synth_fbank(7, T)
+    ref = O.encoder_forward(sd, fb, cfg, ac, cc).numpy()
+    out = hip_model.encoder_forward(torch.from_numpy(fb).cuda(), ac, cc).cpu().numpy()
+    assert out.shape == ref.shape
+    err = np.abs(out - ref).max()
+    assert err < ENC_TOL, f"T={T} chunk={ac}: {err}"
+
+
+@pytest.mark.parametrize("tag", ["offline", "c8"])
+def test_ctc_heads_identical_ids(hip_model, golden_dir, tag):
+    g = _gold(golden_dir, "encoder.npz")
+    enc = torch.from_numpy(g[f"enc_{tag}"]).cuda()
+    for head, name in ((0, "source_unigram"), (1, "ctc_target_unigram")):
+        toks, idx, raw, _ = hip_model.ctc_greedy(head, enc)
+        assert raw.tolist() == g[f"{name}_{tag}_raw"].tolist()
+        assert toks == g[f"{name}_{tag}_tokens"].tolist()
+        assert idx == g[f"{name}_{tag}_index"].tolist()
+
+
+def test_mt_decoder_features_and_greedy(hip_model, golden_dir):
+    ge, gd = _gold(golden_dir, "encoder.npz"), _gold(golden_dir, "decoders.npz")
+    enc = torch.from_numpy(ge["enc_offline"]).cuda()
+    toks = gd["mt_tokens_in"].tolist()
+    hip_model.mt_begin(enc)
+    feats, _ = hip_model.mt_append(toks, 0, ban_eos=False, force_eos=False, want_next=False)
+    err = np.abs(feats.cpu().numpy() - gd["mt_features"]).max()
+    assert err < FEAT_TOL, f"mt features: {err}"
+    # incremental (KV cache) decoding must give the same features as the one-shot pass
+    hip_model.mt_begin(enc)
+    f1, _ = hip_model.mt_append(toks[:4], 0, False, False, want_next=False)
+    f2, _ = hip_model.mt_append(toks[4:], 4, False, False, want_next=False)
+    inc = torch.cat([f1, f2]).cpu().numpy()
+    assert np.abs(inc - feats.cpu().numpy()).max() < 1e-5
+    # greedy continuation: prefix of 9 tokens, max_new_tokens = 5 (reference semantics, golden ids)
+    hip_model.mt_begin(enc)
+    start = len(toks) - 1
+    max_len = start + 5
+    seq = list(toks)
+    _, nxt = hip_model.mt_append(seq, 0, ban_eos=(start < 1), force_eos=(start >= max_len), want_feats=False)
+    gen = [nxt]
+    step = start + 1
+    while nxt != 2 and step <= max_len:
+        _, nxt = hip_model.mt_append([gen[-1]], step, ban_eos=False, force_eos=(step >= max_len), want_feats=False)
+        gen.append(nxt)
+        step += 1
+    assert toks[1:] + gen == gd["mt_greedy_prefix9_new5"].tolist()
+
+
+def test_t2u_and_unit_decoder_identical_units(hip_model, golden_dir):
+    gd = _gold(golden_dir, "decoders.npz")
+    feats = torch.from_numpy(gd["mt_features"]).cuda()
+    toks, raw, logits = hip_model.t2u_units(feats, t2u_causal=False, want_logits=True)
+    err = np.abs(logits[:8].cpu().numpy() - gd["unit_logits_first8"]).max()
+    assert err < 2e-3, f"unit logits {err}"
+    assert raw.tolist() == gd["unit_raw"].tolist()
+    units = [t - 4 for t in toks if t not in (0, 2)]
+    assert units == gd["units"].tolist()
+
+
+def test_vocoder_vs_reference_golden(hip_vocoder, golden_dir):
+    g = _gold(golden_dir, "vocoder.npz")
+    wav, dur = hip_vocoder.forward(g["codes"], dur_prediction=True)
+    assert dur.cpu().tolist() == g["dur"].tolist()
+    w = wav.cpu().numpy()
+    assert w.shape == g["wav"].shape
+    rms = float(np.sqrt(np.mean((w - g["wav"]) ** 2)))
+    assert rms < WAV_RMS_TOL and np.abs(w - g["wav"]).max() < 5e-3, f"rms {rms} max {np.abs(w - g['wav']).max()}"
+    wav1, dur1 = hip_vocoder.forward(g["codes"], dur_prediction=False)
+    assert dur1.cpu().tolist() == [1] * len(g["codes"])
+    rms1 = float(np.sqrt(np.mean((wav1.cpu().numpy() - g["wav_nodur"]) ** 2)))
+    assert rms1 < WAV_RMS_TOL, f"rms {rms1}"
+
+
+def test_vocoder_long_vs_oracle(hip_vocoder, synth_weights):
+    """~4.4 s of speech (F ~ 220 frames): full-size generator against the CPU oracle."""
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import synth
+    _, vcfg, _, vsd = synth_weights
+    codes = [int(c) for c in synth.uniform(3, "voc_codes_long", (160,), 0, 1000)]
+    rw, rd = O.vocoder_forward(vsd, codes, vcfg, True)
+    wav, dur = hip_vocoder.forward(codes, True)
+    assert dur.cpu().tolist() == rd.tolist()
+    rms = float(torch.sqrt(torch.mean((wav.cpu() - rw) ** 2)))
+    assert rms < WAV_RMS_TOL, f"rms {rms}"
+
+
+def test_fbank_cmvn_vs_oracle(hip_model, golden_dir):
+    from oracle import kaldi_fbank as K
+    from streamspeech_amd import synth
+    g = _gold(golden_dir, "gcmvn_fr-en.npz")
+    n = 16000 * 3 + 77
+    pcm = synth.synth_pcm(0, n)
+    feat = hip_model.fbank_cmvn(torch.from_numpy(pcm).cuda()).cpu().numpy()
+    ref = K.global_cmvn(K.fbank(pcm * np.float32(32768.0)), g["mean"], g["std"])
+    assert feat.shape == ref.shape
+    err = np.abs(feat - ref).max()
+    assert err < 1e-3, f"fbank max abs err {err}"
+
+
+def test_offline_utterance_units_and_wav(hip_model, hip_vocoder, synth_weights):
+    """BASELINE.json configs[1] end to end on one 4.35 s synthetic utterance: identical ASR / ST /
+    unit id sequences and waveform RMS <= 1e-3 vs the CPU oracle (teacher-forced MT tokens)."""
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import synth
+    from streamspeech_amd.pipeline import offline_s2st
+    cfg, vcfg, sd, vsd = synth_weights
+    T = 433
+    fb = synth.synth_fbank(11, T)
+    mt = [int(t) for t in synth.uniform(11, "forced_mt", (16,), 4, cfg.tgt_vocab)]
+    ref = O.offline_s2st(sd, vsd, fb, cfg, vcfg, forced_mt_tokens=mt)
+    out = offline_s2st(hip_model, hip_vocoder, torch.from_numpy(fb).cuda(), forced_mt_tokens=mt)
+    assert out["asr"] == ref["asr"]
+    assert out["st"] == ref["st"]
+    assert out["units"] == ref["units"]
+    assert out["dur"].cpu().tolist() == ref["dur"].tolist()
+    rms = float(torch.sqrt(torch.mean((out["wav"].cpu() - ref["wav"]) ** 2)))
+    assert rms < WAV_RMS_TOL, f"rms {rms}"
