@@ -114,6 +114,16 @@ int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_codes, int 
                        const int32_t* d_forced_dur, float* d_wav, int64_t wav_capacity,
                        int32_t* d_dur, int64_t* h_n_samples);
 
+/* ---- profiling hooks for bench.py's roofline leg: bracket every conv-GEMM launch whose tile
+ * configuration is in cls_mask with HIP events recorded on the launch stream.  ss_prof_read
+ * synchronises on the recorded events and returns the summed kernel time, the summed algorithmic
+ * FLOPs (2*M*N*taps*Cin per launch) and the launch count of class `cls`. */
+int ss_prof_enable(int cls_mask);
+int ss_prof_reset(void);
+int ss_prof_read(int cls, double* h_ms_total, double* h_flops_total, int64_t* h_launches);
+int ss_prof_num_classes(void);
+const char* ss_prof_class_name(int cls);
+
 /* ---- op-level entry points (unit tests of single kernels; same launchers the stages use) ---- */
 int ss_op_conv_gemm(void* stream, const float* dA, int lda, const float* dW, const float* dbias,
                     const float* dR, int ldr, const float* dR2, int ldr2, float* dC, int ldc,

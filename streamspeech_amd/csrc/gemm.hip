@@ -10,6 +10,9 @@
 // C/D layout (MI355X guide §3): col = lane&15, row = (lane>>4)*4 + reg.
 #include "gemm.hpp"
 
+#include <utility>
+#include <vector>
+
 namespace ss {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -196,12 +199,53 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
     }
 }
 
+// ---- optional event profiler -------------------------------------------------------------------
+static const char* kTileNames[kNumTileCfg] = {
+    "conv_gemm<128,16,16,4,1>", "conv_gemm<128,32,32,4,1>", "conv_gemm<128,32,16,4,1>", "conv_gemm<16,128,32,1,4>",
+    "conv_gemm<16,128,16,1,4>", "conv_gemm<128,128,16,2,2>", "conv_gemm<128,64,32,2,2>", "conv_gemm<64,64,32,2,2>",
+    "conv_gemm<64,64,16,2,2>", "conv_gemm<32,64,32,2,2>", "conv_gemm<32,64,16,2,2>", "reserved"};
+struct ProfRec { hipEvent_t e0, e1; double flops; int cls; };
+static int g_prof_mask = 0;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+
+void prof_enable(int cls_mask) { g_prof_mask = cls_mask; }
+const char* prof_cfg_name(int cls) { return (cls >= 0 && cls < kNumTileCfg) ? kTileNames[cls] : "?"; }
+void prof_reset() {
+  for (auto& r : g_prof_recs) g_prof_pool.push_back({r.e0, r.e1});
+  g_prof_recs.clear();
+}
+int prof_read(int cls, double* ms_total, double* flops_total, long long* launches) {
+  double ms = 0, fl = 0; long long n = 0;
+  for (auto& r : g_prof_recs) {
+    if (r.cls != cls) continue;
+    if (hipEventSynchronize(r.e1) != hipSuccess) return SS_ERR_HIP;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return SS_ERR_HIP;
+    ms += t; fl += r.flops; ++n;
+  }
+  if (ms_total) *ms_total = ms;
+  if (flops_total) *flops_total = fl;
+  if (launches) *launches = n;
+  return SS_OK;
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
-static int launch_cfg(const GemmArgs& a, hipStream_t stream) {
+static int launch_cfg(const GemmArgs& a, hipStream_t stream, int cls) {
   const int mmax = a.nseg > 0 ? a.max_seg_out : a.M;
   dim3 grid(cdiv(mmax, BM), cdiv(a.N, BN), a.nseg > 0 ? a.nseg : 1);
+  const bool prof = (g_prof_mask >> cls) & 1;
+  ProfRec rec{};
+  if (prof) {
+    if (!g_prof_pool.empty()) { rec.e0 = g_prof_pool.back().first; rec.e1 = g_prof_pool.back().second; g_prof_pool.pop_back(); }
+    else { SS_HIP_CHECK(hipEventCreate(&rec.e0)); SS_HIP_CHECK(hipEventCreate(&rec.e1)); }
+    rec.cls = cls;
+    rec.flops = a.algo_flops > 0 ? a.algo_flops : 2.0 * (double)a.M * a.N * a.taps * a.Cin;
+    SS_HIP_CHECK(hipEventRecord(rec.e0, stream));
+  }
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(256), 0, stream, a);
   SS_LAUNCH_CHECK();
+  if (prof) { SS_HIP_CHECK(hipEventRecord(rec.e1, stream)); g_prof_recs.push_back(rec); }
   return SS_OK;
 }
 
@@ -212,22 +256,22 @@ int launch_conv_gemm(const GemmArgs& a, hipStream_t stream) {
   if (a.glu && (a.N % 32 != 0)) return SS_ERR_ARG;
   const bool k32 = (a.Cin % 32) == 0;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
-  if (a.N <= 16) return launch_cfg<128, 16, 16, 4, 1>(a, stream);
+  if (a.N <= 16) return launch_cfg<128, 16, 16, 4, 1>(a, stream, 0);
   if (a.N <= 32 && !a.glu) {
-    return k32 ? launch_cfg<128, 32, 32, 4, 1>(a, stream) : launch_cfg<128, 32, 16, 4, 1>(a, stream);
+    return k32 ? launch_cfg<128, 32, 32, 4, 1>(a, stream, 1) : launch_cfg<128, 32, 16, 4, 1>(a, stream, 2);
   }
   if (M <= 16) {
-    return k32 ? launch_cfg<16, 128, 32, 1, 4>(a, stream) : launch_cfg<16, 128, 16, 1, 4>(a, stream);
+    return k32 ? launch_cfg<16, 128, 32, 1, 4>(a, stream, 3) : launch_cfg<16, 128, 16, 1, 4>(a, stream, 4);
   }
   const long t128 = (long)cdiv(M, 128) * cdiv(a.N, 128) * nseg;
   const long t12864 = (long)cdiv(M, 128) * cdiv(a.N, 64) * nseg;
   const long t64 = (long)cdiv(M, 64) * cdiv(a.N, 64) * nseg;
-  if (t128 >= 192) return launch_cfg<128, 128, 16, 2, 2>(a, stream);
-  if (t12864 >= 192 && k32) return launch_cfg<128, 64, 32, 2, 2>(a, stream);
+  if (t128 >= 192) return launch_cfg<128, 128, 16, 2, 2>(a, stream, 5);
+  if (t12864 >= 192 && k32) return launch_cfg<128, 64, 32, 2, 2>(a, stream, 6);
   if (t64 >= 160 || M > 256) {
-    return k32 ? launch_cfg<64, 64, 32, 2, 2>(a, stream) : launch_cfg<64, 64, 16, 2, 2>(a, stream);
+    return k32 ? launch_cfg<64, 64, 32, 2, 2>(a, stream, 7) : launch_cfg<64, 64, 16, 2, 2>(a, stream, 8);
   }
-  return k32 ? launch_cfg<32, 64, 32, 2, 2>(a, stream) : launch_cfg<32, 64, 16, 2, 2>(a, stream);
+  return k32 ? launch_cfg<32, 64, 32, 2, 2>(a, stream, 9) : launch_cfg<32, 64, 16, 2, 2>(a, stream, 10);
 }
 
 }  // namespace ss

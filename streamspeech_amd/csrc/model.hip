@@ -601,6 +601,7 @@ extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_
     a.A = bx; a.lda = C; a.W = v->ups[i].w; a.bias = v->ups[i].b; a.C = bs; a.ldc = st * Co;
     a.M = T; a.N = st * Co; a.Cin = C; a.taps = 3; a.dil = 1; a.stride = 1; a.pad = 1; a.in_len = T;
     a.in_act = ACT_LRELU; a.in_slope = 0.1f;
+    a.algo_flops = 2.0 * T * C * Co * c.upsample_kernel_sizes[i];   // zero-padded polyphase slots are not work
     RET(launch_conv_gemm(a, s));
     T *= st; C = Co;
     for (int j = 0; j < c.n_res; ++j) {
@@ -659,3 +660,14 @@ extern "C" int ss_op_dwconv_bn_silu(void* stream, const float* dx, int ldx, floa
                                     const float* beta, float eps, int T, int C, int chunk) {
   return launch_dwconv_bn_silu(dx, ldx, dy, ldy, dwt, K, mean, var, gamma, beta, eps, T, C, chunk, (hipStream_t)stream);
 }
+
+extern "C" int ss_prof_enable(int cls_mask) { prof_enable(cls_mask); return SS_OK; }
+extern "C" int ss_prof_reset(void) { prof_reset(); return SS_OK; }
+extern "C" int ss_prof_read(int cls, double* ms, double* flops, int64_t* launches) {
+  long long n = 0;
+  int rc = prof_read(cls, ms, flops, &n);
+  if (launches) *launches = n;
+  return rc;
+}
+extern "C" int ss_prof_num_classes(void) { return kNumTileCfg; }
+extern "C" const char* ss_prof_class_name(int cls) { return prof_cfg_name(cls); }
