@@ -1,0 +1,335 @@
+"""StreamSpeechS2STAgent -- drop-in for the reference SimulEval agent
+(agent/speech_to_speech.streamspeech.agent.py:101-770) with the model math on MI355X.
+
+Same class name, ``@entrypoint``, ``add_args`` flags, ``reset`` / ``policy`` contract
+(``ReadAction`` | ``WriteAction(SpeechSegment(content=list[float], sample_rate=16000, finished))``)
+and the same read/write gating; every tensor op of the reference policy is replaced by a C-ABI
+stage (fbank -> encoder -> CTC x2 -> MT greedy -> T2U + unit decoder -> vocoder).  Like the
+reference it recomputes the whole utterance-so-far on every call (incremental state
+is the next step, not parity-affecting).
+"""
+import json
+import os
+from pathlib import Path
+
+import numpy as np
+import torch
+import yaml
+
+from .frontend import FEATURE_DIM, ORG_SAMPLE_RATE, SAMPLE_RATE, SHIFT_SIZE, WINDOW_SIZE, OnlineFeatureExtractor
+from .generators import CTCDecoder, CTCSequenceGenerator, SequenceGenerator
+from .modules import CodeHiFiGANVocoderWithDur, Dictionary, StreamSpeechModel, load_model_state
+from .simuleval_shim import ReadAction, SpeechSegment, SpeechToSpeechAgent, WriteAction, entrypoint
+
+DEFAULT_EOS = 2
+
+
+def _detok(symbols):
+    text = "".join(symbols)
+    for a, b in (("_", " "), ("▁", " "), ("<unk>", " "), ("<s>", ""), ("</s>", "")):
+        text = text.replace(a, b)
+    return text[1:] if len(text) > 0 and text[0] == " " else text
+
+
+@entrypoint
+class StreamSpeechS2STAgent(SpeechToSpeechAgent):
+    """Simultaneous speech-to-speech translation agent for StreamSpeech on the HIP backend."""
+
+    def __init__(self, args, model=None, vocoder=None):
+        super().__init__(args)
+        self.eos = DEFAULT_EOS
+        self.args = args
+        self.gpu = True
+        self.device = getattr(args, "device_str", "cuda:0")
+        self.load_model_vocab(args, model)
+        self.max_len = args.max_len
+        self.force_finish = args.force_finish
+        torch.set_grad_enabled(False)
+
+        eng = self.model.hip if hasattr(self.model, "hip") else self.model
+        self.engine = eng
+        tgt_dict_mt = self.dict[self.model.mt_task_name]
+        tgt_dict = self.dict["tgt"]
+        uni = getattr(self.model, "uni_encoder", False)
+        self.ctc_generator = CTCSequenceGenerator(tgt_dict, eng, use_incremental_states=False, t2u_causal=uni)
+        self.asr_ctc_generator = CTCDecoder(self.dict["source_unigram"], eng, 0)
+        self.st_ctc_generator = CTCDecoder(self.dict["ctc_target_unigram"], eng, 1)
+        # generator_mt of the reference: beam 1, max_len_a=0, max_len_b=100, min_len=1 (agent :162-180)
+        self.generator_mt = SequenceGenerator(eng, tgt_dict_mt, beam_size=1, max_len_a=0, max_len_b=100, max_len=0,
+                                              min_len=1, eos=tgt_dict_mt.eos(), use_incremental_states=False)
+        if vocoder is not None:
+            self.vocoder = vocoder
+        else:
+            vcfg = None
+            if args.vocoder_cfg and os.path.exists(args.vocoder_cfg):
+                with open(args.vocoder_cfg) as f:
+                    vcfg = json.load(f)
+            self.vocoder = CodeHiFiGANVocoderWithDur(args.vocoder, vcfg, device=self.device)
+        self.dur_prediction = args.dur_prediction
+        self.lagging_k1, self.lagging_k2 = args.lagging_k1, args.lagging_k2
+        self.segment_size = args.segment_size
+        self.stride_n, self.stride_n2 = args.stride_n, args.stride_n2
+        self.unit_per_subword = args.unit_per_subword
+        if args.extra_output_dir is not None:
+            self.asr_file = Path(args.extra_output_dir + "/asr.txt")
+            self.st_file = Path(args.extra_output_dir + "/st.txt")
+            self.unit_file = Path(args.extra_output_dir + "/unit.txt")
+            self.quiet = False
+        else:
+            self.quiet = True
+        self.output_asr_translation = args.output_asr_translation
+        self.whole_word = args.source_segment_size >= 640
+        self.reset()
+
+    @staticmethod
+    def add_args(parser):
+        a = parser.add_argument
+        a("--model-path", type=str, required=True, help="path to your pretrained model (or synthetic:<seed>)")
+        a("--data-bin", type=str, required=True, help="Path of data binary")
+        a("--config-yaml", type=str, default=None, help="Path to config yaml file")
+        a("--multitask-config-yaml", type=str, default=None, help="Path to config yaml file")
+        a("--global-stats", type=str, default=None, help="Path to json file containing cmvn stats")
+        a("--tgt-splitter-type", type=str, default="SentencePiece", help="Subword splitter type for target text")
+        a("--tgt-splitter-path", type=str, default=None, help="Subword splitter model path for target text")
+        a("--user-dir", type=str, default="researches/ctc_unity", help="User directory for model")
+        a("--agent-dir", type=str, default="agent", help="User directory for agents")
+        a("--max-len", type=int, default=200, help="Max length of translation")
+        a("--force-finish", default=False, action="store_true", help="Force the model to finish the hypothsis")
+        a("--shift-size", type=int, default=SHIFT_SIZE, help="Shift size of feature extraction window.")
+        a("--window-size", type=int, default=WINDOW_SIZE, help="Window size of feature extraction window.")
+        a("--sample-rate", type=int, default=ORG_SAMPLE_RATE, help="Sample rate")
+        a("--feature-dim", type=int, default=FEATURE_DIM, help="Acoustic feature dimension.")
+        a("--vocoder", type=str, required=True, help="path to the CodeHiFiGAN vocoder (or synthetic:<seed>)")
+        a("--vocoder-cfg", type=str, required=False, default=None, help="path to the CodeHiFiGAN vocoder config")
+        a("--dur-prediction", action="store_true", help="enable duration prediction (for reduced/unique code sequences)")
+        a("--lagging-k1", type=int, default=0, help="lagging number")
+        a("--lagging-k2", type=int, default=0, help="lagging number")
+        a("--segment-size", type=int, default=320, help="segment-size")
+        a("--stride-n", type=int, default=1, help="lagging number")
+        a("--stride-n2", type=int, default=1, help="lagging number")
+        a("--unit-per-subword", type=int, default=15, help="lagging number")
+        a("--extra-output-dir", type=str, default=None, help="extra output dir")
+        a("--output-asr-translation", type=bool, default=False, help="extra output dir")
+
+    def reset(self):
+        self.src_seg_num = 0
+        self.tgt_subwords_indices = None
+        self.src_ctc_indices = None
+        self.src_ctc_prefix_length = 0
+        self.tgt_ctc_prefix_length = 0
+        self.tgt_units_indices = None
+        self.prev_output_tokens_mt = None
+        self.tgt_text = []
+        self.mt_decoder_out = None
+        self.unit = None
+        self.wav = []
+        self.post_transcription = ""
+        self.unfinished_wav = None
+        self.states.reset()
+        try:
+            self.generator_mt.reset_incremental_states()
+            self.ctc_generator.reset_incremental_states()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def load_model_vocab(self, args, model=None):
+        """agent :355-420: checkpoint -> model, CMVN stats, dictionaries, chunk sizes."""
+        args.global_cmvn = None
+        config = {}
+        if args.config_yaml is not None:
+            ypath = os.path.join(args.data_bin, args.config_yaml)
+            if os.path.exists(ypath):
+                with open(ypath, "r") as f:
+                    config = yaml.load(f, Loader=yaml.BaseLoader) or {}
+                if "global_cmvn" in config:
+                    npz = config["global_cmvn"]["stats_npz_path"]
+                    if not os.path.exists(npz):  # reference YAMLs hold absolute paths of the authors' machine
+                        npz = os.path.join(args.data_bin, os.path.basename(npz))
+                    args.global_cmvn = np.load(npz)
+        if args.global_cmvn is None and getattr(args, "global_stats", None):
+            args.global_cmvn = np.load(args.global_stats)
+        if model is None:
+            sd, uni = load_model_state(args.model_path)     # raises IOError("Model file not found") like the agent
+            model = StreamSpeechModel(sd, device=self.device, cmvn=args.global_cmvn, uni_encoder=uni)
+        self.model = model
+        self.models = [model]
+        eng = model.hip if hasattr(model, "hip") else model
+        self.feature_extractor = OnlineFeatureExtractor(args, eng)
+
+        chunk_size = args.source_segment_size // 40
+        model.encoder.chunk_size = chunk_size
+        conv_chunk = 16 if chunk_size >= 16 else 8
+        for conv in model.encoder.subsample.conv_layers:
+            conv.chunk_size = conv_chunk
+        for layer in model.encoder.conformer_layers:
+            layer.conv_module.depthwise_conv.chunk_size = conv_chunk
+
+        # dictionaries: target units + the three multitask text dictionaries
+        self.dict = {"tgt": Dictionary.units(1000)}
+        mt_cfg = {}
+        if args.multitask_config_yaml is not None:
+            mpath = os.path.join(args.data_bin, args.multitask_config_yaml)
+            if os.path.exists(mpath):
+                with open(mpath) as f:
+                    mt_cfg = yaml.load(f, Loader=yaml.BaseLoader) or {}
+        cfg = eng.cfg
+        for name, n in (("target_unigram", cfg.tgt_vocab), ("source_unigram", cfg.src_vocab),
+                        ("ctc_target_unigram", cfg.tgt_vocab)):
+            path = (mt_cfg.get(name) or {}).get("dict")
+            if path and not os.path.exists(path):
+                path = os.path.join(args.data_bin, *Path(path).parts[-2:])
+            self.dict[name] = Dictionary.load(path) if path and os.path.exists(path) else Dictionary.placeholder(n)
+
+    @torch.inference_mode()
+    def policy(self):
+        feature = self.feature_extractor(self.states.source)
+        if feature.size(0) == 0 and not self.states.source_finished:
+            return ReadAction()
+        if feature.size(0) < 1:
+            return self._finish_empty() if self.states.source_finished else ReadAction()
+
+        src_indices = feature.unsqueeze(0)
+        src_lengths = torch.tensor([feature.size(0)]).long()
+        model = self.model
+        encoder_out = model.encoder(src_indices, src_lengths)
+        self.encoder_outs = [encoder_out]
+
+        # ASR / ST CTC heads (agent :437-478)
+        finalized_asr = self.asr_ctc_generator.generate(encoder_out, aux_task_name="source_unigram")
+        src_ctc_indices = finalized_asr[0][0]["tokens"].int()
+        if (self.states.source_finished and not self.quiet) or self.output_asr_translation:
+            text = _detok([self.dict["source_unigram"][c] for c in src_ctc_indices])
+            if self.states.source_finished and not self.quiet:
+                with open(self.asr_file, "a") as f:
+                    print(text, file=f)
+            if self.output_asr_translation:
+                print("Streaming ASR:", text)
+        finalized_st = self.st_ctc_generator.generate(encoder_out, aux_task_name="ctc_target_unigram")
+        tgt_ctc_indices = finalized_st[0][0]["tokens"].int()
+
+        # read/write gate on the CTC token counts (agent :480-512)
+        if not self.states.source_finished:
+            src_ctc_prefix_length = src_ctc_indices.size(-1)
+            tgt_ctc_prefix_length = tgt_ctc_indices.size(-1)
+            self.src_ctc_indices = src_ctc_indices
+            if (src_ctc_prefix_length < self.src_ctc_prefix_length + self.stride_n
+                    or tgt_ctc_prefix_length < self.tgt_ctc_prefix_length + self.stride_n):
+                return ReadAction()
+            self.src_ctc_prefix_length = max(src_ctc_prefix_length, self.src_ctc_prefix_length)
+            self.tgt_ctc_prefix_length = max(tgt_ctc_prefix_length, self.tgt_ctc_prefix_length)
+            subword_tokens = ((tgt_ctc_prefix_length - self.lagging_k1) // self.stride_n) * self.stride_n
+            if self.whole_word:
+                subword_tokens += 1
+            new_subword_tokens = (subword_tokens - self.tgt_subwords_indices.size(-1)
+                                  if self.tgt_subwords_indices is not None else subword_tokens)
+            if new_subword_tokens < 1:
+                return ReadAction()
+        else:
+            self.src_ctc_indices = src_ctc_indices
+            new_subword_tokens = -1
+        new_subword_tokens = int(new_subword_tokens)
+
+        # 1. MT decoder: greedy continuation of the committed prefix (agent :520-538)
+        finalized_mt = self.generator_mt.generate_decoder(
+            self.encoder_outs, src_indices, src_lengths, {"id": 1}, self.tgt_subwords_indices, None, None,
+            aux_task_name=model.mt_task_name, max_new_tokens=new_subword_tokens)
+        hyp = finalized_mt[0][0]
+        if hyp["tokens"][-1] == 2:
+            tgt_subwords_indices = hyp["tokens"][:-1].unsqueeze(0)
+        else:
+            tgt_subwords_indices = hyp["tokens"].unsqueeze(0)
+
+        if self.whole_word:  # agent :540-574 (the KV-cache surgery there is dead code: no incremental states)
+            if not self.states.source_finished:
+                j = 999999
+                for j in range(tgt_subwords_indices.size(-1) - 1, -1, -1):
+                    if self.generator_mt.tgt_dict[tgt_subwords_indices[0][j]].startswith("▁"):
+                        break
+                tgt_subwords_indices = tgt_subwords_indices[:, :j]
+                hyp["tokens"] = hyp["tokens"][:j]
+                if j == 0:
+                    return ReadAction()
+
+        tmp = hyp["tokens"].int()
+        if len(tmp) > 0 and tmp[-1] == self.generator_mt.eos:
+            tmp = tmp[:-1]
+        n_tail_pad = 1 if self.whole_word else 0
+        prev_output_tokens_mt = torch.full((1, len(tmp) + 1 + n_tail_pad), self.model.target_unigram_decoder.padding_idx
+                                           if hasattr(self.model, "target_unigram_decoder") else 1, dtype=torch.int32)
+        prev_output_tokens_mt[0, 0] = self.generator_mt.eos
+        prev_output_tokens_mt[0, 1:len(tmp) + 1] = tmp
+        if (self.states.source_finished and not self.quiet) or self.output_asr_translation:
+            text = _detok([self.generator_mt.tgt_dict[c] for c in tmp])
+            if self.states.source_finished and not self.quiet:
+                with open(self.st_file, "a") as f:
+                    print(text, file=f)
+            if self.output_asr_translation:
+                print("Simultaneous translation:", text)
+
+        if self.tgt_subwords_indices is not None and torch.equal(self.tgt_subwords_indices, tgt_subwords_indices):
+            if not self.states.source_finished:
+                return ReadAction()
+            return self._finish_empty()
+        self.tgt_subwords_indices = tgt_subwords_indices
+
+        if not self.states.source_finished and self.prev_output_tokens_mt is not None:
+            if (torch.equal(self.prev_output_tokens_mt, prev_output_tokens_mt)
+                    or prev_output_tokens_mt.size(-1) <= self.prev_output_tokens_mt.size(-1)):
+                return ReadAction()
+        self.prev_output_tokens_mt = prev_output_tokens_mt
+
+        # MT decoder states of [eos, tokens...] = the features the greedy pass already produced
+        # (causal: a prefix slice is exact); the reference recomputes them (agent :638-651).
+        mt_feats = hyp["features"][: len(tmp) + 1]
+        if n_tail_pad:
+            raise NotImplementedError(
+                "source_segment_size >= 640 (whole-word mode) feeds one trailing <pad> position through the "
+                "decoders (agent :576-584); trailing-pad masking is not wired into the HIP stages yet")
+        self.mt_decoder_out = mt_feats
+
+        # 2+3. T2U encoder + CTC unit decoder + CTC search (agent :661-689)
+        finalized = self.ctc_generator.generate(mt_feats, prefix=self.tgt_units_indices)
+        if len(finalized[0][0]["tokens"]) == 0:
+            if not self.states.source_finished:
+                return ReadAction()
+            return self._finish_empty()
+        tmp_u = finalized[0][0]["tokens"].int()
+        if tmp_u[-1] == self.eos:
+            tmp_u = tmp_u[:-1]
+        unit = []
+        for c in tmp_u:
+            u = self.dict["tgt"][c].replace("<s>", "").replace("</s>", "")
+            if u != "":
+                unit.append(int(u))
+        if self.states.source_finished and not self.quiet:
+            with open(self.unit_file, "a") as f:
+                print(" ".join(str(_) for _ in unit), file=f)
+        cur_unit = unit if self.unit is None else unit[len(self.unit):]
+        if len(unit) < 1 or len(cur_unit) < 1:
+            if not self.states.source_finished:
+                return ReadAction()
+            return self._finish_empty()
+
+        # 4. vocoder over ALL units so far; emit the tail that belongs to the new units (agent :743-753)
+        x = {"code": torch.tensor(unit, dtype=torch.long).view(1, -1)}
+        wav, dur = self.vocoder(x, self.dur_prediction)
+        cur_wav_length = int(dur[:, -len(cur_unit):].sum()) * 320
+        new_wav = wav[-cur_wav_length:]
+        if self.unfinished_wav is not None and len(self.unfinished_wav) > 0:
+            new_wav = torch.cat((self.unfinished_wav, new_wav), dim=0)
+        self.wav = wav
+        self.unit = unit
+
+        if self.states.source_finished and new_subword_tokens == -1:
+            self.states.target_finished = True
+            # self.reset() in the reference (agent :759-761) also clears the states; kept
+            self.reset()
+        return WriteAction(
+            SpeechSegment(content=new_wav.tolist(), sample_rate=SAMPLE_RATE, finished=self.states.source_finished),
+            finished=self.states.target_finished)
+
+    def _finish_empty(self):
+        return WriteAction(
+            SpeechSegment(content=(self.unfinished_wav.tolist() if self.unfinished_wav is not None else []),
+                          sample_rate=SAMPLE_RATE, finished=True),
+            finished=True)

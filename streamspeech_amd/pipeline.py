@@ -77,3 +77,14 @@ def offline_s2st(model: HipModel, vocoder: HipVocoder, fbank: torch.Tensor, attn
         wav, dur = vocoder.forward(units, dur_prediction)
         out["wav"], out["dur"] = wav, dur
     return out
+
+
+def ctc_collapse_host(ids: List[int], blank: int, pad: int):
+    """Host twin of the device CTC collapse (agent/ctc_decoder.py:66-88), used only when a caller
+    splices a prefix into the raw argmax sequence."""
+    toks, index = [], []
+    for i, v in enumerate(ids):
+        if (i == 0 or v != ids[i - 1]) and v != blank and v != pad:
+            toks.append(v)
+            index.append(i)
+    return toks, index

@@ -1,0 +1,85 @@
+"""Host control flow of the SimulEval agent (policy gating, generators, registry surface) on CPU
+with the oracle-backed engine: no GPU, no HIP compute."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from streamspeech_amd import synth
+from streamspeech_amd.modules import (ARCH_MODEL_REGISTRY, MODEL_REGISTRY, TASK_REGISTRY, StreamSpeechModel)
+from streamspeech_amd.simuleval_shim import ReadAction, SpeechSegment, WriteAction
+from tests.oracle_engine import OracleEngine, OracleVocoder
+
+
+def make_args(segment_ms=320, **over):
+    from streamspeech_amd.agent import StreamSpeechS2STAgent
+    p = argparse.ArgumentParser()
+    StreamSpeechS2STAgent.add_args(p)
+    a = p.parse_args(["--model-path", "synthetic:0", "--data-bin", "/nonexistent", "--vocoder", "synthetic:0",
+                      "--dur-prediction", "--sample-rate", "16000"])
+    a.source_segment_size = segment_ms
+    a.device = "gpu"
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def stream(agent, pcm, segment_ms=320, sr=16000):
+    """Mimics SentenceLevelEvaluator: send_source(chunk) -> pushpop -> collect (evaluator.py:216-235)."""
+    step = sr * segment_ms // 1000
+    out, actions = [], []
+    pos = 0
+    while True:
+        chunk = pcm[pos:pos + step]
+        pos += step
+        finished = pos >= len(pcm)
+        seg = agent.pushpop(SpeechSegment(content=chunk.tolist(), sample_rate=sr, finished=finished))
+        actions.append("R" if seg.is_empty else "W")
+        if not seg.is_empty:
+            out.append(np.asarray(seg.content, np.float32))
+        if finished:
+            break
+    return (np.concatenate(out) if out else np.zeros(0, np.float32)), actions
+
+
+def test_registry_names():
+    assert "streamspeech" in MODEL_REGISTRY and "streamspeech" in ARCH_MODEL_REGISTRY
+    assert "CodeHiFiGANVocoderWithDur" in MODEL_REGISTRY and "speech_to_speech_ctc" in TASK_REGISTRY
+
+
+def test_missing_model_raises_ioerror():
+    from streamspeech_amd.modules import load_model_state
+    with pytest.raises(IOError):
+        load_model_state("/nonexistent/streamspeech.pt")
+
+
+def test_agent_streaming_control_flow(synth_weights):
+    from streamspeech_amd.agent import StreamSpeechS2STAgent
+    cfg, vcfg, sd, vsd = synth_weights
+    model = StreamSpeechModel.from_engine(OracleEngine(sd, cfg))
+    agent = StreamSpeechS2STAgent(make_args(320), model=model, vocoder=OracleVocoder(vsd, vcfg))
+    # the agent imposes the chunk sizes on the model (agent :395-413)
+    assert model.encoder.chunk_size == 8 and model.encoder._conv_chunk() == 8
+    pcm = synth.synth_pcm(3, 16000 * 2)
+    wav, actions = stream(agent, pcm)
+    assert len(actions) == 7                      # ceil(2 s / 320 ms) policy calls
+    assert "W" in actions and len(wav) > 0 and len(wav) % 320 == 0
+    assert np.isfinite(wav).all() and np.abs(wav).max() <= 1.0
+    # a second utterance after reset() starts from scratch
+    wav2, actions2 = stream(agent, pcm)
+    assert actions2 == actions and np.array_equal(wav, wav2)
+
+
+def test_policy_returns_action_types(synth_weights):
+    from streamspeech_amd.agent import StreamSpeechS2STAgent
+    cfg, vcfg, sd, vsd = synth_weights
+    model = StreamSpeechModel.from_engine(OracleEngine(sd, cfg))
+    agent = StreamSpeechS2STAgent(make_args(320), model=model, vocoder=OracleVocoder(vsd, vcfg))
+    agent.states.source = synth.synth_pcm(3, 100).tolist()   # < one frame
+    assert isinstance(agent.policy(), ReadAction)
+    agent.states.source = synth.synth_pcm(3, 16000).tolist()
+    agent.states.source_finished = True
+    act = agent.policy()
+    assert isinstance(act, WriteAction) and isinstance(act.content, SpeechSegment)
+    assert act.content.sample_rate == 16000

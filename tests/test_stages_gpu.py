@@ -156,3 +156,36 @@ def test_offline_utterance_units_and_wav(hip_model, hip_vocoder, synth_weights):
     assert out["dur"].cpu().tolist() == ref["dur"].tolist()
     rms = float(torch.sqrt(torch.mean((out["wav"].cpu() - ref["wav"]) ** 2)))
     assert rms < WAV_RMS_TOL, f"rms {rms}"
+
+
+@pytest.mark.parametrize("segment_ms", [320])
+def test_streaming_agent_matches_oracle_agent(hip_model, hip_vocoder, synth_weights, segment_ms):
+    """BASELINE.json configs[2]: simultaneous S2ST, chunk = 320 ms, wait-k policy, full recompute
+    per chunk (reference semantics).  The HIP-backed agent and the same agent over the CPU oracle
+    must take the same READ/WRITE decisions and emit the same speech (RMS <= 1e-3), given the same
+    fbank features (the north-star parity contract is 'on the same fbank input')."""
+    from streamspeech_amd import synth
+    from streamspeech_amd.agent import StreamSpeechS2STAgent
+    from streamspeech_amd.modules import CodeHiFiGANVocoderWithDur, StreamSpeechModel
+    from tests.oracle_engine import OracleEngine, OracleVocoder
+    from tests.test_agent_cpu import make_args, stream
+    cfg, vcfg, sd, vsd = synth_weights
+
+    class HipVocSurface:  # CodeHiFiGANVocoderWithDur call surface over the shared fixture handle
+        def __init__(self, hv):
+            self.hip = hv
+        __call__ = CodeHiFiGANVocoderWithDur.__call__
+
+    hip_agent = StreamSpeechS2STAgent(make_args(segment_ms), model=StreamSpeechModel.from_engine(hip_model),
+                                      vocoder=HipVocSurface(hip_vocoder))
+    ora = OracleEngine(sd, cfg)
+    ora.fbank_cmvn = lambda pcm, scale=32768.0: hip_model.fbank_cmvn(pcm.to(hip_model.device), scale).cpu()
+    ora_agent = StreamSpeechS2STAgent(make_args(segment_ms), model=StreamSpeechModel.from_engine(ora),
+                                      vocoder=OracleVocoder(vsd, vcfg))
+    pcm = synth.synth_pcm(17, int(16000 * 2.6))
+    w_hip, a_hip = stream(hip_agent, pcm, segment_ms)
+    w_ora, a_ora = stream(ora_agent, pcm, segment_ms)
+    assert a_hip == a_ora, (a_hip, a_ora)
+    assert w_hip.shape == w_ora.shape
+    rms = float(np.sqrt(np.mean((w_hip - w_ora) ** 2)))
+    assert rms < WAV_RMS_TOL, f"rms {rms}"
