@@ -145,10 +145,65 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
   }
 }
 
+
+// -------------------------------------------------------------------------------------------------
+// Decode form (Tq <= 8, e.g. one new MT token against the KV cache): one wave64 per (query, head),
+// no LDS, no barriers.  Scores: lane = key, the 64-d query is wave-uniform (scalar loads), each lane
+// streams its key row (256 contiguous bytes).  P.V: lane = output dim, probabilities broadcast with
+// v_readlane, V rows read coalesced.  Same online softmax as the tiled kernel.
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void attention_decode_kernel(const AttnArgs p) {
+  const int lane = threadIdx.x;
+  const int i = blockIdx.x, h = blockIdx.y;
+  const int hoff = h * DH;
+  const int qoff = p.Tk - p.Tq;
+  const float* q = p.Q + (size_t)i * p.ldq + hoff;
+  int kmax = p.Tk;
+  if (p.causal) kmax = min(kmax, i + qoff + 1);
+  if (p.chunk > 0) kmax = min(kmax, (i / p.chunk + 1) * p.chunk);
+  float m_run = -INFINITY, l_run = 0.f, acc = 0.f;
+  for (int j0 = 0; j0 < kmax; j0 += 64) {
+    const int j = j0 + lane;
+    const bool vis = j < kmax;
+    float s = 0.f;
+    if (vis) {
+      const float4* kr = reinterpret_cast<const float4*>(p.K + (size_t)j * p.ldk + hoff);
+#pragma unroll
+      for (int d4 = 0; d4 < DH / 4; ++d4) {
+        const float4 kv = kr[d4];
+        s = fmaf(q[4 * d4 + 0], kv.x, s); s = fmaf(q[4 * d4 + 1], kv.y, s);
+        s = fmaf(q[4 * d4 + 2], kv.z, s); s = fmaf(q[4 * d4 + 3], kv.w, s);
+      }
+    }
+    const float sv = vis ? s * p.scale : -INFINITY;
+    const float mn = fmaxf(m_run, wave_max(sv));
+    const float pe = vis ? expf(sv - mn) : 0.f;
+    const float corr = (m_run > -INFINITY) ? expf(m_run - mn) : 0.f;
+    l_run = l_run * corr + wave_sum(pe);
+    acc *= corr;
+    m_run = mn;
+    const int cnt = min(64, kmax - j0);
+    for (int jj0 = 0; jj0 < cnt; jj0 += 16) {   // 16 independent row loads in flight, then the FMAs
+      float vv[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        vv[u] = (jj0 + u < cnt) ? p.V[(size_t)(j0 + jj0 + u) * p.ldv + hoff + lane] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc = fmaf(rdlane(pe, jj0 + u), vv[u], acc);
+    }
+  }
+  p.O[(size_t)i * p.ldo + hoff + lane] = acc / l_run;
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if (a.Tq <= 0 || a.Tk <= 0) return SS_OK;
   if ((a.ldk & 3) || (a.ldv & 3)) return SS_ERR_ARG;
   dim3 grid(cdiv(a.Tq, QB), a.H);
+  if (!a.P && a.Tq <= 8) {
+    hipLaunchKernelGGL(attention_decode_kernel, dim3(a.Tq, a.H), dim3(64), 0, stream, a);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+  }
   if (a.P) {
     if (a.Tq != a.Tk || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
     hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, stream, a);

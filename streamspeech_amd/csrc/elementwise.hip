@@ -144,18 +144,20 @@ int launch_gather_rows(const int* idx, const float* table, int D, float* out, in
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void masked_argmax_kernel(const float* __restrict__ logits, int ld, int M, int N,
                                                             int mask0, int mask1, int mask2, int force, int* ids) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
-  if (force >= 0) { if (lane == 0) ids[row] = force; return; }
+  // one workgroup per row: 256 threads stride over the vocabulary, wave shuffle + LDS reduce
+  __shared__ float sb[4];
+  __shared__ int si[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int row = blockIdx.x;
+  if (force >= 0) { if (t == 0) ids[row] = force; return; }
   const float* r = logits + (size_t)row * ld;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int n = lane; n < N; n += 64) {
+  for (int n = t; n < N; n += 256) {
     if (n == mask0 || n == mask1 || n == mask2) continue;
     const float v = r[n];
     if (v != v) continue;  // NaN -> -inf (agent/sequence_generator.py:350)
-    if (bi == 0x7fffffff || v > best) { best = v; bi = n; }  // n ascends per lane: first max wins
+    if (bi == 0x7fffffff || v > best) { best = v; bi = n; }  // n ascends per thread: first max wins
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -163,13 +165,21 @@ __global__ __launch_bounds__(256) void masked_argmax_kernel(const float* __restr
     const int oi = __shfl_xor(bi, o, 64);
     if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
   }
-  if (lane == 0) ids[row] = bi;
+  if (lane == 0) { sb[wave] = best; si[wave] = bi; }
+  __syncthreads();
+  if (t == 0) {
+    for (int w = 1; w < 4; ++w) {
+      const float ob = sb[w]; const int oi = si[w];
+      if (oi != 0x7fffffff && (bi == 0x7fffffff || ob > best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+    }
+    ids[row] = bi;
+  }
 }
 
 int launch_masked_argmax(const float* logits, int ld, int M, int N, int mask0, int mask1, int mask2,
                          int force, int* ids, hipStream_t stream) {
   if (M <= 0) return SS_OK;
-  hipLaunchKernelGGL(masked_argmax_kernel, dim3(cdiv(M, 4)), dim3(256), 0, stream, logits, ld, M, N, mask0,
+  hipLaunchKernelGGL(masked_argmax_kernel, dim3(M), dim3(256), 0, stream, logits, ld, M, N, mask0,
                      mask1, mask2, force, ids);
   SS_LAUNCH_CHECK();
   return SS_OK;

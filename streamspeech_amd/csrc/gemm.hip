@@ -10,6 +10,7 @@
 // C/D layout (MI355X guide §3): col = lane&15, row = (lane>>4)*4 + reg.
 #include "gemm.hpp"
 
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -199,11 +200,128 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
     }
 }
 
+
+// =================================================================================================
+// Small-M linear layers (M <= 128: every encoder/decoder projection at batch 1, decode steps at
+// M = 1).  These are latency-bound, so there is no LDS staging and no barrier in the main loop:
+// a workgroup owns 16 rows x (16*WN) columns, its 4 waves are arranged SK (split-K) x WN, and
+// each wave feeds v_mfma_f32_16x16x4_f32 straight from global memory -- lane (r, g) loads the
+// float4 at [row r][k + 4g] of A and of W (64-B row segments), 4 MFMAs per pair of loads, loads
+// of 4 chunks kept in flight.  The SK partial tiles are summed through LDS once at the end.
+// Optional fused LayerNorm over K on the A rows (two-pass statistics per wave, rows stay in L1).
+// =================================================================================================
+template <int SK, int WN, bool LNORM>
+__global__ __launch_bounds__(256) void smallm_gemm_kernel(const GemmArgs p) {
+  static_assert(SK * WN == 4, "4 waves");
+  __shared__ f32x4 red[SK > 1 ? (SK - 1) * WN * 64 : 1];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int sk = wave / WN, wn = wave % WN;
+  const int r = lane & 15, g = lane >> 4;
+  const int m0 = blockIdx.x * 16;
+  const int n0 = blockIdx.y * (16 * WN) + wn * 16;
+  const int K = p.Cin;
+  const int KC = K / 16;                          // 16-wide chunks
+  const int c_begin = (KC * sk) / SK, c_end = (KC * (sk + 1)) / SK;
+
+  const int am = m0 + r;
+  const bool a_ok = am < p.M;
+  const float* arow = p.A + (size_t)(a_ok ? am : 0) * p.lda + 4 * g;
+  const int wnr = n0 + r;
+  const bool w_ok = wnr < p.N;
+  const float* wrow = p.W + (size_t)(w_ok ? wnr : 0) * K + 4 * g;
+
+  float mean = 0.f, rstd = 1.f;
+  if (LNORM) {
+    float s = 0.f;
+    for (int c = 0; c < KC; ++c) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(arow + c * 16);
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    mean = s / (float)K;
+    float q = 0.f;
+    for (int c = 0; c < KC; ++c) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(arow + c * 16);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+    }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    rstd = 1.0f / sqrtf(q / (float)K + 1e-5f);
+  }
+
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // 2 chains: MFMA dependent latency 40 > issue 32
+  auto step = [&](auto UN, int c) {      // UN chunks with all their loads issued before the MFMAs
+    constexpr int U = decltype(UN)::value;
+    f32x4 a[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      w[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (a_ok) a[u] = *reinterpret_cast<const f32x4*>(arow + (c + u) * 16);
+      if (w_ok) w[u] = *reinterpret_cast<const f32x4*>(wrow + (c + u) * 16);
+    }
+    if (LNORM) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_g + (c + u) * 16 + 4 * g);
+        const f32x4 bt = *reinterpret_cast<const f32x4*>(p.ln_b + (c + u) * 16 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[u][e] = a_ok ? (a[u][e] - mean) * rstd * gm[e] + bt[e] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; e += 2) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], w[u][e], acc, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e + 1], w[u][e + 1], acc2, 0, 0, 0);
+      }
+  };
+  int c = c_begin;
+  for (; c + 4 <= c_end; c += 4) step(std::integral_constant<int, 4>{}, c);
+  for (; c < c_end; ++c) step(std::integral_constant<int, 1>{}, c);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
+
+  if (SK > 1) {
+    if (sk > 0) red[((sk - 1) * WN + wn) * 64 + lane] = acc;
+    __syncthreads();
+    if (sk > 0) return;
+#pragma unroll
+    for (int s2 = 1; s2 < SK; ++s2) {
+      const f32x4 o = red[((s2 - 1) * WN + wn) * 64 + lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += o[e];
+    }
+  }
+  const int n = n0 + r;
+  if (n >= p.N) return;
+  const float b = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int m = m0 + g * 4 + e;
+    if (m < p.M) {
+      float v = acc[e] + b;
+      switch (p.act) {
+        case ACT_SILU: v = v / (1.0f + expf(-v)); break;
+        case ACT_RELU: v = fmaxf(v, 0.f); break;
+        default: break;
+      }
+      v *= p.alpha;
+      if (p.R) v += p.R[(size_t)m * p.ldr + n];
+      p.C[(size_t)m * p.ldc + n] = v;
+    }
+  }
+}
+
 // ---- optional event profiler -------------------------------------------------------------------
 static const char* kTileNames[kNumTileCfg] = {
     "conv_gemm<128,16,16,4,1>", "conv_gemm<128,32,32,4,1>", "conv_gemm<128,32,16,4,1>", "conv_gemm<16,128,32,1,4>",
     "conv_gemm<16,128,16,1,4>", "conv_gemm<128,128,16,2,2>", "conv_gemm<128,64,32,2,2>", "conv_gemm<64,64,32,2,2>",
-    "conv_gemm<64,64,16,2,2>", "conv_gemm<32,64,32,2,2>", "conv_gemm<32,64,16,2,2>", "reserved"};
+    "conv_gemm<64,64,16,2,2>", "conv_gemm<32,64,32,2,2>", "conv_gemm<32,64,16,2,2>", "conv_gemm<32,32,32,2,2>",
+    "smallm_gemm<4,1>", "smallm_gemm<2,2>", "smallm_gemm<1,4>", "reserved"};
 struct ProfRec { hipEvent_t e0, e1; double flops; int cls; };
 static int g_prof_mask = 0;
 static std::vector<ProfRec> g_prof_recs;
@@ -230,23 +348,51 @@ int prof_read(int cls, double* ms_total, double* flops_total, long long* launche
   return SS_OK;
 }
 
+static int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, bool& prof) {
+  prof = (g_prof_mask >> cls) & 1;
+  if (!prof) return SS_OK;
+  if (!g_prof_pool.empty()) { rec.e0 = g_prof_pool.back().first; rec.e1 = g_prof_pool.back().second; g_prof_pool.pop_back(); }
+  else { SS_HIP_CHECK(hipEventCreate(&rec.e0)); SS_HIP_CHECK(hipEventCreate(&rec.e1)); }
+  rec.cls = cls;
+  rec.flops = a.algo_flops > 0 ? a.algo_flops : 2.0 * (double)a.M * a.N * a.taps * a.Cin;
+  SS_HIP_CHECK(hipEventRecord(rec.e0, stream));
+  return SS_OK;
+}
+static int prof_end(hipStream_t stream, ProfRec& rec, bool prof) {
+  if (prof) { SS_HIP_CHECK(hipEventRecord(rec.e1, stream)); g_prof_recs.push_back(rec); }
+  return SS_OK;
+}
+
 template <int BM, int BN, int BK, int WM, int WN>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream, int cls) {
   const int mmax = a.nseg > 0 ? a.max_seg_out : a.M;
   dim3 grid(cdiv(mmax, BM), cdiv(a.N, BN), a.nseg > 0 ? a.nseg : 1);
-  const bool prof = (g_prof_mask >> cls) & 1;
-  ProfRec rec{};
-  if (prof) {
-    if (!g_prof_pool.empty()) { rec.e0 = g_prof_pool.back().first; rec.e1 = g_prof_pool.back().second; g_prof_pool.pop_back(); }
-    else { SS_HIP_CHECK(hipEventCreate(&rec.e0)); SS_HIP_CHECK(hipEventCreate(&rec.e1)); }
-    rec.cls = cls;
-    rec.flops = a.algo_flops > 0 ? a.algo_flops : 2.0 * (double)a.M * a.N * a.taps * a.Cin;
-    SS_HIP_CHECK(hipEventRecord(rec.e0, stream));
-  }
+  ProfRec rec{}; bool prof = false;
+  int rc = prof_begin(a, stream, cls, rec, prof);
+  if (rc != SS_OK) return rc;
   hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(256), 0, stream, a);
   SS_LAUNCH_CHECK();
-  if (prof) { SS_HIP_CHECK(hipEventRecord(rec.e1, stream)); g_prof_recs.push_back(rec); }
-  return SS_OK;
+  return prof_end(stream, rec, prof);
+}
+
+template <int SK, int WN>
+static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
+  dim3 grid(cdiv(a.M, 16), cdiv(a.N, 16 * WN));
+  ProfRec rec{}; bool prof = false;
+  int rc = prof_begin(a, stream, cls, rec, prof);
+  if (rc != SS_OK) return rc;
+  if (a.ln_g) hipLaunchKernelGGL((smallm_gemm_kernel<SK, WN, true>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((smallm_gemm_kernel<SK, WN, false>), grid, dim3(256), 0, stream, a);
+  SS_LAUNCH_CHECK();
+  return prof_end(stream, rec, prof);
+}
+
+bool smallm_eligible(const GemmArgs& a) {
+  const int M = a.nseg > 0 ? a.max_seg_out : a.M;
+  const bool plain_linear = a.taps == 1 && a.stride == 1 && a.pad == 0 && !a.glu && a.nseg == 0 && a.chunk == 0 &&
+                            a.in_act == ACT_NONE && !a.R2 && a.div == 0.f &&
+                            (a.act == ACT_NONE || a.act == ACT_SILU || a.act == ACT_RELU);
+  return plain_linear && M <= 128 && M > 0 && a.Cin % 64 == 0 && (a.lda & 3) == 0;
 }
 
 int launch_conv_gemm(const GemmArgs& a, hipStream_t stream) {
@@ -256,6 +402,13 @@ int launch_conv_gemm(const GemmArgs& a, hipStream_t stream) {
   if (a.glu && (a.N % 32 != 0)) return SS_ERR_ARG;
   const bool k32 = (a.Cin % 32) == 0;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
+  if (smallm_eligible(a)) {
+    const long wgs16 = (long)cdiv(M, 16) * cdiv(a.N, 16);
+    if (a.Cin >= 1024 || wgs16 <= 1024) return launch_smallm<4, 1>(a, stream, 12);
+    if (wgs16 <= 4096) return launch_smallm<2, 2>(a, stream, 13);
+    return launch_smallm<1, 4>(a, stream, 14);
+  }
+  if (a.ln_g) return SS_ERR_ARG;  // LayerNorm fusion exists only on the small-M path
   if (a.N <= 16) return launch_cfg<128, 16, 16, 4, 1>(a, stream, 0);
   if (a.N <= 32 && !a.glu) {
     return k32 ? launch_cfg<128, 32, 32, 4, 1>(a, stream, 1) : launch_cfg<128, 32, 16, 4, 1>(a, stream, 2);
@@ -268,10 +421,14 @@ int launch_conv_gemm(const GemmArgs& a, hipStream_t stream) {
   const long t64 = (long)cdiv(M, 64) * cdiv(a.N, 64) * nseg;
   if (t128 >= 192) return launch_cfg<128, 128, 16, 2, 2>(a, stream, 5);
   if (t12864 >= 192 && k32) return launch_cfg<128, 64, 32, 2, 2>(a, stream, 6);
-  if (t64 >= 160 || M > 256) {
+  if (t64 >= 384) {
     return k32 ? launch_cfg<64, 64, 32, 2, 2>(a, stream, 7) : launch_cfg<64, 64, 16, 2, 2>(a, stream, 8);
   }
-  return k32 ? launch_cfg<32, 64, 32, 2, 2>(a, stream, 9) : launch_cfg<32, 64, 16, 2, 2>(a, stream, 10);
+  const long t3264 = (long)cdiv(M, 32) * cdiv(a.N, 64) * nseg;
+  if (t3264 >= 384 || !k32 || a.glu) {
+    return k32 ? launch_cfg<32, 64, 32, 2, 2>(a, stream, 9) : launch_cfg<32, 64, 16, 2, 2>(a, stream, 10);
+  }
+  return launch_cfg<32, 32, 32, 2, 2>(a, stream, 11);
 }
 
 }  // namespace ss

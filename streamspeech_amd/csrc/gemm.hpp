@@ -36,15 +36,23 @@ struct GemmArgs {
   int nseg = 0;
   int max_seg_out = 0;        // max out_len over segments (grid sizing)
   double algo_flops = 0.0;    // algorithmic FLOPs of this launch for the profiler (0 -> 2*M*N*taps*Cin)
+  // fused LayerNorm prologue on the A rows (linear layers only: taps == 1, normalised over Cin):
+  // A' = (A - mean) * rstd * ln_g + ln_b, eps 1e-5 -- saves the separate LayerNorm launch.
+  const float* ln_g = nullptr;
+  const float* ln_b = nullptr;
 };
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 12;
+constexpr int kNumTileCfg = 16;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches);  // synchronises
 const char* prof_cfg_name(int cls);
+
+// True when launch_conv_gemm would route `a` to the small-M kernel (the only one with the fused
+// LayerNorm prologue).
+bool smallm_eligible(const GemmArgs& a);
 
 // Launches on `stream`; returns SS_OK / SS_ERR_*.
 int launch_conv_gemm(const GemmArgs& a, hipStream_t stream);

@@ -76,6 +76,23 @@ int layernorm(hipStream_t s, const float* x, float* y, const LN& ln, int M, int 
   return launch_layernorm(x, D, y, D, ln.g, ln.b, M, D, 1e-5f, s);
 }
 
+// C = epilogue(LayerNorm(x) @ W^T): fused into the GEMM prologue on the small-M path, otherwise a
+// LayerNorm launch into `h` followed by the GEMM.
+int ln_linear(hipStream_t s, const float* x, int M, const LN& ln, const Lin& l, int N, int K, float* C, int ldc,
+              float* h, int act = ACT_NONE, float alpha = 1.f, int glu = 0) {
+  GemmArgs a;
+  a.A = x; a.lda = K; a.W = l.w; a.bias = l.b; a.C = C; a.ldc = ldc;
+  a.M = M; a.N = N; a.Cin = K; a.in_len = M; a.act = act; a.alpha = alpha; a.glu = glu;
+  if (smallm_eligible(a)) {
+    a.ln_g = ln.g; a.ln_b = ln.b;
+    return launch_conv_gemm(a, s);
+  }
+  int rc = layernorm(s, x, h, ln, M, K);
+  if (rc != SS_OK) return rc;
+  a.A = h;
+  return launch_conv_gemm(a, s);
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -299,12 +316,10 @@ extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fban
   for (int l = 0; l < c.enc_layers; ++l) {
     const EncLayer& e = m->enc[l];
     // x = x + 0.5 * FFN1(x)
-    RET(layernorm(s, x, h, e.ffn1_ln, T2, d));
-    RET(linear(s, h, d, T2, e.ffn1_w1, f, d, ff, f, ACT_SILU));
+    RET(ln_linear(s, x, T2, e.ffn1_ln, e.ffn1_w1, f, d, ff, f, h, ACT_SILU));
     RET(linear(s, ff, f, T2, e.ffn1_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
     // x = x + RelPosMHA(LN(x))
-    RET(layernorm(s, x, h, e.attn_ln, T2, d));
-    RET(linear(s, h, d, T2, e.qkv, 3 * d, d, qkv, 3 * d));
+    RET(ln_linear(s, x, T2, e.attn_ln, e.qkv, 3 * d, d, qkv, 3 * d, h));
     AttnArgs at;
     at.Q = qkv; at.K = qkv + d; at.V = qkv + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
     at.O = h; at.ldo = d; at.Tq = T2; at.Tk = T2; at.H = c.enc_heads; at.scale = 0.125f;
@@ -312,14 +327,12 @@ extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fban
     RET(launch_attention(at, s));
     RET(linear(s, h, d, T2, e.out, d, d, x, d, ACT_NONE, 1.f, x, d));
     // x = x + ConvModule(x)
-    RET(layernorm(s, x, h, e.conv_ln, T2, d));
-    RET(linear(s, h, d, T2, e.pw1, 2 * d, d, g, d, ACT_NONE, 1.f, nullptr, 0, 1));
+    RET(ln_linear(s, x, T2, e.conv_ln, e.pw1, 2 * d, d, g, d, h, ACT_NONE, 1.f, 1));
     RET(launch_dwconv_bn_silu(g, d, g2, d, e.dw_wt, c.dw_kernel, e.bn_mean, e.bn_var, e.bn_g, e.bn_b, 1e-5f,
                               T2, d, cchunk, s));
     RET(linear(s, g2, d, T2, e.pw2, d, d, x, d, ACT_NONE, 1.f, x, d));
     // x = LN(x + 0.5 * FFN2(x))
-    RET(layernorm(s, x, h, e.ffn2_ln, T2, d));
-    RET(linear(s, h, d, T2, e.ffn2_w1, f, d, ff, f, ACT_SILU));
+    RET(ln_linear(s, x, T2, e.ffn2_ln, e.ffn2_w1, f, d, ff, f, h, ACT_SILU));
     RET(linear(s, ff, f, T2, e.ffn2_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
     RET(layernorm(s, x, x, e.final_ln, T2, d));
   }
@@ -350,25 +363,22 @@ static int dec_layer(hipStream_t s, const ss_config& c, const DecLayer& L, float
                      float* selfbuf, bool causal, const float* crossKV, int Tk_cross, float* h, float* q2,
                      float* ff) {
   const int D = c.dec_dim, F = c.dec_ffn, H = c.dec_heads;
-  RET(layernorm(s, x, h, L.self_ln, n, D));
   float* rows = selfbuf + (size_t)pos0 * 3 * D;
-  RET(linear(s, h, D, n, L.self_qkv, 3 * D, D, rows, 3 * D));   // q (pre-scaled at pack time), k, v
+  RET(ln_linear(s, x, n, L.self_ln, L.self_qkv, 3 * D, D, rows, 3 * D, h));   // q (pre-scaled at pack time), k, v
   AttnArgs at;
   at.Q = rows; at.ldq = 3 * D; at.K = selfbuf + D; at.V = selfbuf + 2 * D; at.ldk = at.ldv = 3 * D;
   at.O = h; at.ldo = D; at.Tq = n; at.Tk = pos0 + n; at.H = H; at.scale = 1.f; at.causal = causal ? 1 : 0;
   RET(launch_attention(at, s));
   RET(linear(s, h, D, n, L.self_out, D, D, x, D, ACT_NONE, 1.f, x, D));
   if (L.has_cross) {
-    RET(layernorm(s, x, h, L.cross_ln, n, D));
-    RET(linear(s, h, D, n, L.cross_q, D, D, q2, D));
+    RET(ln_linear(s, x, n, L.cross_ln, L.cross_q, D, D, q2, D, h));
     AttnArgs ac;
     ac.Q = q2; ac.ldq = D; ac.K = crossKV; ac.V = crossKV + D; ac.ldk = ac.ldv = 2 * D;
     ac.O = h; ac.ldo = D; ac.Tq = n; ac.Tk = Tk_cross; ac.H = H; ac.scale = 1.f;
     RET(launch_attention(ac, s));
     RET(linear(s, h, D, n, L.cross_out, D, D, x, D, ACT_NONE, 1.f, x, D));
   }
-  RET(layernorm(s, x, h, L.ffn_ln, n, D));
-  RET(linear(s, h, D, n, L.fc1, F, D, ff, F, ACT_RELU));
+  RET(ln_linear(s, x, n, L.ffn_ln, L.fc1, F, D, ff, F, h, ACT_RELU));
   RET(linear(s, ff, F, n, L.fc2, D, F, x, D, ACT_NONE, 1.f, x, D));
   return SS_OK;
 }
