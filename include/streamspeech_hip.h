@@ -90,6 +90,15 @@ int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d_enc_out, i
 int ss_mt_begin(ss_model* m, void* stream, const float* d_enc_out, int Tp);
 int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, int n, int pos0, int ban_eos,
                  int force_eos, float* d_feats, int32_t* d_next);
+/* The whole beam-1 search of SequenceGenerator.generate_decoder (agent/sequence_generator.py:165-582)
+ * in one call: begin + prefix pass + autoregressive steps until </s> or max_len (forced </s>), with
+ * the token chain kept on the device.  h_prefix [n_prefix] host ids (no leading </s>).
+ * h_out_tokens (host, >= max_len+1-n_prefix ints) receives the tokens generated after the prefix,
+ * including the final </s>; d_feats [max_len+2, dec_dim] receives the decoder states of every fed
+ * position; *h_n_feats = number of valid rows = 1 + n_prefix + (*h_n_out - 1).  Synchronises. */
+int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, int Tp, const int32_t* h_prefix,
+                 int n_prefix, int max_len, int min_len, int32_t* h_out_tokens, int* h_n_out,
+                 float* d_feats, int* h_n_feats);
 /* Truncate the self-attention cache to `len` positions (whole-word rollback, agent :540-574). */
 int ss_mt_truncate(ss_model* m, int len);
 

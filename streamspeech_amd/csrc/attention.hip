@@ -152,8 +152,10 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
 // streams its key row (256 contiguous bytes).  P.V: lane = output dim, probabilities broadcast with
 // v_readlane, V rows read coalesced.  Same online softmax as the tiled kernel.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void attention_decode_kernel(const AttnArgs p) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(256) void attention_decode_kernel(const AttnArgs p) {
+  // 4 waves per (query, head): wave w takes key tiles w, w+4, ...; partial (max, sum, acc) merged in LDS
+  __shared__ float part_m[4], part_l[4], part_acc[4][DH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x, h = blockIdx.y;
   const int hoff = h * DH;
   const int qoff = p.Tk - p.Tq;
@@ -162,20 +164,20 @@ __global__ __launch_bounds__(64) void attention_decode_kernel(const AttnArgs p) 
   if (p.causal) kmax = min(kmax, i + qoff + 1);
   if (p.chunk > 0) kmax = min(kmax, (i / p.chunk + 1) * p.chunk);
   float m_run = -INFINITY, l_run = 0.f, acc = 0.f;
-  for (int j0 = 0; j0 < kmax; j0 += 64) {
+  for (int j0 = wave * 64; j0 < kmax; j0 += 256) {
     const int j = j0 + lane;
     const bool vis = j < kmax;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (vis) {
       const float4* kr = reinterpret_cast<const float4*>(p.K + (size_t)j * p.ldk + hoff);
 #pragma unroll
       for (int d4 = 0; d4 < DH / 4; ++d4) {
         const float4 kv = kr[d4];
-        s = fmaf(q[4 * d4 + 0], kv.x, s); s = fmaf(q[4 * d4 + 1], kv.y, s);
-        s = fmaf(q[4 * d4 + 2], kv.z, s); s = fmaf(q[4 * d4 + 3], kv.w, s);
+        s0 = fmaf(q[4 * d4 + 0], kv.x, s0); s1 = fmaf(q[4 * d4 + 1], kv.y, s1);
+        s2 = fmaf(q[4 * d4 + 2], kv.z, s2); s3 = fmaf(q[4 * d4 + 3], kv.w, s3);
       }
     }
-    const float sv = vis ? s * p.scale : -INFINITY;
+    const float sv = vis ? ((s0 + s1) + (s2 + s3)) * p.scale : -INFINITY;
     const float mn = fmaxf(m_run, wave_max(sv));
     const float pe = vis ? expf(sv - mn) : 0.f;
     const float corr = (m_run > -INFINITY) ? expf(m_run - mn) : 0.f;
@@ -192,7 +194,20 @@ __global__ __launch_bounds__(64) void attention_decode_kernel(const AttnArgs p) 
       for (int u = 0; u < 16; ++u) acc = fmaf(rdlane(pe, jj0 + u), vv[u], acc);
     }
   }
-  p.O[(size_t)i * p.ldo + hoff + lane] = acc / l_run;
+  if (lane == 0) { part_m[wave] = m_run; part_l[wave] = l_run; }
+  part_acc[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0) {
+    float mt = fmaxf(fmaxf(part_m[0], part_m[1]), fmaxf(part_m[2], part_m[3]));
+    float l = 0.f, o = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float f = (part_m[w] > -INFINITY) ? expf(part_m[w] - mt) : 0.f;
+      l += part_l[w] * f;
+      o += part_acc[w][lane] * f;
+    }
+    p.O[(size_t)i * p.ldo + hoff + lane] = o / l;
+  }
 }
 
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
@@ -200,7 +215,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if ((a.ldk & 3) || (a.ldv & 3)) return SS_ERR_ARG;
   dim3 grid(cdiv(a.Tq, QB), a.H);
   if (!a.P && a.Tq <= 8) {
-    hipLaunchKernelGGL(attention_decode_kernel, dim3(a.Tq, a.H), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(attention_decode_kernel, dim3(a.Tq, a.H), dim3(256), 0, stream, a);
     SS_LAUNCH_CHECK();
     return SS_OK;
   }

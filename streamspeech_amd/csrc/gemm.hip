@@ -214,6 +214,7 @@ template <int SK, int WN, bool LNORM>
 __global__ __launch_bounds__(256) void smallm_gemm_kernel(const GemmArgs p) {
   static_assert(SK * WN == 4, "4 waves");
   __shared__ f32x4 red[SK > 1 ? (SK - 1) * WN * 64 : 1];
+  __shared__ float ln_stat[32];                   // mean[16], rstd[16] of the workgroup's rows
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int sk = wave / WN, wn = wave % WN;
   const int r = lane & 15, g = lane >> 4;
@@ -232,56 +233,81 @@ __global__ __launch_bounds__(256) void smallm_gemm_kernel(const GemmArgs p) {
 
   float mean = 0.f, rstd = 1.f;
   if (LNORM) {
-    float s = 0.f;
-    for (int c = 0; c < KC; ++c) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(arow + c * 16);
-      s += (v[0] + v[1]) + (v[2] + v[3]);
-    }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
-    mean = s / (float)K;
-    float q = 0.f;
-    for (int c = 0; c < KC; ++c) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(arow + c * 16);
+    // 16 threads per row, each keeps its K/16 values in registers (K <= 512): one read, two-pass stats
+    const int lr = t >> 4, part = t & 15;
+    const bool ok = (m0 + lr) < p.M;
+    const float* xr = p.A + (size_t)(ok ? m0 + lr : 0) * p.lda + part * 4;
+    f32x4 v[8];
+    float sm = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = v[e] - mean; q += d * d; }
+    for (int j = 0; j < 8; ++j) {
+      v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (j * 64 < K && ok) v[j] = *reinterpret_cast<const f32x4*>(xr + j * 64);
+      sm += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
     }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
-    rstd = 1.0f / sqrtf(q / (float)K + 1e-5f);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) sm += __shfl_xor(sm, o, 64);
+    const float mu = sm / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j * 64 < K) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mu; q += d * d; }
+      }
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) q += __shfl_xor(q, o, 64);
+    if (part == 0) { ln_stat[lr] = mu; ln_stat[16 + lr] = 1.0f / sqrtf(q / (float)K + 1e-5f); }
+    __syncthreads();
+    mean = ln_stat[r];
+    rstd = ln_stat[16 + r];
   }
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // 2 chains: MFMA dependent latency 40 > issue 32
-  auto step = [&](auto UN, int c) {      // UN chunks with all their loads issued before the MFMAs
-    constexpr int U = decltype(UN)::value;
-    f32x4 a[U], w[U];
+  auto load4 = [&](f32x4 (&a)[4], f32x4 (&w)[4], int c) {
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < 4; ++u) {
       a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       w[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       if (a_ok) a[u] = *reinterpret_cast<const f32x4*>(arow + (c + u) * 16);
       if (w_ok) w[u] = *reinterpret_cast<const f32x4*>(wrow + (c + u) * 16);
     }
-    if (LNORM) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_g + (c + u) * 16 + 4 * g);
-        const f32x4 bt = *reinterpret_cast<const f32x4*>(p.ln_b + (c + u) * 16 + 4 * g);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[u][e] = a_ok ? (a[u][e] - mean) * rstd * gm[e] + bt[e] : 0.f;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int e = 0; e < 4; e += 2) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], w[u][e], acc, 0, 0, 0);
-        acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e + 1], w[u][e + 1], acc2, 0, 0, 0);
-      }
   };
-  int c = c_begin;
-  for (; c + 4 <= c_end; c += 4) step(std::integral_constant<int, 4>{}, c);
-  for (; c < c_end; ++c) step(std::integral_constant<int, 1>{}, c);
+  auto mma = [&](f32x4 a, f32x4 w, int c) {
+    if (LNORM) {
+      const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_g + c * 16 + 4 * g);
+      const f32x4 bt = *reinterpret_cast<const f32x4*>(p.ln_b + c * 16 + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] = a_ok ? (a[e] - mean) * rstd * gm[e] + bt[e] : 0.f;
+    }
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[0], w[0], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[1], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[2], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[3], acc2, 0, 0, 0);
+  };
+  auto mma4 = [&](f32x4 (&a)[4], f32x4 (&w)[4], int c) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mma(a[u], w[u], c + u);
+  };
+  // groups of 4 chunks, register double-buffered: the loads of group g+1 fly under the MFMAs of g
+  const int G = (c_end - c_begin) / 4;
+  f32x4 a0[4], w0[4], a1[4], w1[4];
+  if (G > 0) load4(a0, w0, c_begin);
+  for (int gi = 0; gi < G; gi += 2) {
+    const int c = c_begin + 4 * gi;
+    if (gi + 1 < G) load4(a1, w1, c + 4);
+    mma4(a0, w0, c);
+    if (gi + 1 < G) {
+      if (gi + 2 < G) load4(a0, w0, c + 8);
+      mma4(a1, w1, c + 4);
+    }
+  }
+  for (int c = c_begin + 4 * G; c < c_end; ++c) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, w = {0.f, 0.f, 0.f, 0.f};
+    if (a_ok) a = *reinterpret_cast<const f32x4*>(arow + c * 16);
+    if (w_ok) w = *reinterpret_cast<const f32x4*>(wrow + c * 16);
+    mma(a, w, c);
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e) acc[e] += acc2[e];
 
@@ -381,6 +407,7 @@ static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
   ProfRec rec{}; bool prof = false;
   int rc = prof_begin(a, stream, cls, rec, prof);
   if (rc != SS_OK) return rc;
+  if (a.ln_g && a.Cin > 512) return SS_ERR_ARG;   // fused LayerNorm keeps the row in registers (D <= 512)
   if (a.ln_g) hipLaunchKernelGGL((smallm_gemm_kernel<SK, WN, true>), grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL((smallm_gemm_kernel<SK, WN, false>), grid, dim3(256), 0, stream, a);
   SS_LAUNCH_CHECK();

@@ -83,7 +83,7 @@ int ln_linear(hipStream_t s, const float* x, int M, const LN& ln, const Lin& l, 
   GemmArgs a;
   a.A = x; a.lda = K; a.W = l.w; a.bias = l.b; a.C = C; a.ldc = ldc;
   a.M = M; a.N = N; a.Cin = K; a.in_len = M; a.act = act; a.alpha = alpha; a.glu = glu;
-  if (smallm_eligible(a)) {
+  if (smallm_eligible(a) && K <= 512) {
     a.ln_g = ln.g; a.ln_b = ln.b;
     return launch_conv_gemm(a, s);
   }
@@ -134,6 +134,8 @@ struct ss_model {
   int mt_Tp = 0;
   int mt_len = 0;
   const float* mt_enc = nullptr;
+  DevBuf mt_tok;                 // device token chain [max_tgt_pos] (greedy search feeds itself)
+  int32_t* mt_tok_host = nullptr;  // pinned staging of the same
 };
 
 static int load_dec_layers(ss_model* m, std::vector<DecLayer>& v, const std::string& pfx, int n, int D, int F,
@@ -244,6 +246,9 @@ extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t
   }
   if (rc == SS_OK && hipDeviceSynchronize() != hipSuccess) rc = SS_ERR_HIP;
   if (rc == SS_OK) rc = m->mt_self.ensure((size_t)cfg->mt_layers * cfg->max_tgt_pos * 3 * D * sizeof(float));
+  if (rc == SS_OK) rc = m->mt_tok.ensure((size_t)cfg->max_tgt_pos * sizeof(int32_t));
+  if (rc == SS_OK && hipHostMalloc((void**)&m->mt_tok_host, (size_t)cfg->max_tgt_pos * sizeof(int32_t)) != hipSuccess)
+    rc = SS_ERR_HIP;
   if (rc != SS_OK) { ss_model_destroy(m); return rc; }
   *out = m;
   return SS_OK;
@@ -252,6 +257,8 @@ extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t
 extern "C" void ss_model_destroy(ss_model* m) {
   if (!m) return;
   m->pos_proj.release(); m->ws.release(); m->mt_cross.release(); m->mt_self.release(); m->mt_ws.release();
+  m->mt_tok.release();
+  if (m->mt_tok_host) (void)hipHostFree(m->mt_tok_host);
   delete m;
 }
 
@@ -433,6 +440,53 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
     RET(linear(s, fo + (size_t)(n - 1) * D, D, 1, proj, V, D, logits, V));
     RET(launch_masked_argmax(logits, V, 1, V, c.pad, ban_eos ? c.eos : -1, -1, force_eos ? c.eos : -1, d_next, s));
   }
+  return SS_OK;
+}
+
+
+// Whole beam-1 search in one call: the token chain lives on the device (each step's argmax writes
+// the next step's input), the host only peeks at it every kCheck steps to notice </s>.
+extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, int Tp, const int32_t* h_prefix,
+                            int n_prefix, int max_len, int min_len, int32_t* h_out_tokens, int* h_n_out,
+                            float* d_feats, int* h_n_feats) {
+  if (!m || !d_enc_out || Tp <= 0 || n_prefix < 0 || max_len < n_prefix || !h_out_tokens || !h_n_out || !d_feats)
+    return SS_ERR_ARG;
+  const ss_config& c = m->cfg;
+  if (max_len + 3 > c.max_tgt_pos) return SS_ERR_CAPACITY;
+  hipStream_t s = (hipStream_t)stream;
+  constexpr int kCheck = 4;
+  const int D = c.dec_dim;
+  RET(ss_mt_begin(m, stream, d_enc_out, Tp));
+  int32_t* tok = reinterpret_cast<int32_t*>(m->mt_tok.p);
+  int32_t* host = m->mt_tok_host;
+  host[0] = c.eos;
+  for (int i = 0; i < n_prefix; ++i) host[1 + i] = h_prefix[i];
+  const int start = n_prefix;
+  SS_HIP_CHECK(hipMemcpyAsync(tok, host, (size_t)(start + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  // step `start`: feed [eos, prefix...] in one pass
+  RET(ss_mt_append(m, stream, tok, start + 1, 0, start < min_len, start >= max_len, d_feats, tok + start + 1));
+  int step = start + 1;      // next position to feed == index of the newest generated token
+  int n_gen = 1, eos_at = -1, checked = start + 1;
+  while (true) {
+    const bool last = step > max_len;
+    if (last || (step - (start + 1)) % kCheck == kCheck - 1) {
+      SS_HIP_CHECK(hipMemcpyAsync(host + checked, tok + checked, (size_t)(step + 1 - checked) * sizeof(int32_t),
+                                  hipMemcpyDeviceToHost, s));
+      SS_HIP_CHECK(hipStreamSynchronize(s));
+      for (int i = checked; i <= step && eos_at < 0; ++i) if (host[i] == c.eos) eos_at = i;
+      checked = step + 1;
+      if (eos_at >= 0 || last) break;
+    }
+    RET(ss_mt_append(m, stream, tok + step, 1, step, step < min_len, step >= max_len,
+                     d_feats + (size_t)step * D, tok + step + 1));
+    ++step; ++n_gen;
+  }
+  const int end = eos_at >= 0 ? eos_at : step;          // index of the last generated token
+  const int n_out = end - start;                          // tokens after the prefix (incl. a final eos)
+  for (int i = 0; i < n_out; ++i) h_out_tokens[i] = host[start + 1 + i];
+  *h_n_out = n_out;
+  if (h_n_feats) *h_n_feats = end;                        // fed positions 0 .. end-1 hold valid features
+  m->mt_len = end;
   return SS_OK;
 }
 

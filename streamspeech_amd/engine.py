@@ -122,6 +122,19 @@ class HipModel:
                                       _ptr(feats), _ptr(nxt)), "ss_mt_append")
         return feats, (int(nxt.item()) if want_next else None)
 
+    def mt_greedy(self, enc_out: torch.Tensor, prefix: List[int], max_len: int, min_len: int = 1):
+        """Beam-1 search in one C call -> (tokens after the prefix incl. final eos, feats [n_fed, D])."""
+        self._mt_enc = enc_out
+        n_pre = len(prefix)
+        cap = max_len + 2
+        feats = torch.empty((cap, self.cfg.dec_dim), dtype=torch.float32, device=self.device)
+        c_pre = (C.c_int32 * max(n_pre, 1))(*prefix)
+        c_out = (C.c_int32 * (max_len + 2 - n_pre))()
+        n_out, n_feats = C.c_int(0), C.c_int(0)
+        L.check(self.lib.ss_mt_greedy(self.h, _stream(), _ptr(enc_out), enc_out.shape[0], c_pre, n_pre, max_len,
+                                      min_len, c_out, C.byref(n_out), _ptr(feats), C.byref(n_feats)), "ss_mt_greedy")
+        return list(c_out[: n_out.value]), feats[: n_feats.value]
+
     def mt_truncate(self, length: int):
         L.check(self.lib.ss_mt_truncate(self.h, length), "ss_mt_truncate")
 

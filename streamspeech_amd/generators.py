@@ -93,6 +93,10 @@ class SequenceGenerator:
             max_len = start + max_new_tokens
         assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
         eng = self.engine
+        if hasattr(eng, "mt_greedy"):
+            out, feats = eng.mt_greedy(enc.contiguous(), prefix, max_len, self.min_len)
+            return [[{"tokens": torch.tensor(prefix + out, dtype=torch.long), "features": feats, "score": None,
+                      "attention": None, "alignment": None, "positional_scores": None}]]
         eng.mt_begin(enc.contiguous())
         feats_all = []
         feats, nxt = eng.mt_append([self.eos] + prefix, 0, ban_eos=(start < self.min_len), force_eos=(start >= max_len))

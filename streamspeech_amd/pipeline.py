@@ -28,6 +28,9 @@ def mt_greedy(model: HipModel, enc_out: torch.Tensor, prefix: Optional[List[int]
         max_len = min(max_len_b, cfg.max_target_positions - 1)
     else:
         max_len = start + max_new_tokens
+    if hasattr(model, "mt_greedy"):
+        out, feats = model.mt_greedy(enc_out, prefix, max_len, 1)
+        return prefix + out, feats
     if begin:
         model.mt_begin(enc_out)
     feats_all = []

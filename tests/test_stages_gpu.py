@@ -85,6 +85,11 @@ def test_mt_decoder_features_and_greedy(hip_model, golden_dir):
         gen.append(nxt)
         step += 1
     assert toks[1:] + gen == gd["mt_greedy_prefix9_new5"].tolist()
+    # the same search as one C call with the token chain on the device
+    out, f = hip_model.mt_greedy(enc, toks[1:], max_len, 1)
+    assert toks[1:] + out == gd["mt_greedy_prefix9_new5"].tolist()
+    assert f.shape[0] == len(toks) + len(out) - 1
+    assert np.abs(f[: len(toks)].cpu().numpy() - gd["mt_features"]).max() < FEAT_TOL
 
 
 def test_t2u_and_unit_decoder_identical_units(hip_model, golden_dir):

@@ -1,0 +1,62 @@
+"""Per-shape timing of the conv-GEMM kernel on the vocoder / encoder / decoder layer shapes
+(HIP events around 20 launches each).  Run on the GPU box: python tools/conv_bench.py"""
+import ctypes as C
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from streamspeech_amd import lib as L  # noqa: E402
+
+lib = L.load()
+P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+
+
+def bench(name, M, N, Cin, taps=1, dil=1, reps=20):
+    A = torch.randn(M, Cin, device="cuda")
+    W = torch.randn(N, taps * Cin, device="cuda") * (taps * Cin) ** -0.5
+    b = torch.randn(N, device="cuda")
+    Cc = torch.empty(M, N, device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    pad = dil * (taps - 1) // 2
+    args = (s, P(A), Cin, P(W), P(b), None, N, None, N, P(Cc), N, M, N, Cin, taps, dil, 1, pad, M, 0, 3 if taps > 1 else 0,
+            0.1, 0, 1.0, 0.0, 0)
+    for _ in range(3):
+        lib.ss_op_conv_gemm(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        lib.ss_op_conv_gemm(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    gf = 2.0 * M * N * taps * Cin / 1e9
+    return {"name": name, "M": M, "N": N, "K": taps * Cin, "us": round(us, 2), "gflop": round(gf, 3),
+            "tflops": round(gf / us * 1e-3 * 1e3, 2)}
+
+
+def main():
+    F = 225  # frames of a 4.5 s utterance
+    rows = []
+    T, Cc = F, 512
+    for i, (u, ku) in enumerate(zip((5, 4, 4, 2, 2), (11, 8, 8, 4, 4))):
+        rows.append(bench(f"up{i} (3-tap polyphase)", T, u * Cc // 2, Cc, 3))
+        T, Cc = T * u, Cc // 2
+        for k in (3, 7, 11):
+            rows.append(bench(f"stage{i} resconv k{k} d1", T, Cc, Cc, k, 1))
+            rows.append(bench(f"stage{i} resconv k{k} d5", T, Cc, Cc, k, 5))
+    for name, M, N, K in [("enc ffn1", 113, 2048, 256), ("enc ffn2", 113, 256, 2048), ("enc qkv", 113, 768, 256),
+                          ("ctc head", 113, 6000, 256), ("unit fc1", 425, 2048, 512), ("unit fc2", 425, 512, 2048),
+                          ("unit qkv", 425, 1536, 512), ("unit head", 425, 1005, 512), ("mt fc1 M=1", 1, 2048, 512),
+                          ("mt fc2 M=1", 1, 512, 2048), ("mt out M=1", 1, 512, 512), ("mt logits M=1", 1, 6000, 512)]:
+        rows.append(bench(name, M, N, K))
+    for r in rows:
+        print(f"{r['name']:28s} M={r['M']:6d} N={r['N']:5d} K={r['K']:5d}  {r['us']:8.2f} us  {r['tflops']:7.2f} TFLOP/s")
+    os.makedirs("gpurun_out", exist_ok=True)
+    json.dump(rows, open("gpurun_out/conv_bench.json", "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
