@@ -31,6 +31,7 @@ from streamspeech_amd.engine import HipModel, HipVocoder   # noqa: E402
 from streamspeech_amd.pipeline import mt_greedy, units_from_tokens  # noqa: E402
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured copy)
 
 
 def run_utterance(model, voc, pcm, utt):
@@ -55,6 +56,23 @@ def cpu_baseline(sd, vsd, cfg, vcfg, utts, budget_s=25.0):
     from oracle import streamspeech_oracle as O
     osd, ovsd = O.SD(sd), O.SD(vsd)
     g_mean, g_std = np.zeros(80, np.float32), np.ones(80, np.float32)
+    # torch's default (all cores) is far from the best setting for these small ops on a many-core
+    # host: probe a few thread counts on one encoder+vocoder pass and keep the fastest
+    ncores = os.cpu_count() or 1
+    best_t, best_dt = torch.get_num_threads(), None
+    with torch.inference_mode():
+        probe = utts[0]
+        fb0 = synth.synth_fbank(1, int(probe.seconds * 100) - 2)
+        for nt in sorted({min(ncores, c) for c in (8, 16, 32, 64)}):
+            torch.set_num_threads(nt)
+            O.encoder_forward(osd, fb0, cfg, n_layers=2)
+            t0 = time.perf_counter()
+            O.encoder_forward(osd, fb0, cfg, n_layers=4)
+            O.vocoder_forward(ovsd, list(range(40)), vcfg, False)
+            dt = time.perf_counter() - t0
+            if best_dt is None or dt < best_dt:
+                best_t, best_dt = nt, dt
+    torch.set_num_threads(best_t)
     audio, wall, n = 0.0, 0.0, 0
     with torch.inference_mode():
         for i, u in enumerate(utts):
@@ -92,6 +110,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--streams", type=int, default=8,
+                    help="utterances in flight per GPU (each at batch 1, own HIP stream and scratch context)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,38 +145,93 @@ def main():
         run_utterance(model, voc, p, u)
     torch.cuda.synchronize()
 
-    # dominant kernel class: decided from an untimed profiled pass over one utterance
-    dom = None
+    # dominant kernel classes: decided from an untimed profiled pass over one utterance
+    dom, dom_conv = None, None
     if not args.no_prof and Wn > 0:
         ncls = lib.ss_prof_num_classes()
         lib.ss_prof_reset()
         lib.ss_prof_enable((1 << ncls) - 1)
         run_utterance(model, voc, pcms[0], mine[0])
         torch.cuda.synchronize()
-        best = -1.0
+        best, best_conv = -1.0, -1.0
         for c in range(ncls):
-            ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
-            lib.ss_prof_read(c, C.byref(ms), C.byref(fl), C.byref(n))
+            ms, fl, n, by = C.c_double(), C.c_double(), C.c_int64(), C.c_double()
+            lib.ss_prof_read(c, C.byref(ms), C.byref(fl), C.byref(n), C.byref(by))
             if ms.value > best:
                 best, dom = ms.value, c
+            if lib.ss_prof_class_name(c).decode().startswith("conv_gemm") and ms.value > best_conv:
+                best_conv, dom_conv = ms.value, c
         lib.ss_prof_enable(0)
         lib.ss_prof_reset()
 
+    # single-stream latency pass (untimed for `value`; reported as latency_ms_single_stream)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nlat = min(K, 8)
+    for u, p in zip(mine[Wn:Wn + nlat], pcms[Wn:Wn + nlat]):
+        run_utterance(model, voc, p, u)
+    torch.cuda.synchronize()
+    single_ms = 1e3 * (time.perf_counter() - t0) / nlat
+    single_rtfx = sum(u.seconds for u in mine[Wn:Wn + nlat]) / (single_ms * 1e-3 * nlat)
+
+    # S concurrent utterance streams: worker threads (ctypes releases the GIL inside the C ABI),
+    # each with its own HIP stream and its own scratch/KV-cache context over the shared weights
+    S = max(1, args.streams)
+    import threading
+    ctxs = [(model, voc)] + [(model.new_context(), voc.new_context()) for _ in range(S - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    work = list(zip(mine[Wn:Wn + K], pcms[Wn:Wn + K]))
+    longest = max(range(len(mine)), key=lambda i: mine[i].seconds)
+    next_idx = [0]
+    lock = threading.Lock()
+    start_evt = threading.Barrier(S + 1)
+    samples = [0] * S
+    errors = []
+
+    def worker(wi):
+        try:
+            torch.cuda.set_device(local_rank)
+            m, v = ctxs[wi]
+            with torch.cuda.stream(streams[wi]):
+                run_utterance(m, v, pcms[longest], mine[longest])   # warm this context at the largest shapes
+                streams[wi].synchronize()
+                start_evt.wait()
+                while True:
+                    with lock:
+                        i = next_idx[0]
+                        next_idx[0] += 1
+                    if i >= len(work):
+                        break
+                    u, p = work[i]
+                    wav, _, _, _ = run_utterance(m, v, p, u)
+                    samples[wi] += wav.numel()
+                streams[wi].synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            try:
+                start_evt.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
+    for t in threads:
+        t.start()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     if dom is not None:
-        lib.ss_prof_enable(1 << dom)
+        lib.ss_prof_enable((1 << dom) | ((1 << dom_conv) if dom_conv is not None else 0))
+    start_evt.wait()
     t0 = time.perf_counter()
-    samples_out = 0
-    for u, p in zip(mine[Wn:Wn + K], pcms[Wn:Wn + K]):
-        wav, _, _, _ = run_utterance(model, voc, p, u)
-        samples_out += wav.numel()
+    for t in threads:
+        t.join()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     wall = time.perf_counter() - t0
     lib.ss_prof_enable(0)
+    if errors:
+        raise errors[0]
 
     audio = sum(u.seconds for u in mine[Wn:Wn + K])
     stats = torch.tensor([wall, audio, float(K)], dtype=torch.float64, device=dev)
@@ -168,17 +243,30 @@ def main():
     else:
         nutt = float(K)
 
-    roofline = None
-    if dom is not None:
-        ms, fl, n = C.c_double(), C.c_double(), C.c_int64()
-        lib.ss_prof_read(dom, C.byref(ms), C.byref(fl), C.byref(n))
-        if n.value > 0 and ms.value > 0:
-            ach = fl.value / (ms.value * 1e-3) / 1e12
-            roofline = {"bound": "mfma", "kernel": lib.ss_prof_class_name(dom).decode(), "achieved": round(ach, 3),
-                        "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
-                        "traffic": None, "launches": int(n.value), "avg_launch_us": round(1e3 * ms.value / n.value, 2),
-                        "algo_gflop_per_launch": round(fl.value / n.value / 1e9, 4),
-                        "share_of_wall": round(ms.value * 1e-3 / wall, 3)}
+    def read_class(c):
+        ms, fl, n, by = C.c_double(), C.c_double(), C.c_int64(), C.c_double()
+        lib.ss_prof_read(c, C.byref(ms), C.byref(fl), C.byref(n), C.byref(by))
+        return ms.value, fl.value, n.value, by.value
+
+    def roofline_of(c):
+        ms, fl, n, by = read_class(c)
+        if n == 0 or ms <= 0:
+            return None
+        name = lib.ss_prof_class_name(c).decode()
+        common = {"kernel": name, "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
+                  "algo_gflop_per_launch": round(fl / n / 1e9, 4), "algo_mbytes_per_launch": round(by / n / 1e6, 3),
+                  "traffic": None, "kernel_time_over_wall": round(ms * 1e-3 / wall, 3)}
+        if name.startswith("smallm"):
+            # M <= 128 projections / M = 1 decode GEMVs stream their weights once: HBM-side roofline
+            ach = by / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                    "frac": round(ach / PEAK_HBM_GBS, 4), **common}
+        ach = fl / (ms * 1e-3) / 1e12
+        return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), **common}
+
+    roofline = roofline_of(dom) if dom is not None else None
+    roofline_conv = roofline_of(dom_conv) if dom_conv is not None and dom_conv != dom else None
 
     if rank == 0:
         out = {
@@ -192,8 +280,11 @@ def main():
                                    "fbank+encoder+CTC+AR-MT+T2U+NAR-unit+vocoder HIP path, random-init weights "
                                    "of the streamspeech.offline.fr-en architecture",
                        "audio_seconds_per_gpu": round(sum(u.seconds for u in mine[Wn:Wn + K]), 2),
+                       "concurrent_utterances_per_gpu": S,
                        "parallelism": f"utterance-dp{world}"},
+            "latency_ms_single_stream": round(single_ms, 3), "rtfx_single_stream": round(single_rtfx, 2),
             "roofline": roofline,
+            "roofline_mfma_conv": roofline_conv,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, all_utts[Wn:Wn + K + 1])

@@ -126,12 +126,17 @@ int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_codes, int 
 /* ---- profiling hooks for bench.py's roofline leg: bracket every conv-GEMM launch whose tile
  * configuration is in cls_mask with HIP events recorded on the launch stream.  ss_prof_read
  * synchronises on the recorded events and returns the summed kernel time, the summed algorithmic
- * FLOPs (2*M*N*taps*Cin per launch) and the launch count of class `cls`. */
+ * FLOPs (2*M*N*taps*Cin per launch), the launch count and the summed algorithmic bytes (weights,
+ * inputs, outputs, residuals once each) of class `cls`. */
 int ss_prof_enable(int cls_mask);
 int ss_prof_reset(void);
-int ss_prof_read(int cls, double* h_ms_total, double* h_flops_total, int64_t* h_launches);
+int ss_prof_read(int cls, double* h_ms_total, double* h_flops_total, int64_t* h_launches,
+                 double* h_bytes_total);
 int ss_prof_num_classes(void);
 const char* ss_prof_class_name(int cls);
+
+/* Tuning hook for tools/conv_bench.py: force the LDS-tiled GEMM tile (bm = 0: heuristic). */
+int ss_debug_force_tile(int bm, int bn, int ks);
 
 /* ---- op-level entry points (unit tests of single kernels; same launchers the stages use) ---- */
 int ss_op_conv_gemm(void* stream, const float* dA, int lda, const float* dW, const float* dbias,

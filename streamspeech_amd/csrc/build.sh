@@ -8,10 +8,12 @@ mkdir -p build
 for f in gemm attention elementwise fbank model; do
   if [ ! -f build/$f.o ] || [ $f.hip -nt build/$f.o ] || [ -n "$(find . -maxdepth 1 -name '*.hpp' -newer build/$f.o)" ] \
      || [ ../../include/streamspeech_hip.h -nt build/$f.o ]; then
-    $HIPCC $FLAGS -c $f.hip -o build/$f.o &
+    ( $HIPCC $FLAGS -c $f.hip -o build/$f.o.tmp && mv build/$f.o.tmp build/$f.o ) || { rm -f build/$f.o build/$f.o.tmp; touch build/.failed; } &
   fi
 done
+rm -f build/.failed
 wait
+if [ -f build/.failed ]; then echo "build FAILED"; rm -f build/.failed; exit 1; fi
 $HIPCC --offload-arch=gfx950 -shared -fPIC build/gemm.o build/attention.o build/elementwise.o build/fbank.o build/model.o \
   -o ../libstreamspeech_hip.so
 echo "built $(realpath ../libstreamspeech_hip.so)"

@@ -10,6 +10,7 @@
 // C/D layout (MI355X guide §3): col = lane&15, row = (lane>>4)*4 + reg.
 #include "gemm.hpp"
 
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -18,9 +19,14 @@ namespace ss {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-template <int BM, int BN, int BK, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+// KS > 1: intra-workgroup split-K.  The workgroup has KS groups of 4 waves; every group owns the
+// whole BM x BN tile but only 1/KS of the k-steps, with private LDS staging, and the partial tiles
+// are summed (fixed order) through LDS before the epilogue.  This fills all 1024 SIMDs when M*N
+// alone gives too few tiles (early vocoder stages, M~500 decoder GEMMs) without atomics or a
+// second launch.
+template <int BM, int BN, int BK, int WM, int WN, int KS, int PD>
+__global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
+  static_assert(WM * WN == 4, "4 waves per k-group");
   constexpr int LDK = BK + 4;  // +4 floats keeps 16-B alignment and staggers banks
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
@@ -29,9 +35,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
   constexpr int A_F4 = BM * KQ, W_F4 = BN * KQ;
   constexpr int NA = (A_F4 + 255) / 256, NW = (W_F4 + 255) / 256;
   constexpr int STAGE = (BM + BN) * LDK;
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  extern __shared__ __attribute__((aligned(16))) float smem_all[];
+  const int kg = threadIdx.x >> 8;                     // k-group of this thread
+  float* smem = smem_all + kg * 2 * STAGE;
 
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int t = threadIdx.x & 255, lane = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int r = lane & 15, g = lane >> 4;
 
@@ -75,38 +83,51 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
     w_lds[i] = BM * LDK + row * LDK + c4 * 4;
   }
 
-  f32x4 ra[NA], rw[NW];
-  auto load_regs = [&](int kb) {
-    const int tap = kb / kpt;
-    const int ci0 = (kb - tap * kpt) * BK;
+  // Register ring of PD k-steps: the global loads of step k+PD are issued before the MFMAs of
+  // step k, so a load has PD steps of MFMA work to land before its turn to be written to LDS
+  // (the leaky-ReLU input activation is applied at that write, never right after the load).
+  f32x4 ra[PD][NA], rw[PD][NW];
+  auto load_regs = [&](auto SLOT, bool valid, int kb, int tap, int ci0) {
+    constexpr int sl = decltype(SLOT)::value;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
       const int rin = a_rin0[i] + tap * p.dil;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_ok[i] && rin >= 0 && rin < in_len && rin < a_lim[i]) {
+#ifdef SS_ABLATE
+      if (!(p.dbg & 1))
+#endif
+      if (valid && a_ok[i] && rin >= 0 && rin < in_len && rin < a_lim[i])
         v = *reinterpret_cast<const f32x4*>(p.A + (size_t)(in_start + rin) * p.lda + ci0 + a_c4[i]);
-        if (p.in_act == ACT_LRELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.in_slope;
-        }
-      }
-      ra[i] = v;
+      ra[sl][i] = v;
     }
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (w_ok[i]) v = *reinterpret_cast<const f32x4*>(p.W + w_off[i] + (size_t)kb * BK);
-      rw[i] = v;
+#ifdef SS_ABLATE
+      if (!(p.dbg & 1))
+#endif
+      if (valid && w_ok[i]) v = *reinterpret_cast<const f32x4*>(p.W + w_off[i] + (size_t)kb * BK);
+      rw[sl][i] = v;
     }
   };
-  auto store_lds = [&](int buf) {
+  const bool lrelu = p.in_act == ACT_LRELU;
+  const float slope = p.in_slope;
+  auto store_lds = [&](auto SLOT, int buf) {
+    constexpr int sl = decltype(SLOT)::value;
     float* base = smem + buf * STAGE;
 #pragma unroll
     for (int i = 0; i < NA; ++i)
-      if (t + i * 256 < A_F4) *reinterpret_cast<f32x4*>(base + a_lds[i]) = ra[i];
+      if (t + i * 256 < A_F4) {
+        f32x4 v = ra[sl][i];
+        if (lrelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        }
+        *reinterpret_cast<f32x4*>(base + a_lds[i]) = v;
+      }
 #pragma unroll
     for (int i = 0; i < NW; ++i)
-      if (t + i * 256 < W_F4) *reinterpret_cast<f32x4*>(base + w_lds[i]) = rw[i];
+      if (t + i * 256 < W_F4) *reinterpret_cast<f32x4*>(base + w_lds[i]) = rw[sl][i];
   };
 
   f32x4 acc[TM][TN];
@@ -115,32 +136,91 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = {0.f, 0.f, 0.f, 0.f};
 
-  load_regs(0);
-  store_lds(0);
+  // k-steps of this group: [kb0, kb1); every group runs `kper` iterations (steps past kb1 load
+  // zeros) so barriers and the MFMA body stay uniform
+  const int kper = (nk + KS - 1) / KS;
+  const int kb0 = kg * kper;
+  const int kb1 = min(nk, kb0 + kper);
+  int ntap = kb0 / kpt;                      // (tap, channel offset) of the next step to load
+  int nci = (kb0 - ntap * kpt) * BK;
+  auto advance = [&]() { nci += BK; if (nci >= p.Cin) { nci = 0; ++ntap; } };
+  auto for_slots = [&](auto&& fn) {          // fn(integral_constant<u>) for u = 0..PD-1
+    fn(std::integral_constant<int, 0>{});
+    if constexpr (PD > 1) fn(std::integral_constant<int, 1>{});
+    if constexpr (PD > 2) fn(std::integral_constant<int, 2>{});
+    if constexpr (PD > 3) fn(std::integral_constant<int, 3>{});
+  };
+  for_slots([&](auto U) {
+    constexpr int u = decltype(U)::value;
+    load_regs(U, kb0 + u < kb1, kb0 + u, ntap, nci);
+    advance();
+  });
+  store_lds(std::integral_constant<int, 0>{}, 0);
   __syncthreads();
 
-  for (int kb = 0; kb < nk; ++kb) {
-    const int cur = kb & 1;
-    if (kb + 1 < nk) load_regs(kb + 1);
-    const float* As = smem + cur * STAGE + (wm * WTM + r) * LDK + g * 4;
-    const float* Ws = smem + cur * STAGE + BM * LDK + (wn * WTN + r) * LDK + g * 4;
+  for (int it0 = 0; it0 < kper; it0 += PD) {
+    for_slots([&](auto U) {
+      constexpr int u = decltype(U)::value;
+      const int it = it0 + u;
+      if (it < kper) {                       // block-uniform
+        const int cur = it & 1;
+        load_regs(U, kb0 + it + PD < kb1, kb0 + it + PD, ntap, nci);   // slot u (step it) is already in LDS
+        advance();
+        const float* As = smem + cur * STAGE + (wm * WTM + r) * LDK + g * 4;
+        const float* Ws = smem + cur * STAGE + BM * LDK + (wn * WTN + r) * LDK + g * 4;
+#ifdef SS_ABLATE
+        if (!(p.dbg & 2))
+#endif
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      f32x4 af[TM], bf[TN];
+        for (int kk = 0; kk < BK / 16; ++kk) {
+          f32x4 af[TM], bf[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 16 * LDK + kk * 16);
+          for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(As + i * 16 * LDK + kk * 16);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Ws + j * 16 * LDK + kk * 16);
+          for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Ws + j * 16 * LDK + kk * 16);
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
+          for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+#ifdef SS_ABLATE
+        if (!(p.dbg & 4))
+#endif
+        if (it + 1 < kper) store_lds(std::integral_constant<int, (u + 1) % PD>{}, cur ^ 1);
+#ifdef SS_ABLATE
+        if (!(p.dbg & 8))
+#endif
+        __syncthreads();
+      }
+    });
+  }
+
+  if (KS > 1) {
+    // partial tiles of groups 1..KS-1 -> LDS (staging buffers are dead now), group 0 sums in order
+    f32x4* red = reinterpret_cast<f32x4*>(smem_all);
+    constexpr int PER_GROUP = 4 * TM * TN * 64;
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          red[(kg - 1) * PER_GROUP + ((wave * TM + i) * TN + j) * 64 + lane] = acc[i][j];
     }
-    if (kb + 1 < nk) store_lds(cur ^ 1);
     __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int s2 = 1; s2 < KS; ++s2)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const f32x4 o = red[(s2 - 1) * PER_GROUP + ((wave * TM + i) * TN + j) * 64 + lane];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i][j][e] += o[e];
+        }
   }
 
   // ---- epilogue ----
@@ -348,10 +428,11 @@ static const char* kTileNames[kNumTileCfg] = {
     "conv_gemm<16,128,16,1,4>", "conv_gemm<128,128,16,2,2>", "conv_gemm<128,64,32,2,2>", "conv_gemm<64,64,32,2,2>",
     "conv_gemm<64,64,16,2,2>", "conv_gemm<32,64,32,2,2>", "conv_gemm<32,64,16,2,2>", "conv_gemm<32,32,32,2,2>",
     "smallm_gemm<4,1>", "smallm_gemm<2,2>", "smallm_gemm<1,4>", "reserved"};
-struct ProfRec { hipEvent_t e0, e1; double flops; int cls; };
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int cls; };
 static int g_prof_mask = 0;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
+static std::mutex g_prof_mu;
 
 void prof_enable(int cls_mask) { g_prof_mask = cls_mask; }
 const char* prof_cfg_name(int cls) { return (cls >= 0 && cls < kNumTileCfg) ? kTileNames[cls] : "?"; }
@@ -359,46 +440,77 @@ void prof_reset() {
   for (auto& r : g_prof_recs) g_prof_pool.push_back({r.e0, r.e1});
   g_prof_recs.clear();
 }
-int prof_read(int cls, double* ms_total, double* flops_total, long long* launches) {
-  double ms = 0, fl = 0; long long n = 0;
+int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total) {
+  double ms = 0, fl = 0, by = 0; long long n = 0;
   for (auto& r : g_prof_recs) {
     if (r.cls != cls) continue;
     if (hipEventSynchronize(r.e1) != hipSuccess) return SS_ERR_HIP;
     float t = 0.f;
     if (hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) return SS_ERR_HIP;
-    ms += t; fl += r.flops; ++n;
+    ms += t; fl += r.flops; by += r.bytes; ++n;
   }
   if (ms_total) *ms_total = ms;
   if (flops_total) *flops_total = fl;
   if (launches) *launches = n;
+  if (bytes_total) *bytes_total = by;
   return SS_OK;
 }
 
 static int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, bool& prof) {
   prof = (g_prof_mask >> cls) & 1;
   if (!prof) return SS_OK;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_pool.empty()) { rec.e0 = g_prof_pool.back().first; rec.e1 = g_prof_pool.back().second; g_prof_pool.pop_back(); }
   else { SS_HIP_CHECK(hipEventCreate(&rec.e0)); SS_HIP_CHECK(hipEventCreate(&rec.e1)); }
   rec.cls = cls;
   rec.flops = a.algo_flops > 0 ? a.algo_flops : 2.0 * (double)a.M * a.N * a.taps * a.Cin;
+  // algorithmic bytes: weights + bias once, every input row once, every output element once,
+  // residual operands once (all f32)
+  const double ncols = a.glu ? a.N / 2 : a.N;
+  rec.bytes = 4.0 * ((double)a.N * a.taps * a.Cin + (a.bias ? a.N : 0) + (double)a.in_len * a.Cin +
+                     (double)a.M * ncols * (1 + (a.R ? 1 : 0) + (a.R2 ? 1 : 0)));
   SS_HIP_CHECK(hipEventRecord(rec.e0, stream));
   return SS_OK;
 }
 static int prof_end(hipStream_t stream, ProfRec& rec, bool prof) {
-  if (prof) { SS_HIP_CHECK(hipEventRecord(rec.e1, stream)); g_prof_recs.push_back(rec); }
+  if (prof) { SS_HIP_CHECK(hipEventRecord(rec.e1, stream)); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_recs.push_back(rec); }
   return SS_OK;
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
+// register prefetch depth: measured flat from 1 to 4 on MI355X (profiles/r01_tile_sweep.txt) -> 1
+constexpr int default_pd(int, int) { return 1; }
+
+template <int BM, int BN, int BK, int WM, int WN, int KS = 1, int PD = default_pd(BM, BN)>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream, int cls) {
+  constexpr size_t kLds = (size_t)KS * 2 * (BM + BN) * (BK + 4) * sizeof(float);
+  static_assert(kLds <= 160 * 1024, "LDS budget");
+  static_assert((size_t)(KS - 1) * BM * BN * sizeof(float) <= kLds, "reduction scratch fits the staging buffers");
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (kLds > 64 * 1024)
+      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, KS, PD>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+    attr_set = true;
+  }
   const int mmax = a.nseg > 0 ? a.max_seg_out : a.M;
   dim3 grid(cdiv(mmax, BM), cdiv(a.N, BN), a.nseg > 0 ? a.nseg : 1);
   ProfRec rec{}; bool prof = false;
   int rc = prof_begin(a, stream, cls, rec, prof);
   if (rc != SS_OK) return rc;
-  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN>), grid, dim3(256), 0, stream, a);
+  hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, KS, PD>), grid, dim3(256 * KS), kLds, stream, a);
   SS_LAUNCH_CHECK();
   return prof_end(stream, rec, prof);
+}
+
+// pick the k-split so that tiles * 4 * KS waves cover the 1024 SIMDs (each group keeps >= 2 k-steps)
+template <int BM, int BN, int BK, int WM, int WN, int MAXKS>
+static int launch_cfg_ks(const GemmArgs& a, hipStream_t stream, int cls, long tiles) {
+  const int nk = a.taps * (a.Cin / BK);
+  int ks = 1;
+  while (ks < MAXKS && tiles * 4 * ks < 1024 && nk / (ks * 2) >= 2) ks *= 2;
+  if constexpr (MAXKS >= 4) { if (ks >= 4) return launch_cfg<BM, BN, BK, WM, WN, 4>(a, stream, cls); }
+  if constexpr (MAXKS >= 2) { if (ks >= 2) return launch_cfg<BM, BN, BK, WM, WN, 2>(a, stream, cls); }
+  return launch_cfg<BM, BN, BK, WM, WN, 1>(a, stream, cls);
 }
 
 template <int SK, int WN>
@@ -414,7 +526,11 @@ static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
   return prof_end(stream, rec, prof);
 }
 
+static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
+void debug_force_tile(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn; g_force_ks = ks; }
+
 bool smallm_eligible(const GemmArgs& a) {
+  if (g_force_bm) return false;
   const int M = a.nseg > 0 ? a.max_seg_out : a.M;
   const bool plain_linear = a.taps == 1 && a.stride == 1 && a.pad == 0 && !a.glu && a.nseg == 0 && a.chunk == 0 &&
                             a.in_act == ACT_NONE && !a.R2 && a.div == 0.f &&
@@ -422,7 +538,16 @@ bool smallm_eligible(const GemmArgs& a) {
   return plain_linear && M <= 128 && M > 0 && a.Cin % 64 == 0 && (a.lda & 3) == 0;
 }
 
-int launch_conv_gemm(const GemmArgs& a, hipStream_t stream) {
+#ifdef SS_ABLATE
+static int g_dbg = 0;
+void debug_set_ablate(int v) { g_dbg = v; }
+#endif
+
+int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
+#ifdef SS_ABLATE
+  a.dbg = g_dbg;
+#endif
   const int M = a.nseg > 0 ? a.max_seg_out : a.M;
   if (M <= 0 || a.N <= 0) return SS_OK;
   if (a.Cin % 16 != 0 || (a.lda & 3) != 0 || a.taps < 1) return SS_ERR_ARG;
@@ -436,26 +561,42 @@ int launch_conv_gemm(const GemmArgs& a, hipStream_t stream) {
     return launch_smallm<1, 4>(a, stream, 14);
   }
   if (a.ln_g) return SS_ERR_ARG;  // LayerNorm fusion exists only on the small-M path
-  if (a.N <= 16) return launch_cfg<128, 16, 16, 4, 1>(a, stream, 0);
+  if (g_force_bm && a.N > 32 && k32) {   // tuning hook (tools/conv_bench.py): ks = KS*10 + PD
+    const int f = g_force_bm * 10000 + g_force_bn * 100 + g_force_ks;
+    switch (f) {
+#define SS_CASE(BM_, BN_, KS_, PD_, CLS_) case BM_ * 10000 + BN_ * 100 + KS_ * 10 + PD_: return launch_cfg<BM_, BN_, 32, 2, 2, KS_, PD_>(a, stream, CLS_);
+      SS_CASE(64, 64, 1, 1, 7) SS_CASE(64, 64, 1, 2, 7) SS_CASE(64, 64, 1, 3, 7)
+      SS_CASE(64, 64, 2, 2, 7) SS_CASE(64, 64, 2, 3, 7)
+      SS_CASE(32, 64, 1, 1, 9) SS_CASE(32, 64, 1, 2, 9) SS_CASE(32, 64, 1, 3, 9) SS_CASE(32, 64, 1, 4, 9)
+      SS_CASE(32, 64, 2, 3, 9) SS_CASE(32, 64, 4, 3, 9)
+      SS_CASE(32, 32, 1, 1, 11) SS_CASE(32, 32, 1, 2, 11) SS_CASE(32, 32, 1, 3, 11) SS_CASE(32, 32, 1, 4, 11)
+      SS_CASE(32, 32, 2, 3, 11) SS_CASE(32, 32, 4, 3, 11)
+#undef SS_CASE
+      default: break;
+    }
+  }
+  if (a.N <= 16) return launch_cfg_ks<128, 16, 16, 4, 1, 2>(a, stream, 0, (long)cdiv(M, 128) * nseg);
   if (a.N <= 32 && !a.glu) {
-    return k32 ? launch_cfg<128, 32, 32, 4, 1>(a, stream, 1) : launch_cfg<128, 32, 16, 4, 1>(a, stream, 2);
+    const long tl = (long)cdiv(M, 128) * nseg;
+    return k32 ? launch_cfg_ks<128, 32, 32, 4, 1, 2>(a, stream, 1, tl) : launch_cfg_ks<128, 32, 16, 4, 1, 2>(a, stream, 2, tl);
   }
   if (M <= 16) {
     return k32 ? launch_cfg<16, 128, 32, 1, 4>(a, stream, 3) : launch_cfg<16, 128, 16, 1, 4>(a, stream, 4);
   }
+  // Tile choice (tools/conv_bench.py sweep on MI355X, profiles/r01_tile_sweep.txt): these problems are
+  // a few GFLOP at most, so what matters is an even spread over 1024 SIMDs with several resident
+  // workgroups per CU -- small 32x32 tiles, plus intra-workgroup split-K when even those are few.
   const long t128 = (long)cdiv(M, 128) * cdiv(a.N, 128) * nseg;
-  const long t12864 = (long)cdiv(M, 128) * cdiv(a.N, 64) * nseg;
-  const long t64 = (long)cdiv(M, 64) * cdiv(a.N, 64) * nseg;
-  if (t128 >= 192) return launch_cfg<128, 128, 16, 2, 2>(a, stream, 5);
-  if (t12864 >= 192 && k32) return launch_cfg<128, 64, 32, 2, 2>(a, stream, 6);
-  if (t64 >= 384) {
-    return k32 ? launch_cfg<64, 64, 32, 2, 2>(a, stream, 7) : launch_cfg<64, 64, 16, 2, 2>(a, stream, 8);
-  }
+  const long t3232 = (long)cdiv(M, 32) * cdiv(a.N, 32) * nseg;
   const long t3264 = (long)cdiv(M, 32) * cdiv(a.N, 64) * nseg;
-  if (t3264 >= 384 || !k32 || a.glu) {
-    return k32 ? launch_cfg<32, 64, 32, 2, 2>(a, stream, 9) : launch_cfg<32, 64, 16, 2, 2>(a, stream, 10);
+  if (t128 >= 1024) return launch_cfg<128, 128, 16, 2, 2>(a, stream, 5);
+  if (!k32 || a.glu) {
+    return k32 ? launch_cfg_ks<32, 64, 32, 2, 2, 4>(a, stream, 9, t3264) : launch_cfg_ks<32, 64, 16, 2, 2, 4>(a, stream, 10, t3264);
   }
-  return launch_cfg<32, 32, 32, 2, 2>(a, stream, 11);
+  const int nk = a.taps * (a.Cin / 32);
+  if (t3232 >= 700 || nk < 4) return launch_cfg<32, 32, 32, 2, 2, 1>(a, stream, 11);
+  if (t3232 >= 300 || nk < 8) return launch_cfg<32, 32, 32, 2, 2, 2>(a, stream, 11);
+  return launch_cfg<32, 32, 32, 2, 2, 4>(a, stream, 11);
 }
 
 }  // namespace ss

@@ -40,6 +40,9 @@ struct GemmArgs {
   // A' = (A - mean) * rstd * ln_g + ln_b, eps 1e-5 -- saves the separate LayerNorm launch.
   const float* ln_g = nullptr;
   const float* ln_b = nullptr;
+#ifdef SS_ABLATE
+  int dbg = 0;                // timing-only ablation switches (tools/, never in the product build)
+#endif
 };
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
@@ -47,12 +50,15 @@ struct GemmArgs {
 constexpr int kNumTileCfg = 16;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
-int prof_read(int cls, double* ms_total, double* flops_total, long long* launches);  // synchronises
+int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
 const char* prof_cfg_name(int cls);
 
 // True when launch_conv_gemm would route `a` to the small-M kernel (the only one with the fused
 // LayerNorm prologue).
 bool smallm_eligible(const GemmArgs& a);
+
+// Tuning hook: force the tile of the LDS-tiled kernel (bm = 0 restores the heuristic).
+void debug_force_tile(int bm, int bn, int ks);
 
 // Launches on `stream`; returns SS_OK / SS_ERR_*.
 int launch_conv_gemm(const GemmArgs& a, hipStream_t stream);

@@ -466,7 +466,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
   // step `start`: feed [eos, prefix...] in one pass
   RET(ss_mt_append(m, stream, tok, start + 1, 0, start < min_len, start >= max_len, d_feats, tok + start + 1));
   int step = start + 1;      // next position to feed == index of the newest generated token
-  int n_gen = 1, eos_at = -1, checked = start + 1;
+  int eos_at = -1, checked = start + 1;
   while (true) {
     const bool last = step > max_len;
     if (last || (step - (start + 1)) % kCheck == kCheck - 1) {
@@ -479,7 +479,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
     }
     RET(ss_mt_append(m, stream, tok + step, 1, step, step < min_len, step >= max_len,
                      d_feats + (size_t)step * D, tok + step + 1));
-    ++step; ++n_gen;
+    ++step;
   }
   const int end = eos_at >= 0 ? eos_at : step;          // index of the last generated token
   const int n_out = end - start;                          // tokens after the prefix (incl. a final eos)
@@ -727,11 +727,13 @@ extern "C" int ss_op_dwconv_bn_silu(void* stream, const float* dx, int ldx, floa
 
 extern "C" int ss_prof_enable(int cls_mask) { prof_enable(cls_mask); return SS_OK; }
 extern "C" int ss_prof_reset(void) { prof_reset(); return SS_OK; }
-extern "C" int ss_prof_read(int cls, double* ms, double* flops, int64_t* launches) {
+extern "C" int ss_prof_read(int cls, double* ms, double* flops, int64_t* launches, double* bytes) {
   long long n = 0;
-  int rc = prof_read(cls, ms, flops, &n);
+  int rc = prof_read(cls, ms, flops, &n, bytes);
   if (launches) *launches = n;
   return rc;
 }
 extern "C" int ss_prof_num_classes(void) { return kNumTileCfg; }
 extern "C" const char* ss_prof_class_name(int cls) { return prof_cfg_name(cls); }
+
+extern "C" int ss_debug_force_tile(int bm, int bn, int ks) { debug_force_tile(bm, bn, ks); return SS_OK; }

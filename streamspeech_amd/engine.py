@@ -41,12 +41,17 @@ class HipModel:
     """ss_model handle + packed weights (StreamSpeechModel replacement)."""
 
     def __init__(self, state_dict, cfg: ModelConfig = None, device="cuda:0", cmvn_mean=None, cmvn_std=None,
-                 max_rel_pos: int = 2048, max_tgt_pos: int = 1026):
+                 max_rel_pos: int = 2048, max_tgt_pos: int = 1026, _share=None):
         self.lib = L.load()
         self.cfg = cfg or ModelConfig()
         self.device = _require_gpu(device)
-        names, offsets, numels, blob = pack_model(state_dict, self.cfg, cmvn_mean, cmvn_std, max_rel_pos, max_tgt_pos)
-        self.blob = blob.to(self.device)
+        if _share is not None:      # another execution context over the same (read-only) weight blob
+            names, offsets, numels, self.blob = _share
+        else:
+            names, offsets, numels, blob = pack_model(state_dict, self.cfg, cmvn_mean, cmvn_std, max_rel_pos, max_tgt_pos)
+            self.blob = blob.to(self.device)
+        self._packed = (names, offsets, numels, self.blob)
+        self._dims = (max_rel_pos, max_tgt_pos)
         c = self.cfg
         self.c_cfg = L.SSConfig(
             c.input_feat, c.conv_channels, c.conv_kernel, c.enc_dim, c.enc_ffn, c.enc_heads, c.enc_layers,
@@ -59,6 +64,12 @@ class HipModel:
                                              C.byref(h)), "ss_model_create")
         self.h = h
         self.max_tgt_pos = max_tgt_pos
+
+    def new_context(self) -> "HipModel":
+        """A second ss_model handle (own scratch / KV caches) borrowing the same weights: one per
+        concurrent utterance stream."""
+        return HipModel(None, self.cfg, device=str(self.device), max_rel_pos=self._dims[0],
+                        max_tgt_pos=self._dims[1], _share=self._packed)
 
     def __del__(self):
         try:
@@ -157,12 +168,16 @@ class HipModel:
 class HipVocoder:
     """ss_vocoder handle (CodeHiFiGANVocoderWithDur replacement)."""
 
-    def __init__(self, generator_state_dict, cfg: VocoderConfig = None, device="cuda:0"):
+    def __init__(self, generator_state_dict, cfg: VocoderConfig = None, device="cuda:0", _share=None):
         self.lib = L.load()
         self.cfg = cfg or VocoderConfig()
         self.device = _require_gpu(device)
-        names, offsets, numels, blob = pack_vocoder(generator_state_dict, self.cfg)
-        self.blob = blob.to(self.device)
+        if _share is not None:
+            names, offsets, numels, self.blob = _share
+        else:
+            names, offsets, numels, blob = pack_vocoder(generator_state_dict, self.cfg)
+            self.blob = blob.to(self.device)
+        self._packed = (names, offsets, numels, self.blob)
         c = self.cfg
         cc = L.SSVocoderConfig()
         cc.num_embeddings, cc.embedding_dim, cc.model_in_dim = c.num_embeddings, c.embedding_dim, c.model_in_dim
@@ -186,6 +201,9 @@ class HipVocoder:
         self.h = h
         self.hop = int(np.prod(c.upsample_rates))
         self.max_dur = 64
+
+    def new_context(self) -> "HipVocoder":
+        return HipVocoder(None, self.cfg, device=str(self.device), _share=self._packed)
 
     def __del__(self):
         try:

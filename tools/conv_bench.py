@@ -34,10 +34,31 @@ def bench(name, M, N, Cin, taps=1, dil=1, reps=20):
     us = e0.elapsed_time(e1) * 1e3 / reps
     gf = 2.0 * M * N * taps * Cin / 1e9
     return {"name": name, "M": M, "N": N, "K": taps * Cin, "us": round(us, 2), "gflop": round(gf, 3),
-            "tflops": round(gf / us * 1e-3 * 1e3, 2)}
+            "tflops": round(gf / (us * 1e-6) / 1e3, 2)}
+
+
+def sweep():
+    """tile sweep on representative shapes (N > 32, Cin % 32 == 0)."""
+    shapes = [("stage0 k11", 1125, 256, 256, 11), ("stage0 k3", 1125, 256, 256, 3), ("stage1 k11", 4500, 128, 128, 11),
+              ("stage1 k3", 4500, 128, 128, 3), ("stage2 k11", 18000, 64, 64, 11), ("stage2 k3", 18000, 64, 64, 3),
+              ("up0", 225, 1280, 512, 3), ("unit fc2", 425, 512, 2048, 1), ("unit fc1", 425, 2048, 512, 1),
+              ("unit qkv", 425, 1536, 512, 1), ("sub1", 112, 512, 512, 5)]
+    tiles = [(64, 64, 11), (64, 64, 12), (64, 64, 13), (64, 64, 23), (32, 64, 11), (32, 64, 12), (32, 64, 13), (32, 64, 14),
+             (32, 64, 23), (32, 64, 43), (32, 32, 11), (32, 32, 12), (32, 32, 13), (32, 32, 14), (32, 32, 23), (32, 32, 43)]
+    print("%-12s" % "shape" + "".join("%9s" % f"{a}x{b}/{k}" for a, b, k in tiles))
+    for name, M, N, Cin, taps in shapes:
+        line = "%-12s" % name
+        for bm, bn, ks in tiles:
+            lib.ss_debug_force_tile(bm, bn, ks)
+            r = bench(name, M, N, Cin, taps, 1, reps=10)
+            line += "%9.1f" % r["us"]
+        print(line, flush=True)
+    lib.ss_debug_force_tile(0, 0, 0)
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep":
+        return sweep()
     F = 225  # frames of a 4.5 s utterance
     rows = []
     T, Cc = F, 512
