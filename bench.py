@@ -25,7 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from streamspeech_amd import lib as L                      # noqa: E402
-from streamspeech_amd import synth, workload               # noqa: E402
+from streamspeech_amd import dp, synth, workload           # noqa: E402
 from streamspeech_amd.config import ModelConfig, VocoderConfig  # noqa: E402
 from streamspeech_amd.engine import HipModel, HipVocoder   # noqa: E402
 from streamspeech_amd.pipeline import mt_greedy, units_from_tokens  # noqa: E402
@@ -106,7 +106,7 @@ def cpu_baseline(sd, vsd, cfg, vcfg, utts, budget_s=25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20, help="timed utterances per GPU")
+    ap.add_argument("--steps", type=int, default=48, help="timed utterances per GPU")
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
@@ -137,7 +137,7 @@ def main():
 
     K, Wn = args.steps, args.warmup
     all_utts = workload.make_utterances((K + Wn) * world)
-    mine = workload.shard(all_utts, rank, world)            # weak scaling: K + W utterances per rank
+    mine = dp.shard(all_utts, rank, world)                  # weak scaling: K + W utterances per rank
     pcms = [torch.from_numpy(synth.synth_pcm(1234 + u.idx, u.n_samples)).to(dev) for u in mine]
     torch.cuda.synchronize()
 
@@ -234,14 +234,7 @@ def main():
         raise errors[0]
 
     audio = sum(u.seconds for u in mine[Wn:Wn + K])
-    stats = torch.tensor([wall, audio, float(K)], dtype=torch.float64, device=dev)
-    if dist is not None:
-        mx = stats.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(stats, op=dist.ReduceOp.SUM)
-        wall, audio, nutt = float(mx[0]), float(stats[1]), float(stats[2])
-    else:
-        nutt = float(K)
+    wall, audio, nutt = dp.reduce_stats(dist, wall, audio, float(K), device=dev)
 
     def read_class(c):
         ms, fl, n, by = C.c_double(), C.c_double(), C.c_int64(), C.c_double()

@@ -1,0 +1,58 @@
+"""N > 1 path on CPU: world_size-2 gloo run of the utterance-DP sharding and statistics reduction
+that bench.py uses (no GPU, no HIP compute)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from streamspeech_amd import dp, workload
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    utts = workload.make_utterances(10)
+    mine = dp.shard(utts, rank, world)
+    dist.barrier()
+    wall = 1.0 + rank            # rank 1 is the straggler
+    audio = sum(u.seconds for u in mine)
+    w, a, n = dp.reduce_stats(dist, wall, audio, float(len(mine)))
+    q.put((rank, [u.idx for u in mine], w, a, n))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_and_reduction():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    utts = workload.make_utterances(10)
+    idx = sorted(res[0][1] + res[1][1])
+    assert idx == list(range(10)) and not set(res[0][1]) & set(res[1][1])      # a partition
+    total_audio = sum(u.seconds for u in utts)
+    for _, _, w, a, n in res:
+        assert w == 2.0 and abs(a - total_audio) < 1e-9 and n == 10.0          # MAX wall, SUM audio / utterances
+
+
+def test_balanced_shards():
+    durs = [u.seconds for u in workload.make_utterances(64)]
+    sh = dp.balanced_shards(durs, 8)
+    assert sorted(i for s in sh for i in s) == list(range(64))
+    loads = [sum(durs[i] for i in s) for s in sh]
+    assert max(loads) / min(loads) < 1.15
