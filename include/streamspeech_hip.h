@@ -123,6 +123,34 @@ int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_codes, int 
                        const int32_t* d_forced_dur, float* d_wav, int64_t wav_capacity,
                        int32_t* d_dur, int64_t* h_n_samples);
 
+/* ---- ragged-batch twins (BASELINE.json configs[3]/[4]: many utterances per GPU) --------------
+ * B independent utterances packed along the row axis (no padding; each keeps the B = 1 arithmetic
+ * of the entry points above -- SURVEY.md H2b).  h_* arrays are host arrays of length B; packed
+ * device buffers are the concatenation of the per-utterance arrays in batch order. */
+int ss_batch_fbank_cmvn(ss_model* m, void* stream, int B, const float* d_pcm, const int64_t* h_pcm_start,
+                        const int32_t* h_n_samples, float pcm_scale, float* d_feat, int32_t* h_T);
+int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const float* d_fbank, const int32_t* h_T,
+                             int attn_chunk, int conv_chunk, float* d_enc_out, int32_t* h_Tp);
+int ss_batch_ctc_greedy(ss_model* m, void* stream, int head, int B, const float* d_enc_out,
+                        const int32_t* h_Tp, int32_t* d_raw, int32_t* d_tokens, int32_t* d_index,
+                        int32_t* d_counts);
+/* Lockstep beam-1 search from [</s>] (offline: no prefix).  h_max_len[b] = forced-</s> step of
+ * utterance b.  h_out_tokens [B][out_stride] receives the generated tokens (incl. the final </s>),
+ * h_n_out[b] their number (= rows of valid decoder states); d_feats is [B][feat_rows][dec_dim].
+ * B <= 128.  Synchronises. */
+int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float* d_enc_out, const int32_t* h_Tp,
+                       const int32_t* h_max_len, int min_len, int32_t* h_out_tokens, int out_stride,
+                       int32_t* h_n_out, float* d_feats, int feat_rows);
+int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float* d_feats, int feat_rows,
+                       const int32_t* h_n, int t2u_causal, int mask_eos, int32_t* d_raw, int32_t* d_tokens,
+                       int32_t* d_counts);
+/* d_codes / d_dur / d_forced_dur packed [sum K]; d_wav packed, utterance b at h_wav_start[b] with
+ * h_n_samples[b] samples.  Synchronises once. */
+int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, const int32_t* d_codes, const int32_t* h_K,
+                             int dur_prediction, const int32_t* d_forced_dur, float* d_wav,
+                             int64_t wav_capacity, int32_t* d_dur, int64_t* h_wav_start,
+                             int64_t* h_n_samples);
+
 /* ---- profiling hooks for bench.py's roofline leg: bracket every conv-GEMM launch whose tile
  * configuration is in cls_mask with HIP events recorded on the launch stream.  ss_prof_read
  * synchronises on the recorded events and returns the summed kernel time, the summed algorithmic

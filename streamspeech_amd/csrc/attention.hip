@@ -21,7 +21,15 @@ __device__ __forceinline__ float rdlane(float v, int l) {
 }
 
 template <bool RELPOS>
-__global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
+  if (p.nseg > 0) {   // ragged batch: rebase this workgroup onto its utterance
+    const int* sg = p.segs + 4 * blockIdx.z;
+    p.Tq = sg[1]; p.Tk = sg[3];
+    if ((int)blockIdx.x * QB >= p.Tq) return;
+    p.Q += (size_t)sg[0] * p.ldq; p.O += (size_t)sg[0] * p.ldo;
+    p.K += (size_t)sg[2] * p.ldk; p.V += (size_t)sg[2] * p.ldv;
+    if (RELPOS) p.P += (size_t)(p.p_tmax - p.Tk) * p.ldp;
+  }
   __shared__ float Ks[KT * LDKS];
   __shared__ float Vs[KT * DH];
   __shared__ float Ps[RELPOS ? (KT + QB - 1) * LDKS : 1];
@@ -152,8 +160,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const AttnArgs p) {
 // streams its key row (256 contiguous bytes).  P.V: lane = output dim, probabilities broadcast with
 // v_readlane, V rows read coalesced.  Same online softmax as the tiled kernel.
 // -------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attention_decode_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256) void attention_decode_kernel(AttnArgs p) {
   // 4 waves per (query, head): wave w takes key tiles w, w+4, ...; partial (max, sum, acc) merged in LDS
+  if (p.nseg > 0) {
+    const int* sg = p.segs + 4 * blockIdx.z;
+    p.Tq = sg[1]; p.Tk = sg[3];
+    if ((int)blockIdx.x >= p.Tq) return;
+    p.Q += (size_t)sg[0] * p.ldq; p.O += (size_t)sg[0] * p.ldo;
+    p.K += (size_t)sg[2] * p.ldk; p.V += (size_t)sg[2] * p.ldv;
+  }
   __shared__ float part_m[4], part_l[4], part_acc[4][DH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x, h = blockIdx.y;
@@ -211,16 +226,19 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(const AttnArgs p)
 }
 
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
-  if (a.Tq <= 0 || a.Tk <= 0) return SS_OK;
+  const int tq = a.nseg > 0 ? a.max_q : a.Tq;
+  if (tq <= 0 || (a.nseg == 0 && a.Tk <= 0)) return SS_OK;
   if ((a.ldk & 3) || (a.ldv & 3)) return SS_ERR_ARG;
-  dim3 grid(cdiv(a.Tq, QB), a.H);
-  if (!a.P && a.Tq <= 8) {
-    hipLaunchKernelGGL(attention_decode_kernel, dim3(a.Tq, a.H), dim3(256), 0, stream, a);
+  const int gz = a.nseg > 0 ? a.nseg : 1;
+  if (!a.P && tq <= 8) {
+    hipLaunchKernelGGL(attention_decode_kernel, dim3(tq, a.H, gz), dim3(256), 0, stream, a);
     SS_LAUNCH_CHECK();
     return SS_OK;
   }
+  dim3 grid(cdiv(tq, QB), a.H, gz);
   if (a.P) {
-    if (a.Tq != a.Tk || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
+    if ((a.nseg == 0 && a.Tq != a.Tk) || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
+    if (a.nseg > 0 && a.p_tmax <= 0) return SS_ERR_ARG;
     hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, stream, a);
   } else {
     hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, stream, a);

@@ -21,6 +21,11 @@ struct AttnArgs {
   // rel-pos extras (null => plain attention); requires Tq == Tk
   const float* P = nullptr; int ldp = 0;   // projected positional table [2*Tk-1, H*64]
   const float* bias_u = nullptr; const float* bias_v = nullptr;  // [H*64]
+  // Ragged batch (nseg > 0): independent utterances packed along the row axis.  segs[4*s] =
+  // {q_start, q_len, k_start, k_len}: queries/outputs are rows q_start.. of Q/O, keys rows k_start..
+  // of K/V; Tq/Tk above are ignored except max_q (grid sizing).  For the rel-pos form P must point
+  // at row 0 of the FULL table (relative offset p_tmax-1) and the kernel slices it per segment.
+  const int* segs = nullptr; int nseg = 0; int max_q = 0; int p_tmax = 0;
 };
 
 int launch_attention(const AttnArgs& a, hipStream_t stream);

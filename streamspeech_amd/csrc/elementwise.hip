@@ -55,10 +55,15 @@ int launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* ga
 __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
     const float* __restrict__ x, int ldx, float* y, int ldy, const float* __restrict__ wt, int K,
     const float* __restrict__ bn_mean, const float* __restrict__ bn_var, const float* __restrict__ bn_gamma,
-    const float* __restrict__ bn_beta, float bn_eps, int T, int C, int chunk) {
+    const float* __restrict__ bn_beta, float bn_eps, int T, int C, int chunk, const int* __restrict__ segs) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int t = blockIdx.y;
-  if (c >= C) return;
+  if (segs) {   // ragged batch: {row_start, len} per utterance
+    const int st = segs[2 * blockIdx.z];
+    T = segs[2 * blockIdx.z + 1];
+    x += (size_t)st * ldx; y += (size_t)st * ldy;
+  }
+  if (c >= C || t >= T) return;
   const int half = K / 2;
   int lo = t - half, hi = t + half;            // inclusive tap window in input positions
   if (lo < 0) lo = 0;
@@ -73,11 +78,12 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
 
 int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const float* wt, int K,
                           const float* bn_mean, const float* bn_var, const float* bn_gamma,
-                          const float* bn_beta, float bn_eps, int T, int C, int chunk, hipStream_t stream) {
+                          const float* bn_beta, float bn_eps, int T, int C, int chunk, hipStream_t stream,
+                          const int* segs, int nseg) {
   if (T <= 0) return SS_OK;
-  dim3 grid(cdiv(C, 256), T);
+  dim3 grid(cdiv(C, 256), T, nseg > 0 ? nseg : 1);
   hipLaunchKernelGGL(dwconv_bn_silu_kernel, grid, dim3(256), 0, stream, x, ldx, y, ldy, wt, K, bn_mean,
-                     bn_var, bn_gamma, bn_beta, bn_eps, T, C, chunk);
+                     bn_var, bn_gamma, bn_beta, bn_eps, T, C, chunk, nseg > 0 ? segs : nullptr);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
@@ -87,18 +93,18 @@ int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const floa
 // ---------------------------------------------------------------------------------------------
 __global__ void embed_tokens_kernel(const int* __restrict__ tok, const float* __restrict__ emb,
                                     const float* __restrict__ pos_table, float scale, int pos0, float* out,
-                                    int n, int D) {
+                                    int n, int D, int pos_stride) {
   const int i = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= D) return;
-  out[(size_t)i * D + c] = scale * emb[(size_t)tok[i] * D + c] + pos_table[(size_t)(pos0 + i) * D + c];
+  out[(size_t)i * D + c] = scale * emb[(size_t)tok[i] * D + c] + pos_table[(size_t)(pos0 + i * pos_stride) * D + c];
 }
 
 int launch_embed_tokens(const int* tok, const float* emb, const float* pos_table, float scale, int pos0,
-                        float* out, int n, int D, hipStream_t stream) {
+                        float* out, int n, int D, hipStream_t stream, int pos_stride) {
   if (n <= 0) return SS_OK;
   hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, stream, tok, emb, pos_table,
-                     scale, pos0, out, n, D);
+                     scale, pos0, out, n, D, pos_stride);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
@@ -143,12 +149,14 @@ int launch_gather_rows(const int* idx, const float* table, int D, float* out, in
 // logits with those indices skipped; ties resolve to the lowest index like torch.max / topk.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void masked_argmax_kernel(const float* __restrict__ logits, int ld, int M, int N,
-                                                            int mask0, int mask1, int mask2, int force, int* ids) {
+                                                            int mask0, int mask1, int mask2, int force, int* ids,
+                                                            const int* __restrict__ row_max_len, int step, int force_id) {
   // one workgroup per row: 256 threads stride over the vocabulary, wave shuffle + LDS reduce
   __shared__ float sb[4];
   __shared__ int si[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int row = blockIdx.x;
+  if (row_max_len && step >= row_max_len[row]) force = force_id;   // batched search: per-utterance max length
   if (force >= 0) { if (t == 0) ids[row] = force; return; }
   const float* r = logits + (size_t)row * ld;
   float best = -INFINITY;
@@ -177,10 +185,10 @@ __global__ __launch_bounds__(256) void masked_argmax_kernel(const float* __restr
 }
 
 int launch_masked_argmax(const float* logits, int ld, int M, int N, int mask0, int mask1, int mask2,
-                         int force, int* ids, hipStream_t stream) {
+                         int force, int* ids, hipStream_t stream, const int* row_max_len, int step, int force_id) {
   if (M <= 0) return SS_OK;
   hipLaunchKernelGGL(masked_argmax_kernel, dim3(M), dim3(256), 0, stream, logits, ld, M, N, mask0,
-                     mask1, mask2, force, ids);
+                     mask1, mask2, force, ids, row_max_len, step, force_id);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
@@ -189,10 +197,16 @@ int launch_masked_argmax(const float* logits, int ld, int M, int N, int mask0, i
 // CTC collapse: single workgroup, chunks of 1024 frames with a running output offset.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int* __restrict__ raw, int T, int blank, int pad,
-                                                            int* tokens, int* index, int* count) {
+                                                            int* tokens, int* index, int* count,
+                                                            const int* __restrict__ segs) {
   __shared__ int wave_tot[16];
   __shared__ int base_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (segs) {   // one workgroup per utterance: rows [start, start+len) of the packed arrays
+    const int st = segs[2 * blockIdx.x];
+    T = segs[2 * blockIdx.x + 1];
+    raw += st; tokens += st; index += st; count += blockIdx.x;
+  }
   if (t == 0) base_s = 0;
   __syncthreads();
   for (int c0 = 0; c0 < T; c0 += 1024) {
@@ -218,8 +232,9 @@ __global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int* __restric
 }
 
 int launch_ctc_collapse(const int* raw, int T, int blank, int pad, int* tokens, int* index, int* count,
-                        hipStream_t stream) {
-  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(1), dim3(1024), 0, stream, raw, T, blank, pad, tokens, index, count);
+                        hipStream_t stream, const int* segs, int nseg) {
+  hipLaunchKernelGGL(ctc_collapse_kernel, dim3(nseg > 0 ? nseg : 1), dim3(1024), 0, stream, raw, T, blank, pad, tokens,
+                     index, count, nseg > 0 ? segs : nullptr);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
@@ -228,10 +243,17 @@ int launch_ctc_collapse(const int* raw, int T, int blank, int pad, int* tokens, 
 // Duration predictor tail + repeat_interleave
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void dur_predict_kernel(const float* __restrict__ logdur,
-                                                           const int* __restrict__ forced, int K, int* dur, int* cum) {
+                                                           const int* __restrict__ forced, int K, int* dur, int* cum,
+                                                           const int* __restrict__ segs) {
   __shared__ int wave_tot[16];
   __shared__ int base_s;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  if (segs) {   // utterance s: units [start, start+len); its cum[] (len+1 entries) starts at start + s
+    const int st = segs[2 * blockIdx.x];
+    K = segs[2 * blockIdx.x + 1];
+    logdur += st; dur += st; cum += st + blockIdx.x;
+    if (forced) forced += st;
+  }
   if (t == 0) { base_s = 0; cum[0] = 0; }
   __syncthreads();
   for (int c0 = 0; c0 < K; c0 += 1024) {
@@ -260,16 +282,23 @@ __global__ __launch_bounds__(1024) void dur_predict_kernel(const float* __restri
   }
 }
 
-int launch_dur_predict(const float* logdur, const int* forced, int K, int* dur, int* cum, hipStream_t stream) {
-  if (K <= 0) return SS_ERR_ARG;
-  hipLaunchKernelGGL(dur_predict_kernel, dim3(1), dim3(1024), 0, stream, logdur, forced, K, dur, cum);
+int launch_dur_predict(const float* logdur, const int* forced, int K, int* dur, int* cum, hipStream_t stream,
+                       const int* segs, int nseg) {
+  if (K <= 0 && nseg <= 0) return SS_ERR_ARG;
+  hipLaunchKernelGGL(dur_predict_kernel, dim3(nseg > 0 ? nseg : 1), dim3(1024), 0, stream, logdur, forced, K, dur, cum,
+                     nseg > 0 ? segs : nullptr);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
 
 __global__ void repeat_rows_kernel(const float* __restrict__ emb, const int* __restrict__ cum, int K, int D,
-                                   float* out) {
+                                   float* out, const int* __restrict__ segs) {
   const int f = blockIdx.y;
+  if (segs) {   // {unit_start, n_units, frame_start, n_frames}
+    const int* sg = segs + 4 * blockIdx.z;
+    if (f >= sg[3]) return;
+    emb += (size_t)sg[0] * D; cum += sg[0] + blockIdx.z; K = sg[1]; out += (size_t)sg[2] * D;
+  }
   // largest k with cum[k] <= f
   int lo = 0, hi = K - 1;
   while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (cum[mid] <= f) lo = mid; else hi = mid - 1; }
@@ -277,9 +306,11 @@ __global__ void repeat_rows_kernel(const float* __restrict__ emb, const int* __r
   if (c < D) out[(size_t)f * D + c] = emb[(size_t)lo * D + c];
 }
 
-int launch_repeat_rows(const float* emb, const int* cum, int K, int D, float* out, int F, hipStream_t stream) {
+int launch_repeat_rows(const float* emb, const int* cum, int K, int D, float* out, int F, hipStream_t stream,
+                       const int* segs, int nseg) {
   if (F <= 0) return SS_OK;
-  hipLaunchKernelGGL(repeat_rows_kernel, dim3(cdiv(D, 256), F), dim3(256), 0, stream, emb, cum, K, D, out);
+  hipLaunchKernelGGL(repeat_rows_kernel, dim3(cdiv(D, 256), F, nseg > 0 ? nseg : 1), dim3(256), 0, stream, emb, cum, K, D,
+                     out, nseg > 0 ? segs : nullptr);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
@@ -290,10 +321,15 @@ int launch_repeat_rows(const float* emb, const int* cum, int K, int D, float* ou
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __restrict__ x, int T, int C,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
-                                                             float slope, float* wav) {
+                                                             float slope, float* wav, const int* __restrict__ segs) {
   extern __shared__ float ws[];  // 7*C weights
   for (int i = threadIdx.x; i < 7 * C; i += 256) ws[i] = w[i];
   __syncthreads();
+  if (segs) {   // {sample_start, n_samples}
+    const int st = segs[2 * blockIdx.y];
+    T = segs[2 * blockIdx.y + 1];
+    x += (size_t)st * C; wav += st;
+  }
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= T) return;
   float acc = 0.f;
@@ -311,10 +347,10 @@ __global__ __launch_bounds__(256) void conv_post_tanh_kernel(const float* __rest
 }
 
 int launch_conv_post_tanh(const float* x, int T, int C, const float* w, const float* bias, float slope,
-                          float* wav, hipStream_t stream) {
+                          float* wav, hipStream_t stream, const int* segs, int nseg) {
   if (T <= 0) return SS_OK;
-  hipLaunchKernelGGL(conv_post_tanh_kernel, dim3(cdiv(T, 256)), dim3(256), 7 * C * sizeof(float), stream, x, T,
-                     C, w, bias, slope, wav);
+  hipLaunchKernelGGL(conv_post_tanh_kernel, dim3(cdiv(T, 256), nseg > 0 ? nseg : 1), dim3(256), 7 * C * sizeof(float),
+                     stream, x, T, C, w, bias, slope, wav, nseg > 0 ? segs : nullptr);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }

@@ -15,12 +15,18 @@ __global__ __launch_bounds__(256) void fbank_cmvn_kernel(const float* __restrict
                                                          const float* __restrict__ window,   // [400]
                                                          const float* __restrict__ melw,     // [80][257]
                                                          const float* __restrict__ cmvn_mean,
-                                                         const float* __restrict__ cmvn_std, float* feat) {
+                                                         const float* __restrict__ cmvn_std, float* feat,
+                                                         const int* __restrict__ segs) {
   __shared__ float re[NFFT], im[NFFT];
   __shared__ float tw_c[NFFT / 2], tw_s[NFFT / 2];
   __shared__ float red[4];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int frame = blockIdx.x;
+  if (segs) {   // ragged batch {pcm_start, n_frames, frame_start}; whole workgroup exits together
+    const int* sg = segs + 3 * blockIdx.y;
+    if (frame >= sg[1]) return;
+    pcm += sg[0]; feat += (size_t)sg[2] * NMEL;
+  }
   const float* src = pcm + (size_t)frame * SHIFT;
 
   // load (coalesced) and frame mean
@@ -90,7 +96,17 @@ int launch_fbank_cmvn(const float* pcm, int n_samples, float pcm_scale, const fl
   if (n_frames) *n_frames = T;
   if (T == 0) return SS_OK;
   hipLaunchKernelGGL(fbank_cmvn_kernel, dim3(T), dim3(256), 0, stream, pcm, pcm_scale, window, melw,
-                     cmvn_mean, cmvn_std, feat);
+                     cmvn_mean, cmvn_std, feat, (const int*)nullptr);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+int launch_fbank_cmvn_batch(const float* pcm, float pcm_scale, const float* window, const float* melw,
+                            const float* cmvn_mean, const float* cmvn_std, float* feat, const int* segs, int nseg,
+                            int max_frames, hipStream_t stream) {
+  if (nseg <= 0 || max_frames <= 0) return SS_OK;
+  hipLaunchKernelGGL(fbank_cmvn_kernel, dim3(max_frames, nseg), dim3(256), 0, stream, pcm, pcm_scale, window, melw,
+                     cmvn_mean, cmvn_std, feat, segs);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }

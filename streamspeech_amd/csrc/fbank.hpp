@@ -12,4 +12,9 @@ int launch_fbank_cmvn(const float* pcm, int n_samples, float pcm_scale, const fl
                       const float* melw, const float* cmvn_mean, const float* cmvn_std, float* feat,
                       int* n_frames, hipStream_t stream);
 
+// Ragged batch: segs[3*s] = {pcm_start, n_frames, frame_start} into the packed PCM / feature arrays.
+int launch_fbank_cmvn_batch(const float* pcm, float pcm_scale, const float* window, const float* melw,
+                            const float* cmvn_mean, const float* cmvn_std, float* feat, const int* segs, int nseg,
+                            int max_frames, hipStream_t stream);
+
 }  // namespace ss

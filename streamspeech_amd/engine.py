@@ -29,7 +29,7 @@ def _require_gpu(device):
     return torch.device(device)
 
 
-def _slots(names, offsets, numels):
+def _slots(names, offsets, numels):  # noqa: E302
     n = len(names)
     c_names = (C.c_char_p * n)(*[s.encode() for s in names])
     c_off = (C.c_int64 * n)(*offsets)
@@ -37,7 +37,80 @@ def _slots(names, offsets, numels):
     return c_names, c_off, c_num, n
 
 
-class HipModel:
+def _i32(vals):
+    return (C.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+class BatchMixin:
+    """Ragged-batch calls on a HipModel (B utterances packed along the row axis, no padding)."""
+
+    def batch_fbank_cmvn(self, pcm_packed: torch.Tensor, n_samples: List[int], pcm_scale: float = 32768.0):
+        B = len(n_samples)
+        starts = np.concatenate([[0], np.cumsum(n_samples)[:-1]]).astype(np.int64)
+        T = [self.lib.ss_fbank_num_frames(int(n)) for n in n_samples]
+        feat = torch.empty((sum(T), 80), dtype=torch.float32, device=self.device)
+        hT = (C.c_int32 * B)()
+        L.check(self.lib.ss_batch_fbank_cmvn(self.h, _stream(), B, _ptr(pcm_packed), (C.c_int64 * B)(*starts.tolist()),
+                                             _i32(n_samples), pcm_scale, _ptr(feat), hT), "ss_batch_fbank_cmvn")
+        return feat, list(hT)
+
+    def batch_encoder_forward(self, fbank_packed: torch.Tensor, T: List[int], attn_chunk=999999, conv_chunk=999999):
+        B = len(T)
+        Tp = [self.lib.ss_encoder_out_len(int(t)) for t in T]
+        out = torch.empty((sum(Tp), self.cfg.enc_dim), dtype=torch.float32, device=self.device)
+        hTp = (C.c_int32 * B)()
+        L.check(self.lib.ss_batch_encoder_forward(self.h, _stream(), B, _ptr(fbank_packed), _i32(T),
+                                                  int(min(attn_chunk, 1 << 30)), int(min(conv_chunk, 1 << 30)),
+                                                  _ptr(out), hTp), "ss_batch_encoder_forward")
+        return out, list(hTp)
+
+    def batch_ctc_greedy(self, head: int, enc_packed: torch.Tensor, Tp: List[int]):
+        """-> per-utterance (tokens, frame index) lists."""
+        B, tot = len(Tp), sum(Tp)
+        ibuf = torch.empty((3 * tot + B,), dtype=torch.int32, device=self.device)
+        raw, toks, idx, cnt = ibuf[:tot], ibuf[tot:2 * tot], ibuf[2 * tot:3 * tot], ibuf[3 * tot:]
+        L.check(self.lib.ss_batch_ctc_greedy(self.h, _stream(), head, B, _ptr(enc_packed), _i32(Tp), _ptr(raw),
+                                             _ptr(toks), _ptr(idx), _ptr(cnt)), "ss_batch_ctc_greedy")
+        host = ibuf.cpu().numpy()
+        out, off = [], 0
+        for b in range(B):
+            n = int(host[3 * tot + b])
+            out.append((host[tot + off: tot + off + n].tolist(), host[2 * tot + off: 2 * tot + off + n].tolist()))
+            off += Tp[b]
+        return out
+
+    def batch_mt_greedy(self, enc_packed: torch.Tensor, Tp: List[int], max_len: List[int], min_len: int = 1):
+        """-> (list of token lists incl. final eos, feats [B, Lcap, D], n_feats list)."""
+        B = len(Tp)
+        Lmax = max(max_len)
+        rows, stride = Lmax + 2, Lmax + 1
+        feats = torch.empty((B, rows, self.cfg.dec_dim), dtype=torch.float32, device=self.device)
+        out = (C.c_int32 * (B * stride))()
+        n_out = (C.c_int32 * B)()
+        L.check(self.lib.ss_batch_mt_greedy(self.h, _stream(), B, _ptr(enc_packed), _i32(Tp), _i32(max_len), min_len, out,
+                                            stride, n_out, _ptr(feats), rows), "ss_batch_mt_greedy")
+        toks = [list(out[b * stride: b * stride + n_out[b]]) for b in range(B)]
+        return toks, feats, list(n_out)
+
+    def batch_t2u_units(self, feats: torch.Tensor, n_rows: List[int], t2u_causal=False, mask_eos=False):
+        """feats [B, rows, D] (rows of utterance b used: n_rows[b]) -> list of collapsed unit-vocab token lists."""
+        B, rows = feats.shape[0], feats.shape[1]
+        up = self.cfg.ctc_upsample
+        U = sum(n_rows) * up
+        ibuf = torch.empty((2 * U + B,), dtype=torch.int32, device=self.device)
+        raw, toks, cnt = ibuf[:U], ibuf[U:2 * U], ibuf[2 * U:]
+        L.check(self.lib.ss_batch_t2u_units(self.h, _stream(), B, _ptr(feats), rows, _i32(n_rows), int(t2u_causal),
+                                            int(mask_eos), _ptr(raw), _ptr(toks), _ptr(cnt)), "ss_batch_t2u_units")
+        host = ibuf.cpu().numpy()
+        out, off = [], 0
+        for b in range(B):
+            k = int(host[2 * U + b])
+            out.append(host[U + off: U + off + k].tolist())
+            off += n_rows[b] * up
+        return out
+
+
+class HipModel(BatchMixin):
     """ss_model handle + packed weights (StreamSpeechModel replacement)."""
 
     def __init__(self, state_dict, cfg: ModelConfig = None, device="cuda:0", cmvn_mean=None, cmvn_std=None,
@@ -204,6 +277,25 @@ class HipVocoder:
 
     def new_context(self) -> "HipVocoder":
         return HipVocoder(None, self.cfg, device=str(self.device), _share=self._packed)
+
+    def batch_forward(self, codes: List[List[int]], dur_prediction=True, forced_dur: Optional[List[List[int]]] = None):
+        """-> (list of wav tensors (views into one packed buffer), list of dur lists)."""
+        B = len(codes)
+        K = [len(c) for c in codes]
+        flat = torch.tensor([u for c in codes for u in c], dtype=torch.int32).to(self.device)
+        fd = None
+        if forced_dur is not None:
+            fd = torch.tensor([d for ds in forced_dur for d in ds], dtype=torch.int32).to(self.device)
+            cap = int(sum(sum(ds) for ds in forced_dur)) * self.hop
+        else:
+            cap = sum(K) * (self.max_dur if dur_prediction else 1) * self.hop
+        wav = torch.empty((cap,), dtype=torch.float32, device=self.device)
+        dur = torch.empty((sum(K),), dtype=torch.int32, device=self.device)
+        st, ns = (C.c_int64 * B)(), (C.c_int64 * B)()
+        L.check(self.lib.ss_batch_vocoder_forward(self.h, _stream(), B, _ptr(flat), _i32(K), int(dur_prediction), _ptr(fd),
+                                                  _ptr(wav), cap, _ptr(dur), st, ns), "ss_batch_vocoder_forward")
+        wavs = [wav[st[b]: st[b] + ns[b]] for b in range(B)]
+        return wavs, dur, K
 
     def __del__(self):
         try:

@@ -51,6 +51,14 @@ SIGNATURES = {
                                C.POINTER(_i64), C.POINTER(_i64), _i, C.POINTER(_vp)]),
     "ss_vocoder_destroy": (None, [_vp]),
     "ss_vocoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, C.POINTER(_i64)]),
+    "ss_batch_fbank_cmvn": (_i, [_vp, _vp, _i, _vp, C.POINTER(_i64), C.POINTER(C.c_int32), _f, _vp, C.POINTER(C.c_int32)]),
+    "ss_batch_encoder_forward": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_int32), _i, _i, _vp, C.POINTER(C.c_int32)]),
+    "ss_batch_ctc_greedy": (_i, [_vp, _vp, _i, _i, _vp, C.POINTER(C.c_int32), _vp, _vp, _vp, _vp]),
+    "ss_batch_mt_greedy": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _i,
+                                C.POINTER(C.c_int32), _i, C.POINTER(C.c_int32), _vp, _i]),
+    "ss_batch_t2u_units": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(C.c_int32), _i, _i, _vp, _vp, _vp]),
+    "ss_batch_vocoder_forward": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_int32), _i, _vp, _vp, _i64, _vp,
+                                      C.POINTER(_i64), C.POINTER(_i64)]),
     "ss_prof_enable": (_i, [_i]),
     "ss_prof_reset": (_i, []),
     "ss_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),

@@ -1,0 +1,94 @@
+"""Ragged-batch stages (BASELINE.json configs[3]/[4]): B utterances of different lengths packed
+together must give, per utterance, exactly what the single-utterance path gives (identical ids;
+floats within summation-order noise) -- there is no padding, so no batch effect may leak."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LENS = [83, 435, 9, 257, 31, 612]   # fbank frames per utterance (ragged, incl. tiny)
+
+
+def _fbanks():
+    from streamspeech_amd import synth
+    return [synth.synth_fbank(40 + i, T) for i, T in enumerate(LENS)]
+
+
+@pytest.mark.parametrize("ac,cc", [(999999, 999999), (8, 8)])
+def test_batch_encoder_and_ctc_match_single(hip_model, ac, cc):
+    fbs = _fbanks()
+    packed = torch.from_numpy(np.concatenate(fbs)).cuda()
+    enc, Tp = hip_model.batch_encoder_forward(packed, LENS, ac, cc)
+    ctc = [hip_model.batch_ctc_greedy(h, enc, Tp) for h in (0, 1)]
+    off = 0
+    for b, fb in enumerate(fbs):
+        one = hip_model.encoder_forward(torch.from_numpy(fb).cuda(), ac, cc)
+        assert one.shape[0] == Tp[b]
+        err = (enc[off:off + Tp[b]] - one).abs().max().item()
+        assert err < 2e-4, f"utt {b}: {err}"
+        for h in (0, 1):
+            toks, idx, _, _ = hip_model.ctc_greedy(h, one)
+            assert ctc[h][b][0] == toks and ctc[h][b][1] == idx
+        off += Tp[b]
+
+
+def test_batch_fbank_matches_single(hip_model):
+    from streamspeech_amd import synth
+    ns = [16000, 4000, 23017, 400]
+    pcms = [synth.synth_pcm(70 + i, n) for i, n in enumerate(ns)]
+    feat, T = hip_model.batch_fbank_cmvn(torch.from_numpy(np.concatenate(pcms)).cuda(), ns)
+    off = 0
+    for p, t in zip(pcms, T):
+        one = hip_model.fbank_cmvn(torch.from_numpy(p).cuda())
+        assert one.shape[0] == t and torch.equal(feat[off:off + t], one)
+        off += t
+
+
+def test_batch_mt_t2u_vocoder_match_single(hip_model, hip_vocoder, synth_weights):
+    from streamspeech_amd import synth
+    from streamspeech_amd.pipeline import mt_greedy, units_from_tokens
+    cfg = hip_model.cfg
+    fbs = _fbanks()[:4]
+    lens = LENS[:4]
+    max_new = [7, 12, 3, 9]
+    enc, Tp = hip_model.batch_encoder_forward(torch.from_numpy(np.concatenate(fbs)).cuda(), lens)
+    toks, feats, n = hip_model.batch_mt_greedy(enc, Tp, max_new)
+    units_b = hip_model.batch_t2u_units(feats, n)
+    off = 0
+    all_units = []
+    for b in range(4):
+        e1 = enc[off:off + Tp[b]].contiguous()
+        t1, f1 = mt_greedy(hip_model, e1, max_new_tokens=max_new[b])
+        assert toks[b] == t1, (b, toks[b], t1)
+        assert n[b] == f1.shape[0]
+        assert (feats[b, :n[b]] - f1).abs().max().item() < 2e-4
+        u1, _, _ = hip_model.t2u_units(f1)
+        assert units_b[b] == u1
+        all_units.append(units_from_tokens(u1, cfg))
+        off += Tp[b]
+    codes = [u if len(u) > 0 else [1, 2, 3] for u in all_units]
+    wavs, dur, K = hip_vocoder.batch_forward(codes, dur_prediction=True)
+    dur_h = dur.cpu().tolist()
+    o = 0
+    for b, c in enumerate(codes):
+        w1, d1 = hip_vocoder.forward(c, True)
+        assert dur_h[o:o + K[b]] == d1.cpu().tolist()
+        assert wavs[b].shape == w1.shape
+        rms = float(torch.sqrt(torch.mean((wavs[b] - w1) ** 2)))
+        assert rms < 1e-5, f"utt {b}: rms {rms}"
+        o += K[b]
+
+
+def test_batch_vocoder_forced_durations_vs_oracle(hip_vocoder, synth_weights):
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import synth
+    _, vcfg, _, vsd = synth_weights
+    codes = [[int(c) for c in synth.uniform(5, f"bv/{i}", (k,), 0, 1000)] for i, k in enumerate((30, 7, 55))]
+    durs = [[1 + (j % 3 == 2) for j in range(len(c))] for c in codes]
+    wavs, dur, K = hip_vocoder.batch_forward(codes, True, forced_dur=durs)
+    for b in range(3):
+        rw, rd = O.vocoder_forward(vsd, codes[b], vcfg, True, forced_dur=durs[b])
+        assert wavs[b].numel() == rw.numel()
+        rms = float(torch.sqrt(torch.mean((wavs[b].cpu() - rw) ** 2)))
+        assert rms < 1e-3, f"rms {rms}"
