@@ -562,7 +562,7 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   }
   if (a.ln_g) return SS_ERR_ARG;  // LayerNorm fusion exists only on the small-M path
   if (g_force_bm && a.N > 32 && k32) {   // tuning hook (tools/conv_bench.py): ks = KS*10 + PD
-    const int f = g_force_bm * 10000 + g_force_bn * 100 + g_force_ks;
+    const int f = g_force_bm * 10000 + (g_force_bn % 100) * 100 + g_force_ks;   // 128x128 -> bn code 28... see cases
     switch (f) {
 #define SS_CASE(BM_, BN_, KS_, PD_, CLS_) case BM_ * 10000 + BN_ * 100 + KS_ * 10 + PD_: return launch_cfg<BM_, BN_, 32, 2, 2, KS_, PD_>(a, stream, CLS_);
       SS_CASE(64, 64, 1, 1, 7) SS_CASE(64, 64, 1, 2, 7) SS_CASE(64, 64, 1, 3, 7)
@@ -572,6 +572,8 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
       SS_CASE(32, 32, 1, 1, 11) SS_CASE(32, 32, 1, 2, 11) SS_CASE(32, 32, 1, 3, 11) SS_CASE(32, 32, 1, 4, 11)
       SS_CASE(32, 32, 2, 3, 11) SS_CASE(32, 32, 4, 3, 11)
 #undef SS_CASE
+      case 128 * 10000 + 28 * 100 + 11: return launch_cfg<128, 128, 16, 2, 2, 1, 1>(a, stream, 5);
+      case 128 * 10000 + 64 * 100 + 11: return launch_cfg<128, 64, 32, 2, 2, 1, 1>(a, stream, 6);
       default: break;
     }
   }
@@ -589,7 +591,8 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   const long t128 = (long)cdiv(M, 128) * cdiv(a.N, 128) * nseg;
   const long t3232 = (long)cdiv(M, 32) * cdiv(a.N, 32) * nseg;
   const long t3264 = (long)cdiv(M, 32) * cdiv(a.N, 64) * nseg;
-  if (t128 >= 1024) return launch_cfg<128, 128, 16, 2, 2>(a, stream, 5);
+  (void)t128;   // 128x128 tiles lose to 32x64 even at batch scale (profiles/r01_tile_sweep_batch.txt)
+  if (k32 && t3264 >= 768) return launch_cfg<32, 64, 32, 2, 2, 1>(a, stream, 9);   // big (batched) problems: ~90 TFLOP/s
   if (!k32 || a.glu) {
     return k32 ? launch_cfg_ks<32, 64, 32, 2, 2, 4>(a, stream, 9, t3264) : launch_cfg_ks<32, 64, 16, 2, 2, 4>(a, stream, 10, t3264);
   }

@@ -56,9 +56,30 @@ def sweep():
     lib.ss_debug_force_tile(0, 0, 0)
 
 
+def sweep_big():
+    """batch-scale shapes (16 utterances packed)."""
+    shapes = [("enc ffn1", 1800, 2048, 256, 1), ("enc ffn2", 1800, 256, 2048, 1), ("enc qkv", 1800, 768, 256, 1),
+              ("ctc head", 1800, 6000, 256, 1), ("unit fc1", 6800, 2048, 512, 1), ("unit fc2", 6800, 512, 2048, 1),
+              ("stage0 k11", 18000, 256, 256, 11), ("stage0 k3", 18000, 256, 256, 3), ("stage1 k11", 72000, 128, 128, 11),
+              ("stage1 k3", 72000, 128, 128, 3), ("stage2 k11", 288000, 64, 64, 11), ("stage2 k3", 288000, 64, 64, 3),
+              ("up0", 3600, 1280, 512, 3), ("up1", 18000, 512, 256, 3)]
+    tiles = [(128, 128, 11), (128, 64, 11), (64, 64, 11), (64, 64, 12), (32, 64, 11), (32, 32, 11)]
+    print("%-12s" % "shape" + "".join("%11s" % f"{a}x{b}/{k}" for a, b, k in tiles) + "   GFLOP")
+    for name, M, N, Cin, taps in shapes:
+        line = "%-12s" % name
+        for bm, bn, ks in tiles:
+            lib.ss_debug_force_tile(bm, bn, ks)
+            r = bench(name, M, N, Cin, taps, 1, reps=5)
+            line += "%11.1f" % r["us"]
+        print(line + "   %.2f" % r["gflop"], flush=True)
+    lib.ss_debug_force_tile(0, 0, 0)
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         return sweep()
+    if len(sys.argv) > 1 and sys.argv[1] == "sweep_big":
+        return sweep_big()
     F = 225  # frames of a 4.5 s utterance
     rows = []
     T, Cc = F, 512
