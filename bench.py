@@ -127,6 +127,7 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--streams", type=int, default=4,
                     help="concurrent HIP streams per GPU (own scratch context each)")
+    ap.add_argument("--no-latency-pass", action="store_true", help="skip the single-stream latency measurement")
     ap.add_argument("--batch", type=int, default=32,
                     help="utterances packed per ragged batch (1 = the one-utterance-at-a-time entry points)")
     args = ap.parse_args()
@@ -188,7 +189,7 @@ def main():
     # single-stream latency pass (untimed for `value`; reported as latency_ms_single_stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nlat = min(K, 8)
+    nlat = 1 if args.no_latency_pass else min(K, 8)
     for u, p in zip(mine[Wn:Wn + nlat], pcms[Wn:Wn + nlat]):
         run_utterance(model, voc, p, u)
     torch.cuda.synchronize()

@@ -27,7 +27,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 template <int BM, int BN, int BK, int WM, int WN, int KS, int PD>
 __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
   static_assert(WM * WN == 4, "4 waves per k-group");
-  constexpr int LDK = BK + 4;  // +4 floats keeps 16-B alignment and staggers banks
+  // row stride in floats: 16-B aligned and = 10 (BK=32) / 6 (BK=16) sixteen-byte slots, which makes the
+  // 16-lane groups of ds_read_b128 hit 16 distinct slots (conflict-free; +4 was 2-way)
+  constexpr int LDK = BK + 8;
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int TM = WTM / 16, TN = WTN / 16;
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 16x16 MFMA tile");
@@ -482,7 +484,7 @@ constexpr int default_pd(int, int) { return 1; }
 
 template <int BM, int BN, int BK, int WM, int WN, int KS = 1, int PD = default_pd(BM, BN)>
 static int launch_cfg(const GemmArgs& a, hipStream_t stream, int cls) {
-  constexpr size_t kLds = (size_t)KS * 2 * (BM + BN) * (BK + 4) * sizeof(float);
+  constexpr size_t kLds = (size_t)KS * 2 * (BM + BN) * (BK + 8) * sizeof(float);
   static_assert(kLds <= 160 * 1024, "LDS budget");
   static_assert((size_t)(KS - 1) * BM * BN * sizeof(float) <= kLds, "reduction scratch fits the staging buffers");
   static bool attr_set = false;

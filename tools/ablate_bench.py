@@ -22,8 +22,8 @@ def bench(M, N, Cin, taps, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 
-shapes = [("stage2 k11", 18000, 64, 64, 11), ("stage0 k11", 1125, 256, 256, 11), ("stage1 k11", 4500, 128, 128, 11)]
-tiles = [(64, 64, 12), (32, 64, 13), (32, 32, 13)]
+shapes = [("stage2 k11", 288000, 64, 64, 11), ("stage0 k11", 18000, 256, 256, 11), ("unit fc2", 6800, 512, 2048, 1)]
+tiles = [(64, 64, 11), (32, 64, 11)]
 masks = [0, 1, 2, 4, 8, 1 | 4, 1 | 4 | 8, 2 | 4 | 8, 1 | 2, 1 | 2 | 4 | 8]
 print("%-12s %-9s" % ("shape", "tile") + "".join("%9s" % f"m{m}" for m in masks))
 for name, M, N, Cin, taps in shapes:
@@ -32,5 +32,5 @@ for name, M, N, Cin, taps in shapes:
         line = "%-12s %-9s" % (name, f"{bm}x{bn}/{ks}")
         for m in masks:
             lib.ss_debug_set_ablate(m)
-            line += "%9.1f" % bench(M, N, Cin, taps)
+            line += "%9.1f" % bench(M, N, Cin, taps, reps=5)
         print(line, flush=True)
