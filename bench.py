@@ -284,9 +284,19 @@ def main():
         if n == 0 or ms <= 0:
             return None
         name = lib.ss_prof_class_name(c).decode()
+        traffic = None
+        try:   # PMC pass is a separate rocprofv3 run (profiles/); per-launch MB with the guide's gfx950 correction
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+            for kn, kv in pm.items():
+                if kn.replace(" ", "").startswith("voidss::" + name.replace("conv_gemm", "conv_gemm_kernel").replace("smallm_gemm", "smallm_gemm_kernel").replace(" ", "")[:-1]):
+                    traffic = {"mbytes_per_launch": kv["hbm_mbytes_per_launch_corrected"], "source": "profiles/r01_pmc_traffic.json "
+                               "(rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE, batch 32, 1 stream; 2x FETCH_SIZE correction)"}
+                    break
+        except Exception:  # noqa: BLE001
+            pass
         common = {"kernel": name, "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
                   "algo_gflop_per_launch": round(fl / n / 1e9, 4), "algo_mbytes_per_launch": round(by / n / 1e6, 3),
-                  "traffic": None, "kernel_time_over_wall": round(ms * 1e-3 / wall, 3)}
+                  "traffic": traffic, "kernel_time_over_wall": round(ms * 1e-3 / wall, 3)}
         if name.startswith("smallm"):
             # M <= 128 projections / M = 1 decode GEMVs stream their weights once: HBM-side roofline
             ach = by / (ms * 1e-3) / 1e9

@@ -89,7 +89,9 @@ int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d_enc_out, i
  *   ban_eos, and forced to eos when force_eos (agent/sequence_generator.py:350-372 at beam 1). */
 int ss_mt_begin(ss_model* m, void* stream, const float* d_enc_out, int Tp);
 int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, int n, int pos0, int ban_eos,
-                 int force_eos, float* d_feats, int32_t* d_next);
+                 int force_eos, float* d_feats, int32_t* d_next, int n_tail_pad);
+/*   n_tail_pad: the last n_tail_pad fed tokens are <pad> (whole-word mode feeds one, agent :576-584):
+ *   they take the zero positional row and are masked as keys (fairseq self_attn_padding_mask). */
 /* The whole beam-1 search of SequenceGenerator.generate_decoder (agent/sequence_generator.py:165-582)
  * in one call: begin + prefix pass + autoregressive steps until </s> or max_len (forced </s>), with
  * the token chain kept on the device.  h_prefix [n_prefix] host ids (no leading </s>).
@@ -108,7 +110,11 @@ int ss_mt_truncate(ss_model* m, int len);
  * checkpoint's --uni-encoder flag; mask_eos = the offline generator's extra eos mask
  * (researches/ctc_unity/ctc_generator.py:58). */
 int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, int n, int t2u_causal,
-                 int mask_eos, int32_t* d_raw, int32_t* d_tokens, int32_t* d_count, float* d_logits);
+                 int mask_eos, int32_t* d_raw, int32_t* d_tokens, int32_t* d_count, float* d_logits,
+                 int n_tail_pad);
+/*   n_tail_pad: trailing rows of d_mt_feats that belong to <pad> tokens: masked as keys in the T2U
+ *   encoder, the unit decoder's self-attention (25 positions each) and its cross-attention, but
+ *   still decoded (the reference emits their units too, agent :661-717). */
 
 /* ---- a14-a15: CodeHiFiGANVocoderWithDur.forward (agent/tts/vocoder.py:48-60). -------------- */
 int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_blob, size_t blob_floats,

@@ -171,6 +171,28 @@ def main():
     dec_fix["unit_logits_first8"] = ulogits[:8].numpy()
     dec_fix["unit_raw"] = np.array(raw, np.int32)
     dec_fix["units"] = np.array(units, np.int32)
+    # ---- whole-word mode: one trailing <pad> position through MT decoder / T2U / unit decoder (agent :576-584)
+    ptoks = toks[:6] + [cfg.pad]
+    pmask = torch.tensor([ptoks]).eq(cfg.pad)
+    pfeats = mt(torch.tensor([ptoks]), encoder_out=enc_dict, features_only=True)[0][0]
+    mine = O.mt_decoder_features(osd, ptoks, enc_out, cfg)
+    summary["mt_features_pad"] = _err(pfeats, mine)
+    assert summary["mt_features_pad"] < 2e-4, summary
+    pt2u = t2u(pfeats[:, None], pmask)
+    assert len(pt2u["encoder_padding_mask"]) == 1
+    summary["t2u_pad"] = _err(pt2u["encoder_out"][0][:, 0], O.t2u_encoder(osd, pfeats, cfg, n_tail_pad=1))
+    assert summary["t2u_pad"] < 2e-4, summary
+    pul, _ = ud(None, encoder_out=pt2u)
+    pmine = O.unit_decoder_logits(osd, pt2u["encoder_out"][0][:, 0], cfg, n_tail_pad=1)
+    summary["unit_logits_pad"] = _err(pul[0], pmine)
+    assert summary["unit_logits_pad"] < 5e-4, summary
+    lp = torch.log_softmax(pul[0], -1)
+    lp[:, cfg.pad] = -np.inf
+    lp[:, cfg.unk] = -np.inf
+    dec_fix["pad_tokens_in"] = np.array(ptoks, np.int32)
+    dec_fix["pad_mt_features"] = pfeats.numpy()
+    dec_fix["pad_unit_raw"] = lp.argmax(-1).numpy().astype(np.int32)
+    assert dec_fix["pad_unit_raw"].tolist() == O.unit_ctc_generate(pmine, cfg)[1]
     np.savez(os.path.join(OUT, "decoders.npz"), **dec_fix)
 
     # ---- vocoder ----

@@ -260,7 +260,7 @@ def sinusoid_table(n: int, dim: int, padding_idx: int) -> torch.Tensor:
     return e
 
 
-def fairseq_mha(sd: SD, p: str, q_in, kv_in, heads: int, causal: bool = False):
+def fairseq_mha(sd: SD, p: str, q_in, kv_in, heads: int, causal: bool = False, k_mask_tail: int = 0):
     """ctc_unity/modules/multihead_attention.py:544-573,673-760 for B = 1, no padding:
     q = (W_q x + b_q) * d_h^-0.5, additive triu(-inf,1) mask when causal, fp32 softmax, bmm, out_proj."""
     Tq, D = q_in.shape
@@ -272,26 +272,28 @@ def fairseq_mha(sd: SD, p: str, q_in, kv_in, heads: int, causal: bool = False):
     w = torch.bmm(q, k.transpose(1, 2))
     if causal:
         w = w + torch.triu(torch.full((Tq, Tk), float("-inf")), 1)[None]
+    if k_mask_tail > 0:   # key_padding_mask on trailing <pad> keys (multihead_attention.py:700-718)
+        w[:, :, Tk - k_mask_tail:] = float("-inf")
     w = torch.softmax(w, dim=-1)
     ctx = torch.bmm(w, v).transpose(0, 1).reshape(Tq, D)
     return linear(ctx, sd, p + ".out_proj")
 
 
-def decoder_layer(sd: SD, p: str, x, enc, heads: int):
+def decoder_layer(sd: SD, p: str, x, enc, heads: int, self_tail: int = 0, cross_tail: int = 0):
     """ctc_unity/modules/transformer_layer.py:388-551 (pre-LN, ReLU, causal self-attn + cross-attn)."""
     h = layer_norm(x, sd[p + ".self_attn_layer_norm.weight"], sd[p + ".self_attn_layer_norm.bias"])
-    x = x + fairseq_mha(sd, p + ".self_attn", h, h, heads, causal=True)
+    x = x + fairseq_mha(sd, p + ".self_attn", h, h, heads, causal=True, k_mask_tail=self_tail)
     h = layer_norm(x, sd[p + ".encoder_attn_layer_norm.weight"], sd[p + ".encoder_attn_layer_norm.bias"])
-    x = x + fairseq_mha(sd, p + ".encoder_attn", h, enc, heads)
+    x = x + fairseq_mha(sd, p + ".encoder_attn", h, enc, heads, k_mask_tail=cross_tail)
     h = layer_norm(x, sd[p + ".final_layer_norm.weight"], sd[p + ".final_layer_norm.bias"])
     h = linear(F.relu(linear(h, sd, p + ".fc1")), sd, p + ".fc2")
     return x + h
 
 
-def encoder_layer(sd: SD, p: str, x, heads: int, causal: bool):
+def encoder_layer(sd: SD, p: str, x, heads: int, causal: bool, tail: int = 0):
     """ctc_unity/modules/transformer_layer.py:165-230 (pre-LN encoder layer, ReLU)."""
     h = layer_norm(x, sd[p + ".self_attn_layer_norm.weight"], sd[p + ".self_attn_layer_norm.bias"])
-    x = x + fairseq_mha(sd, p + ".self_attn", h, h, heads, causal=causal)
+    x = x + fairseq_mha(sd, p + ".self_attn", h, h, heads, causal=causal, k_mask_tail=tail)
     h = layer_norm(x, sd[p + ".final_layer_norm.weight"], sd[p + ".final_layer_norm.bias"])
     h = linear(F.relu(linear(h, sd, p + ".fc1")), sd, p + ".fc2")
     return x + h
@@ -312,8 +314,10 @@ def mt_decoder_features(sd, tokens: List[int], enc_out, cfg) -> torch.Tensor:
     positions = torch.cumsum(mask, 0) * mask + cfg.pad
     table = sinusoid_table(cfg.pad + 1 + max(n, 1024), D, cfg.pad)
     x = math.sqrt(D) * F.embedding(tok, sd[p + ".embed_tokens.weight"]) + table[positions]
+    n_pad = int((tok == cfg.pad).sum())      # trailing <pad> (whole-word mode, agent :576-584)
+    assert n_pad == 0 or bool((tok[-n_pad:] == cfg.pad).all())
     for i in range(cfg.mt_layers):
-        x = decoder_layer(sd, f"{p}.layers.{i}", x, enc_out, cfg.dec_heads)
+        x = decoder_layer(sd, f"{p}.layers.{i}", x, enc_out, cfg.dec_heads, self_tail=n_pad)
     return layer_norm(x, sd[p + ".layer_norm.weight"], sd[p + ".layer_norm.bias"])
 
 
@@ -350,17 +354,17 @@ def mt_greedy(sd, enc_out, cfg, prefix: Optional[List[int]] = None, max_new_toke
     return tokens[1:]
 
 
-def t2u_encoder(sd, x, cfg, causal: bool = False) -> torch.Tensor:
+def t2u_encoder(sd, x, cfg, causal: bool = False, n_tail_pad: int = 0) -> torch.Tensor:
     """synthesizer_encoder: ctc_unity/modules/transformer_encoder.py:32-77 (2 pre-LN layers + LN);
     causal iff --uni-encoder (simultaneous checkpoints)."""
     sd = sd if isinstance(sd, SD) else SD(sd)
     x = _t(x)
     for i in range(cfg.t2u_layers):
-        x = encoder_layer(sd, f"synthesizer_encoder.layers.{i}", x, cfg.dec_heads, causal)
+        x = encoder_layer(sd, f"synthesizer_encoder.layers.{i}", x, cfg.dec_heads, causal, n_tail_pad)
     return layer_norm(x, sd["synthesizer_encoder.layer_norm.weight"], sd["synthesizer_encoder.layer_norm.bias"])
 
 
-def unit_decoder_logits(sd, t2u_out, cfg) -> torch.Tensor:
+def unit_decoder_logits(sd, t2u_out, cfg, n_tail_pad: int = 0) -> torch.Tensor:
     """CTCTransformerUnitDecoder.forward for B = 1: ctc_transformer_unit_decoder.py:153-260.
     Each T2U state is repeated ctc_upsample times; the positional term is the reference's quirk
     (SURVEY.md H2): embed_positions(x[:, :, 0]) treats [U, B] floats as [bsz, seqlen], so for
@@ -375,7 +379,8 @@ def unit_decoder_logits(sd, t2u_out, cfg) -> torch.Tensor:
     posidx = torch.where(first.ne(float(cfg.pad)), torch.tensor(cfg.pad + 1), torch.tensor(cfg.pad))
     x = x + table[posidx]
     for i in range(cfg.unit_layers):
-        x = decoder_layer(sd, f"decoder.layers.{i}", x, t2u_out, cfg.dec_heads)
+        x = decoder_layer(sd, f"decoder.layers.{i}", x, t2u_out, cfg.dec_heads,
+                          self_tail=n_tail_pad * cfg.ctc_upsample, cross_tail=n_tail_pad)
     x = layer_norm(x, sd["decoder.layer_norm.weight"], sd["decoder.layer_norm.bias"])
     return F.linear(x, sd["decoder.output_projection.weight"])
 

@@ -282,13 +282,18 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
         # (causal: a prefix slice is exact); the reference recomputes them (agent :638-651).
         mt_feats = hyp["features"][: len(tmp) + 1]
         if n_tail_pad:
-            raise NotImplementedError(
-                "source_segment_size >= 640 (whole-word mode) feeds one trailing <pad> position through the "
-                "decoders (agent :576-584); trailing-pad masking is not wired into the HIP stages yet")
+            # whole-word mode: prev_output_tokens_mt carries one trailing <pad> (agent :576-584); the
+            # reference runs that position through the MT decoder, T2U encoder and unit decoder with
+            # key-padding masks, and its 25 unit positions are decoded like any other
+            eng = self.engine
+            eng.mt_truncate(len(tmp) + 1)
+            pad_feat, _ = eng.mt_append([int(prev_output_tokens_mt[0, -1])], len(tmp) + 1, False, False,
+                                        want_next=False, n_tail_pad=1)
+            mt_feats = torch.cat((mt_feats, pad_feat), 0)
         self.mt_decoder_out = mt_feats
 
         # 2+3. T2U encoder + CTC unit decoder + CTC search (agent :661-689)
-        finalized = self.ctc_generator.generate(mt_feats, prefix=self.tgt_units_indices)
+        finalized = self.ctc_generator.generate(mt_feats, prefix=self.tgt_units_indices, n_tail_pad=n_tail_pad)
         if len(finalized[0][0]["tokens"]) == 0:
             if not self.states.source_finished:
                 return ReadAction()

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
   for (int rr = 0; rr < 4; ++rr) { m_run[rr] = -INFINITY; l_run[rr] = 0.f; acc[rr] = 0.f; }
 
   // last key any row of this block may see (block-uniform loop bound)
-  int kmax = p.Tk;
+  int kmax = p.Tk - p.k_mask_tail;
   const int ilast = min(i0 + QB, p.Tq) - 1;
   if (p.causal) kmax = min(kmax, ilast + qoff + 1);
   if (p.chunk > 0) kmax = min(kmax, (ilast / p.chunk + 1) * p.chunk);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) {
       const int i = i0 + wave * 4 + rr;
-      bool vis = (j < p.Tk) && (i < p.Tq);
+      bool vis = (j < p.Tk - p.k_mask_tail) && (i < p.Tq);
       if (p.causal) vis = vis && (j <= i + qoff);
       if (p.chunk > 0) vis = vis && (j < (i / p.chunk + 1) * p.chunk);
       const float sv = vis ? s[rr] * p.scale : -INFINITY;
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(AttnArgs p) {
   const int hoff = h * DH;
   const int qoff = p.Tk - p.Tq;
   const float* q = p.Q + (size_t)i * p.ldq + hoff;
-  int kmax = p.Tk;
+  int kmax = p.Tk - p.k_mask_tail;
   if (p.causal) kmax = min(kmax, i + qoff + 1);
   if (p.chunk > 0) kmax = min(kmax, (i / p.chunk + 1) * p.chunk);
   float m_run = -INFINITY, l_run = 0.f, acc = 0.f;

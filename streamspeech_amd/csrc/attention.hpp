@@ -18,6 +18,7 @@ struct AttnArgs {
   float scale = 1.0f;        // scores *= scale
   int causal = 0;            // key j visible iff j <= i + (Tk - Tq)
   int chunk = 0;             // > 0: key j visible iff j < (i/chunk + 1)*chunk
+  int k_mask_tail = 0;       // the last k_mask_tail keys are padding (fairseq key_padding_mask on trailing <pad>)
   // rel-pos extras (null => plain attention); requires Tq == Tk
   const float* P = nullptr; int ldp = 0;   // projected positional table [2*Tk-1, H*64]
   const float* bias_u = nullptr; const float* bias_v = nullptr;  // [H*64]

@@ -93,18 +93,21 @@ int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const floa
 // ---------------------------------------------------------------------------------------------
 __global__ void embed_tokens_kernel(const int* __restrict__ tok, const float* __restrict__ emb,
                                     const float* __restrict__ pos_table, float scale, int pos0, float* out,
-                                    int n, int D, int pos_stride) {
+                                    int n, int D, int pos_stride, int pad_id) {
   const int i = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= D) return;
-  out[(size_t)i * D + c] = scale * emb[(size_t)tok[i] * D + c] + pos_table[(size_t)(pos0 + i * pos_stride) * D + c];
+  const int tk = tok[i];
+  // make_positions (fairseq/utils.py:256-266): a <pad> token takes position padding_idx (the zero row)
+  const int pos = (tk == pad_id) ? pad_id : pos0 + i * pos_stride;
+  out[(size_t)i * D + c] = scale * emb[(size_t)tk * D + c] + pos_table[(size_t)pos * D + c];
 }
 
 int launch_embed_tokens(const int* tok, const float* emb, const float* pos_table, float scale, int pos0,
-                        float* out, int n, int D, hipStream_t stream, int pos_stride) {
+                        float* out, int n, int D, hipStream_t stream, int pos_stride, int pad_id) {
   if (n <= 0) return SS_OK;
   hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, stream, tok, emb, pos_table,
-                     scale, pos0, out, n, D, pos_stride);
+                     scale, pos0, out, n, D, pos_stride, pad_id);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }

@@ -390,16 +390,17 @@ static int dec_layer_ex(hipStream_t s, const ss_config& c, const DecLayer& L, fl
 // single utterance: self K/V cache rows live in `selfbuf` ([*, 3D], row = absolute position)
 static int dec_layer(hipStream_t s, const ss_config& c, const DecLayer& L, float* x, int n, int pos0,
                      float* selfbuf, bool causal, const float* crossKV, int Tk_cross, float* h, float* q2,
-                     float* ff) {
+                     float* ff, int self_tail_pad = 0, int cross_tail_pad = 0) {
   const int D = c.dec_dim, H = c.dec_heads;
   float* rows = selfbuf + (size_t)pos0 * 3 * D;
   AttnArgs at;
   at.Q = rows; at.ldq = 3 * D; at.K = selfbuf + D; at.V = selfbuf + 2 * D; at.ldk = at.ldv = 3 * D;
   at.O = h; at.ldo = D; at.Tq = n; at.Tk = pos0 + n; at.H = H; at.scale = 1.f; at.causal = causal ? 1 : 0;
+  at.k_mask_tail = self_tail_pad;
   AttnArgs ac;
   if (L.has_cross) {
     ac.Q = q2; ac.ldq = D; ac.K = crossKV; ac.V = crossKV + D; ac.ldk = ac.ldv = 2 * D;
-    ac.O = h; ac.ldo = D; ac.Tq = n; ac.Tk = Tk_cross; ac.H = H; ac.scale = 1.f;
+    ac.O = h; ac.ldo = D; ac.Tq = n; ac.Tk = Tk_cross; ac.H = H; ac.scale = 1.f; ac.k_mask_tail = cross_tail_pad;
   }
   return dec_layer_ex(s, c, L, x, n, rows, 3 * D, at, L.has_cross ? &ac : nullptr, h, q2, ff);
 }
@@ -426,7 +427,7 @@ extern "C" int ss_mt_truncate(ss_model* m, int len) {
 }
 
 extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, int n, int pos0, int ban_eos,
-                            int force_eos, float* d_feats, int32_t* d_next) {
+                            int force_eos, float* d_feats, int32_t* d_next, int n_tail_pad) {
   if (!m || n <= 0 || pos0 < 0 || pos0 > m->mt_len || m->mt_Tp <= 0) return SS_ERR_ARG;
   const ss_config& c = m->cfg;
   if (pos0 + n + 2 > c.max_tgt_pos) return SS_ERR_CAPACITY;
@@ -440,11 +441,11 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
   float* ff = feats + (size_t)n * D;
   float* logits = ff + (size_t)n * F;
   // sqrt(D) * E[tok] + sinusoid(position), positions start at padding_idx + 1 (transformer_decoder.py:297-326)
-  RET(launch_embed_tokens(d_tokens, m->mt_emb, m->mt_pos, sqrtf((float)D), pos0 + c.pad + 1, x, n, D, s));
+  RET(launch_embed_tokens(d_tokens, m->mt_emb, m->mt_pos, sqrtf((float)D), pos0 + c.pad + 1, x, n, D, s, 1, c.pad));
   for (int l = 0; l < c.mt_layers; ++l) {
     float* selfbuf = m->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
     const float* cross = m->mt_cross.f() + (size_t)l * m->mt_Tp * 2 * D;
-    RET(dec_layer(s, c, m->mt[l], x, n, pos0, selfbuf, true, cross, m->mt_Tp, h, q2, ff));
+    RET(dec_layer(s, c, m->mt[l], x, n, pos0, selfbuf, true, cross, m->mt_Tp, h, q2, ff, n_tail_pad, 0));
   }
   float* fo = d_feats ? d_feats : feats;
   RET(launch_layernorm(x, D, fo, D, m->mt_ln.g, m->mt_ln.b, n, D, 1e-5f, s));
@@ -478,7 +479,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
   const int start = n_prefix;
   SS_HIP_CHECK(hipMemcpyAsync(tok, host, (size_t)(start + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
   // step `start`: feed [eos, prefix...] in one pass
-  RET(ss_mt_append(m, stream, tok, start + 1, 0, start < min_len, start >= max_len, d_feats, tok + start + 1));
+  RET(ss_mt_append(m, stream, tok, start + 1, 0, start < min_len, start >= max_len, d_feats, tok + start + 1, 0));
   int step = start + 1;      // next position to feed == index of the newest generated token
   int eos_at = -1, checked = start + 1;
   while (true) {
@@ -492,7 +493,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
       if (eos_at >= 0 || last) break;
     }
     RET(ss_mt_append(m, stream, tok + step, 1, step, step < min_len, step >= max_len,
-                     d_feats + (size_t)step * D, tok + step + 1));
+                     d_feats + (size_t)step * D, tok + step + 1, 0));
     ++step;
   }
   const int end = eos_at >= 0 ? eos_at : step;          // index of the last generated token
@@ -506,7 +507,8 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
 
 // ---- T2U encoder + CTC unit decoder ------------------------------------------------------------
 extern "C" int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, int n, int t2u_causal,
-                            int mask_eos, int32_t* d_raw, int32_t* d_tokens, int32_t* d_count, float* d_logits) {
+                            int mask_eos, int32_t* d_raw, int32_t* d_tokens, int32_t* d_count, float* d_logits,
+                            int n_tail_pad) {
   if (!m || n <= 0) return SS_ERR_ARG;
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
@@ -529,13 +531,13 @@ extern "C" int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, 
   // T2U encoder (transformer_encoder.py:32-77): 2 pre-LN layers + final LN
   SS_HIP_CHECK(hipMemcpyAsync(x, d_mt_feats, (size_t)n * D * sizeof(float), hipMemcpyDeviceToDevice, s));
   for (int l = 0; l < c.t2u_layers; ++l)
-    RET(dec_layer(s, c, m->t2u[l], x, n, 0, selfbuf, t2u_causal != 0, nullptr, 0, h, q2, ff));
+    RET(dec_layer(s, c, m->t2u[l], x, n, 0, selfbuf, t2u_causal != 0, nullptr, 0, h, q2, ff, n_tail_pad, 0));
   RET(launch_layernorm(x, D, t2u_out, D, m->t2u_ln.g, m->t2u_ln.b, n, D, 1e-5f, s));
   // unit decoder input: each T2U state 25x + the (quirky) positional row
   RET(launch_upsample_add_pos(t2u_out, n, c.ctc_upsample, m->unit_pos_row, (float)c.pad, x, D, s));
   for (int l = 0; l < c.unit_layers; ++l) {
     RET(linear(s, t2u_out, D, n, m->unit[l].cross_kv, 2 * D, D, crosskv, 2 * D));
-    RET(dec_layer(s, c, m->unit[l], x, U, 0, selfbuf, true, crosskv, n, h, q2, ff));
+    RET(dec_layer(s, c, m->unit[l], x, U, 0, selfbuf, true, crosskv, n, h, q2, ff, n_tail_pad * c.ctc_upsample, n_tail_pad));
   }
   RET(launch_layernorm(x, D, h, D, m->unit_ln.g, m->unit_ln.b, U, D, 1e-5f, s));
   RET(linear(s, h, D, U, m->unit_out, V, D, logits, V));

@@ -197,13 +197,13 @@ class HipModel(BatchMixin):
         L.check(self.lib.ss_mt_begin(self.h, _stream(), _ptr(enc_out), enc_out.shape[0]), "ss_mt_begin")
 
     def mt_append(self, tokens: List[int], pos0: int, ban_eos: bool, force_eos: bool,
-                  want_feats: bool = True, want_next: bool = True) -> Tuple[Optional[torch.Tensor], Optional[int]]:
+                  want_feats: bool = True, want_next: bool = True, n_tail_pad: int = 0) -> Tuple[Optional[torch.Tensor], Optional[int]]:
         n = len(tokens)
         tok = torch.tensor(tokens, dtype=torch.int32).to(self.device)
         feats = torch.empty((n, self.cfg.dec_dim), dtype=torch.float32, device=self.device) if want_feats else None
         nxt = torch.empty((1,), dtype=torch.int32, device=self.device) if want_next else None
         L.check(self.lib.ss_mt_append(self.h, _stream(), _ptr(tok), n, pos0, int(ban_eos), int(force_eos),
-                                      _ptr(feats), _ptr(nxt)), "ss_mt_append")
+                                      _ptr(feats), _ptr(nxt), n_tail_pad), "ss_mt_append")
         return feats, (int(nxt.item()) if want_next else None)
 
     def mt_greedy(self, enc_out: torch.Tensor, prefix: List[int], max_len: int, min_len: int = 1):
@@ -224,7 +224,7 @@ class HipModel(BatchMixin):
 
     # ---- a11-a13 --------------------------------------------------------------------------
     def t2u_units(self, mt_feats: torch.Tensor, t2u_causal: bool = False, mask_eos: bool = False,
-                  want_logits: bool = False):
+                  want_logits: bool = False, n_tail_pad: int = 0):
         """mt_feats [n,512] -> (collapsed unit-vocab tokens list, raw argmax tensor(host), logits or None)."""
         n = mt_feats.shape[0]
         U = n * self.cfg.ctc_upsample
@@ -232,7 +232,7 @@ class HipModel(BatchMixin):
         raw, toks, cnt = ibuf[:U], ibuf[U:2 * U], ibuf[2 * U:]
         logits = torch.empty((U, self.cfg.unit_vocab), dtype=torch.float32, device=self.device) if want_logits else None
         L.check(self.lib.ss_t2u_units(self.h, _stream(), _ptr(mt_feats.contiguous()), n, int(t2u_causal),
-                                      int(mask_eos), _ptr(raw), _ptr(toks), _ptr(cnt), _ptr(logits)), "ss_t2u_units")
+                                      int(mask_eos), _ptr(raw), _ptr(toks), _ptr(cnt), _ptr(logits), n_tail_pad), "ss_t2u_units")
         host = ibuf.cpu()
         k = int(host[2 * U])
         return host[U:U + k].tolist(), host[:U], logits

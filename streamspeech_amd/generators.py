@@ -50,11 +50,12 @@ class CTCSequenceGenerator:
         self.incremental_states = None
 
     @torch.no_grad()
-    def generate(self, mt_features: torch.Tensor, prefix=None, **kw):
+    def generate(self, mt_features: torch.Tensor, prefix=None, n_tail_pad: int = 0, **kw):
         """mt_features [n,512] = the MT decoder states the reference feeds to synthesizer_encoder
         (agent :652-689; T2U encoder and unit decoder run inside one C-ABI stage)."""
         assert prefix is None, "tgt_units_indices is never set by the reference agent (SURVEY.md App. B)"
-        toks, raw, _ = self.engine.t2u_units(mt_features, t2u_causal=self.t2u_causal, mask_eos=self.mask_eos)
+        toks, raw, _ = self.engine.t2u_units(mt_features, t2u_causal=self.t2u_causal, mask_eos=self.mask_eos,
+                                             n_tail_pad=n_tail_pad)
         return [[{"tokens": torch.tensor(toks, dtype=torch.long), "org_tokens": raw, "attn": None, "alignment": None}]]
 
 

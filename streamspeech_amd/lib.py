@@ -42,11 +42,11 @@ SIGNATURES = {
     "ss_encoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ss_ctc_greedy": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ss_mt_begin": (_i, [_vp, _vp, _vp, _i]),
-    "ss_mt_append": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ss_mt_append": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i]),
     "ss_mt_truncate": (_i, [_vp, _i]),
     "ss_mt_greedy": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), _i, _i, _i, C.POINTER(C.c_int32), C.POINTER(_i),
                           _vp, C.POINTER(_i)]),
-    "ss_t2u_units": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ss_t2u_units": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "ss_vocoder_create": (_i, [C.POINTER(SSVocoderConfig), _vp, C.c_size_t, C.POINTER(C.c_char_p),
                                C.POINTER(_i64), C.POINTER(_i64), _i, C.POINTER(_vp)]),
     "ss_vocoder_destroy": (None, [_vp]),

@@ -30,7 +30,7 @@ class OracleEngine:
     def mt_begin(self, enc_out):
         self._enc, self._tokens = enc_out.cpu(), []
 
-    def mt_append(self, tokens, pos0, ban_eos, force_eos, want_feats=True, want_next=True):
+    def mt_append(self, tokens, pos0, ban_eos, force_eos, want_feats=True, want_next=True, n_tail_pad=0):
         self._tokens = self._tokens[:pos0] + list(tokens)
         feats = O.mt_decoder_features(self.sd, self._tokens, self._enc, self.cfg)
         nxt = None
@@ -50,9 +50,9 @@ class OracleEngine:
     def mt_truncate(self, length):
         self._tokens = self._tokens[:length]
 
-    def t2u_units(self, mt_feats, t2u_causal=False, mask_eos=False, want_logits=False):
-        t2u = O.t2u_encoder(self.sd, mt_feats.cpu(), self.cfg, causal=t2u_causal)
-        logits = O.unit_decoder_logits(self.sd, t2u, self.cfg)
+    def t2u_units(self, mt_feats, t2u_causal=False, mask_eos=False, want_logits=False, n_tail_pad=0):
+        t2u = O.t2u_encoder(self.sd, mt_feats.cpu(), self.cfg, causal=t2u_causal, n_tail_pad=n_tail_pad)
+        logits = O.unit_decoder_logits(self.sd, t2u, self.cfg, n_tail_pad=n_tail_pad)
         lp = torch.log_softmax(logits, -1)
         lp[:, self.cfg.pad] = float("-inf")
         lp[:, self.cfg.unk] = float("-inf")

@@ -83,3 +83,14 @@ def test_policy_returns_action_types(synth_weights):
     act = agent.policy()
     assert isinstance(act, WriteAction) and isinstance(act.content, SpeechSegment)
     assert act.content.sample_rate == 16000
+
+
+def test_whole_word_mode_runs(synth_weights):
+    """source_segment_size >= 640 ms: whole-word truncation + trailing <pad> position (agent :540-584)."""
+    from streamspeech_amd.agent import StreamSpeechS2STAgent
+    cfg, vcfg, sd, vsd = synth_weights
+    model = StreamSpeechModel.from_engine(OracleEngine(sd, cfg))
+    agent = StreamSpeechS2STAgent(make_args(640), model=model, vocoder=OracleVocoder(vsd, vcfg))
+    assert agent.whole_word and model.encoder.chunk_size == 16 and model.encoder._conv_chunk() == 16
+    wav, actions = stream(agent, synth.synth_pcm(4, 16000 * 2), segment_ms=640)
+    assert "W" in actions and len(wav) % 320 == 0 and np.isfinite(wav).all()

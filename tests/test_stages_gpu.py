@@ -103,6 +103,25 @@ def test_t2u_and_unit_decoder_identical_units(hip_model, golden_dir):
     assert units == gd["units"].tolist()
 
 
+def test_whole_word_trailing_pad_vs_reference_golden(hip_model, golden_dir):
+    """chunk >= 640 ms: one trailing <pad> position (agent :576-584) through MT decoder, T2U and unit
+    decoder with key-padding masks -- reference-module golden."""
+    ge, gd = _gold(golden_dir, "encoder.npz"), _gold(golden_dir, "decoders.npz")
+    enc = torch.from_numpy(ge["enc_offline"]).cuda()
+    ptoks = gd["pad_tokens_in"].tolist()
+    hip_model.mt_begin(enc)
+    f0, _ = hip_model.mt_append(ptoks[:-1], 0, False, False, want_next=False)
+    f1, _ = hip_model.mt_append(ptoks[-1:], len(ptoks) - 1, False, False, want_next=False, n_tail_pad=1)
+    feats = torch.cat([f0, f1])
+    assert np.abs(feats.cpu().numpy() - gd["pad_mt_features"]).max() < FEAT_TOL
+    # one-shot feed of [.., <pad>] gives the same thing
+    hip_model.mt_begin(enc)
+    f2, _ = hip_model.mt_append(ptoks, 0, False, False, want_next=False, n_tail_pad=1)
+    assert (f2 - feats).abs().max().item() < 1e-5
+    _, raw, _ = hip_model.t2u_units(torch.from_numpy(gd["pad_mt_features"]).cuda(), n_tail_pad=1)
+    assert raw.tolist() == gd["pad_unit_raw"].tolist()
+
+
 def test_vocoder_vs_reference_golden(hip_vocoder, golden_dir):
     g = _gold(golden_dir, "vocoder.npz")
     wav, dur = hip_vocoder.forward(g["codes"], dur_prediction=True)
@@ -163,7 +182,7 @@ def test_offline_utterance_units_and_wav(hip_model, hip_vocoder, synth_weights):
     assert rms < WAV_RMS_TOL, f"rms {rms}"
 
 
-@pytest.mark.parametrize("segment_ms", [320])
+@pytest.mark.parametrize("segment_ms", [320, 640])
 def test_streaming_agent_matches_oracle_agent(hip_model, hip_vocoder, synth_weights, segment_ms):
     """BASELINE.json configs[2]: simultaneous S2ST, chunk = 320 ms, wait-k policy, full recompute
     per chunk (reference semantics).  The HIP-backed agent and the same agent over the CPU oracle
