@@ -130,6 +130,8 @@ def main():
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the single-stream latency measurement")
     ap.add_argument("--batch", type=int, default=32,
                     help="utterances packed per ragged batch (1 = the one-utterance-at-a-time entry points)")
+    ap.add_argument("--no-length-bucketing", action="store_true",
+                    help="form ragged batches in arrival order instead of sorted by source length")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -206,7 +208,14 @@ def main():
     timed = list(zip(mine[Wn:Wn + K], pcms[Wn:Wn + K]))
     if Bsz == 1:
         work = timed
-    else:   # consecutive groups of Bsz utterances; the packed PCM buffer is built before the timed region
+    else:
+        # Groups of Bsz utterances; the packed PCM buffer is built before the timed region.  Like the
+        # reference's offline driver (fairseq-generate: dataset.ordered_indices() sorts by source
+        # length before batch_by_size, fairseq/tasks/fairseq_task.py get_batch_iterator), batches are
+        # formed from length-sorted utterances: the lock-step MT greedy search then runs ~mean instead
+        # of ~max-of-32 steps per batch.  Longest batches are dispatched first (LPT over the streams).
+        if not args.no_length_bucketing:
+            timed = sorted(timed, key=lambda t: -t[0].n_samples)
         work = []
         for g0 in range(0, len(timed), Bsz):
             grp = timed[g0:g0 + Bsz]
@@ -321,7 +330,7 @@ def main():
                                    "fbank+encoder+CTC+AR-MT+T2U+NAR-unit+vocoder HIP path, random-init weights "
                                    "of the streamspeech.offline.fr-en architecture",
                        "audio_seconds_per_gpu": round(sum(u.seconds for u in mine[Wn:Wn + K]), 2),
-                       "utterances_per_ragged_batch": Bsz, "concurrent_streams_per_gpu": S,
+                       "length_bucketed_batches": (not args.no_length_bucketing) and Bsz > 1, "utterances_per_ragged_batch": Bsz, "concurrent_streams_per_gpu": S,
                        "parallelism": f"utterance-dp{world}"},
             "latency_ms_single_stream": round(single_ms, 3), "rtfx_single_stream": round(single_rtfx, 2),
             "roofline": roofline,

@@ -169,8 +169,12 @@ int ss_prof_read(int cls, double* h_ms_total, double* h_flops_total, int64_t* h_
 int ss_prof_num_classes(void);
 const char* ss_prof_class_name(int cls);
 
-/* Tuning hook for tools/conv_bench.py: force the LDS-tiled GEMM tile (bm = 0: heuristic). */
+/* Tuning hook for tools/conv_bench.py: force the LDS-tiled GEMM tile (bm = 0: heuristic;
+ * bm = 1: route every eligible launch to the persistent stream-K kernel with a grid of ks
+ * workgroups, ks = 0 -> 2 per CU). */
 int ss_debug_force_tile(int bm, int bn, int ks);
+/* Number of bounded-spin time-outs the stream-K kernel has recorded (any value but 0 is a bug). */
+int ss_debug_sk_errors(void);
 
 /* ---- op-level entry points (unit tests of single kernels; same launchers the stages use) ---- */
 int ss_op_conv_gemm(void* stream, const float* dA, int lda, const float* dW, const float* dbias,

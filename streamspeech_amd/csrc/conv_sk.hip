@@ -1,0 +1,390 @@
+// Persistent stream-K implicit-GEMM Conv1d for gfx950 (exact-f32 MFMA), the big-problem path of
+// launch_conv_gemm: HiFi-GAN resblock / upsampling convs over a packed batch of utterances
+// (reference fairseq/models/text_to_speech/hifigan.py:52-172).
+//
+// Why a second kernel: at batch scale the 32x64-tile kernel is bound by everything *except* the
+// matrix cores (24 B/cycle/CU of L2->LDS traffic, LDS at 56 %, one barrier per 512 MFMA cycles), and
+// 128x128 tiles -- which need 3x less of all of that -- leave half the chip idle because a launch
+// has only ~300 of them for 512 resident workgroups (profiles/r01_tile_sweep_batch.txt).  Here:
+//   * 128 x BN tiles (BN = 128 | 64), BK = 32, 4 waves as 2x2, each wave 64 x BN/2 (TM=4, TN=BN/32).
+//   * stream-K: the linear (tile, k-step) space is cut into G equal contiguous ranges, one per
+//     workgroup (G = 2 per CU, all resident).  A workgroup that owns a tile's last k-step is its
+//     finisher; earlier owners park their partial tile in a workspace slot and raise a flag
+//     (agent-scope release); the finisher adds the partials in workgroup order (fixed order ->
+//     deterministic) and runs the epilogue.  Logical workgroup ids come from an atomic ticket, so a
+//     finisher only ever waits on workgroups that are already running (no dispatch-order assumption).
+//   * global -> LDS with global_load_lds_dwordx4 (no staging registers, no ds_write pass).  The LDS
+//     image is lane-linear (HW rule), so the bank swizzle is applied to the per-lane SOURCE address
+//     and again at the ds_read_b128: 16-B chunk c of row r sits at chunk position c ^ ((r>>1)&7).
+//     Out-of-segment rows (conv zero padding, ragged batch edges) read a zero page instead.
+//   * one barrier per k-step: wait own loads -> barrier -> issue next step's loads -> 128 MFMAs.
+//   * the leaky-ReLU on the conv input is applied to the A fragments after the ds_read
+//     (max(v, slope*v), 8 VALU per 64 MFMAs).
+#include "gemm.hpp"
+
+#include <map>
+#include <mutex>
+
+namespace ss {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
+
+struct SkArgs {
+  float* ws;            // [G][128*BN] partial tiles
+  unsigned* sync;       // [0] ticket counter, [1] time-out counter, [16 + w] flag of logical workgroup w
+  const float* zeros;   // >= 16 B of zeros
+  unsigned base;        // ticket value of logical workgroup 0 of this launch
+  unsigned epoch;       // flag value meaning "partial of this launch is in place"
+  int G;
+};
+
+constexpr int SK_BM = 128, SK_BK = 32, SK_FLAG0 = 16, SK_MAXG = 512;
+constexpr unsigned SK_SPIN_LIMIT = 1u << 22;
+constexpr int SK_NUM_RECORDS = 0x7ffffff0;          // buffer range: every real offset is below, SK_OOB is above
+constexpr unsigned SK_OOB = 0x80000000u;
+
+template <int BN, bool LRELU>
+__global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const SkArgs q) {
+#if __HIP_DEVICE_COMPILE__   // the buffer-resource builtins have no host-pass meaning (the stub would not be emitted)
+  constexpr int BM = SK_BM, BK = SK_BK;
+  constexpr int TM = 4, TN = BN / 32;          // 16x16 MFMA tiles per wave (wave tile 64 x BN/2)
+  constexpr int NWI = BN / 32;                 // W glds instructions per wave per k-step (A: 4)
+  constexpr int STAGE = (BM + BN) * BK;        // floats per LDS stage
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* s_lo = reinterpret_cast<int*>(smem + 2 * STAGE);
+  int* s_hi = s_lo + BM;
+  int* s_misc = s_hi + BM;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+
+  if (t == 0) s_misc[0] = (int)(atomicAdd(q.sync, 1u) - q.base);
+  __syncthreads();
+  const int w = __builtin_amdgcn_readfirstlane(s_misc[0]);
+
+  const int kpt = p.Cin / BK;
+  const int nk = p.taps * kpt;
+  const int Ktot = p.taps * p.Cin;
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const long long U = (long long)tiles_m * tiles_n * nk;
+  const long long u0 = (long long)w * U / q.G;
+  long long ue = (long long)(w + 1) * U / q.G;     // the range is walked from its END: see below
+
+  const float slope = p.in_slope;
+  // Buffer resources for the LDS-DMA loads: per-lane byte offsets stay constant over a tile and the
+  // k-step (tap shift, channel block) goes into the wave-uniform soffset, so staging costs 4 VALU
+  // per A row and none per W row.  Rows outside their utterance get an offset beyond num_records:
+  // the buffer range check then returns zeros (conv zero padding).  The A base is moved back by
+  // `pad` rows so that every valid offset is non-negative.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<uintptr_t>(p.A) - (uintptr_t)p.pad * p.lda * sizeof(float)), 0, SK_NUM_RECORDS, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, SK_NUM_RECORDS, 0x00020000);
+
+  // per-lane LDS read offsets (floats) inside a stage: row (r) * 32 + swizzled chunk
+  const int swz = (r >> 1) & 7;
+  const int rdA0 = (wm * 64 + r) * BK + ((g ^ swz) << 2);
+  const int rdA1 = (wm * 64 + r) * BK + (((4 + g) ^ swz) << 2);
+  const int rdW0 = BM * BK + (wn * (BN / 2) + r) * BK + ((g ^ swz) << 2);
+  const int rdW1 = BM * BK + (wn * (BN / 2) + r) * BK + (((4 + g) ^ swz) << 2);
+  // per-lane staging roles: instruction j of this wave covers 8 rows x 8 chunks
+  const int st_row = lane >> 3, st_pos = lane & 7;
+
+  int cur_tm = -1;
+  // Tiles of the range are processed last-to-first.  The only tile a workgroup can leave unfinished
+  // is the last one of its range (it owns the head k-steps, a later workgroup owns the end), so its
+  // partial is parked before anything else; the tile it must finish is the first one of its range
+  // and comes last -- by then the earlier workgroups (lower tickets, already running) have parked
+  // theirs.  Nobody ever waits on a workgroup that is itself waiting: no dependency chains.
+  while (ue > u0) {
+    const int tile = (int)((ue - 1) / nk);
+    const long long ut0 = (long long)tile * nk;
+    const int ka = (int)(max(u0, ut0) - ut0);
+    const int kb = (int)(ue - ut0);
+    ue = ut0 + ka;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    __syncthreads();                     // previous tile's LDS reads (stages, row bounds) are done
+    if (tm != cur_tm) {
+      cur_tm = tm;
+      if (t < BM) {
+        const int m = m0 + t;
+        int lo = 0, hi = 0;
+        if (m < p.M) {
+          if (p.nseg > 0) {
+            for (int s = 0; s < p.nseg; ++s) {
+              const int st = p.segs[4 * s], ln = p.segs[4 * s + 1];
+              if (m >= st && m < st + ln) { lo = st; hi = st + ln; }
+            }
+          } else {
+            hi = p.in_len;
+          }
+        }
+        s_lo[t] = lo; s_hi[t] = hi;
+      }
+      __syncthreads();
+    }
+    int a_rin0[4], a_lo[4], a_hi[4];
+    unsigned a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int row = wave * 32 + j * 8 + st_row;
+      a_rin0[j] = m0 + row - p.pad;
+      a_lo[j] = s_lo[row]; a_hi[j] = s_hi[row];
+      a_off[j] = (unsigned)(((m0 + row) * p.lda + ((st_pos ^ ((row >> 1) & 7)) << 2)) * 4);
+    }
+    unsigned w_off[NWI];
+#pragma unroll
+    for (int j = 0; j < NWI; ++j) {
+      const int nrow = wave * (BN / 4) + j * 8 + st_row;
+      w_off[j] = (unsigned)(((n0 + nrow) * Ktot + ((st_pos ^ ((nrow >> 1) & 7)) << 2)) * 4);
+    }
+    int ntap = ka / kpt, nci = (ka - ntap * kpt) * BK;     // (tap, channel offset) of the next step to stage
+    auto issue = [&](int kstep, int stage) {
+      float* sA = smem + stage * STAGE + (wave * 32) * BK;
+      float* sW = smem + stage * STAGE + BM * BK + (wave * (BN / 4)) * BK;
+      const int shift = ntap * p.dil;
+      const int soffA = (shift * p.lda + nci) * 4;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int rin = a_rin0[j] + shift;
+        const bool ok = rin >= a_lo[j] && rin < a_hi[j];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + j * 8 * BK), 16, ok ? a_off[j] : SK_OOB, soffA, 0, 0);
+      }
+      const int soffW = kstep * BK * 4;
+#pragma unroll
+      for (int j = 0; j < NWI; ++j)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sW + j * 8 * BK), 16, w_off[j], soffW, 0, 0);
+      nci += BK;
+      if (nci >= p.Cin) { nci = 0; ++ntap; }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    issue(ka, 0);
+    for (int k = ka; k < kb; ++k) {
+      const int cur = (k - ka) & 1;
+#ifdef SS_ABLATE
+      if (!(p.dbg & 8))
+#endif
+      {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                   // step k landed for everyone; everyone finished reading stage cur^1
+      }
+#ifdef SS_ABLATE
+      if (!(p.dbg & 1))
+#endif
+      if (k + 1 < kb) issue(k + 1, cur ^ 1);
+      const float* S = smem + cur * STAGE;
+#ifdef SS_ABLATE
+      if (!(p.dbg & 2))
+#endif
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f32x4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          af[i] = *reinterpret_cast<const f32x4*>(S + (kk ? rdA1 : rdA0) + i * 16 * BK);
+          if (LRELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) af[i][e] = fmaxf(af[i][e], af[i][e] * slope);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(S + (kk ? rdW1 : rdW0) + j * 16 * BK);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+      }
+    }
+
+    bool has_end = kb == nk;
+#ifdef SS_ABLATE
+    if (p.dbg & 16) { if (!has_end) continue; }
+    if (p.dbg & 32) continue;
+#endif
+    if (!has_end) {
+      // ---- contributor: park the partial tile, raise the flag ----
+      // Partials and flags move with agent-scope (sc1) relaxed atomics: they write through / read
+      // past the per-XCD L2, so no L2 write-back or invalidate (which would evict the weights every
+      // other workgroup of the XCD is streaming) is needed.  Order: stores complete (vmcnt 0) ->
+      // workgroup barrier -> flag.
+      unsigned* slot = reinterpret_cast<unsigned*>(q.ws + (size_t)w * (BM * BN));
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            __hip_atomic_store(slot + (((wave * TM + i) * TN + j) * 4 + e) * 64 + lane, __float_as_uint(acc[i][j][e]),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (t == 0) __hip_atomic_store(q.sync + SK_FLAG0 + w, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+#ifdef SS_ABLATE
+    if (!(p.dbg & 16))
+#endif
+    if (ka > 0) {
+      // ---- finisher: collect the partials of the workgroups that own k-steps [0, ka) of this tile ----
+      const int wf = (int)(((ut0 + 1) * q.G - 1) / U);                // workgroup that owns the tile's first unit
+      if (t == 0) {
+        for (int ww = wf; ww < w; ++ww) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(q.sync + SK_FLAG0 + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q.epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > SK_SPIN_LIMIT) { atomicAdd(q.sync + 1, 1u); break; }
+          }
+        }
+      }
+      __syncthreads();
+      for (int ww = wf; ww < w; ++ww) {      // fixed order: ((mine + P[wf]) + P[wf+1]) + ...
+        const unsigned* slot = reinterpret_cast<const unsigned*>(q.ws + (size_t)ww * (BM * BN));
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            unsigned o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              o[e] = __hip_atomic_load(slot + (((wave * TM + i) * TN + j) * 4 + e) * 64 + lane, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] += __uint_as_float(o[e]);
+            __builtin_amdgcn_sched_barrier(0);   // 4 loads in flight per step: keeps the register budget of the main loop
+          }
+      }
+    }
+
+    // ---- epilogue (same operation order as conv_gemm_kernel) ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / 2) + j * 16 + r;
+        const float b = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int m = m0 + wm * 64 + i * 16 + g * 4 + e;
+          if (m < p.M) {
+            float v = acc[i][j][e] + b;
+            switch (p.act) {
+              case ACT_SILU: v = v / (1.0f + expf(-v)); break;
+              case ACT_RELU: v = fmaxf(v, 0.f); break;
+              case ACT_TANH: v = tanhf(v); break;
+              case ACT_LRELU: v = v > 0.f ? v : v * p.act_slope; break;
+              default: break;
+            }
+            v *= p.alpha;
+            if (p.R) v += p.R[(size_t)m * p.ldr + n];
+            if (p.R2) v = p.R2[(size_t)m * p.ldr2 + n] + v;
+            if (p.div > 0.f) v = v / p.div;
+            p.C[(size_t)m * p.ldc + n] = v;
+            if (p.C2) p.C2[(size_t)m * p.ldc2 + n] = v > 0.f ? v : v * p.c2_slope;
+          }
+        }
+      }
+  }
+#endif
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+struct SkState {
+  float* ws = nullptr;
+  unsigned* sync = nullptr;
+  unsigned base = 0, epoch = 0;
+};
+static std::map<hipStream_t, SkState> g_sk;
+static std::mutex g_sk_mu;
+static int g_sk_cus = 0;
+constexpr size_t SK_SYNC_BYTES = (SK_FLAG0 + SK_MAXG) * sizeof(unsigned) + 256;
+
+static int sk_state(hipStream_t stream, SkState** out) {
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  if (!g_sk_cus) {
+    int dev = 0;
+    SS_HIP_CHECK(hipGetDevice(&dev));
+    SS_HIP_CHECK(hipDeviceGetAttribute(&g_sk_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (g_sk_cus <= 0) g_sk_cus = 256;
+    if (2 * g_sk_cus > SK_MAXG) g_sk_cus = SK_MAXG / 2;
+  }
+  SkState& st = g_sk[stream];
+  if (!st.ws) {
+    SS_HIP_CHECK(hipMalloc(&st.ws, (size_t)SK_MAXG * SK_BM * 128 * sizeof(float)));
+    SS_HIP_CHECK(hipMalloc(&st.sync, SK_SYNC_BYTES));
+    SS_HIP_CHECK(hipMemsetAsync(st.sync, 0, SK_SYNC_BYTES, stream));
+  }
+  *out = &st;
+  return SS_OK;
+}
+
+bool conv_sk_eligible(const GemmArgs& a) {
+  return a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && a.Cin % SK_BK == 0 && (a.lda & 3) == 0 &&
+         a.N % 64 == 0 && a.M > 0 && ((size_t)(a.M + a.pad + 128) * a.lda + a.Cin) * 4 < 0x7ff00000ull &&
+         (size_t)a.N * a.taps * a.Cin * 4 < 0x7ff00000ull && (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f));
+}
+
+int conv_sk_error_count() {
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  int total = 0;
+  for (auto& kv : g_sk) {
+    unsigned v = 0;
+    if (kv.second.sync && hipMemcpy(&v, kv.second.sync + 1, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) total += (int)v;
+  }
+  return total;
+}
+
+template <int BN, bool LRELU>
+static int launch_sk(const GemmArgs& a, hipStream_t stream, int g_force) {
+  constexpr size_t kLds = 2 * (size_t)(SK_BM + BN) * SK_BK * sizeof(float) + (2 * SK_BM + 4) * sizeof(int);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_kernel<BN, LRELU>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+    attr_set = true;
+  }
+  SkState* st = nullptr;
+  int rc = sk_state(stream, &st);
+  if (rc != SS_OK) return rc;
+  const long long nk = (long long)a.taps * (a.Cin / SK_BK);
+  const long long U = (long long)cdiv(a.M, SK_BM) * (a.N / BN) * nk;
+  // every workgroup gets >= 8 k-steps so that the fix-up (one 64-KB partial) stays a small fraction
+  long long G = g_force > 0 ? g_force : 2LL * g_sk_cus;
+  if (G > U / 8) G = U / 8;
+  if (G < 1) G = 1;
+  if (G > SK_MAXG) G = SK_MAXG;
+  SkArgs q;
+  q.ws = st->ws; q.sync = st->sync;
+  q.zeros = reinterpret_cast<const float*>(st->sync + SK_FLAG0 + SK_MAXG);
+  q.base = st->base; q.epoch = ++st->epoch; q.G = (int)G;
+  st->base += (unsigned)G;
+  ProfRec rec{}; bool prof = false;
+  rc = prof_begin(a, stream, 15, rec, prof);
+  if (rc != SS_OK) return rc;
+  hipLaunchKernelGGL((conv_sk_kernel<BN, LRELU>), dim3((unsigned)G), dim3(256), kLds, stream, a, q);
+  SS_LAUNCH_CHECK();
+  return prof_end(stream, rec, prof);
+}
+
+int launch_conv_sk(const GemmArgs& a, hipStream_t stream, int g_force) {
+  if (!conv_sk_eligible(a)) return SS_ERR_ARG;
+  const bool lr = a.in_act == ACT_LRELU;
+  if (a.N % 128 == 0) return lr ? launch_sk<128, true>(a, stream, g_force) : launch_sk<128, false>(a, stream, g_force);
+  return lr ? launch_sk<64, true>(a, stream, g_force) : launch_sk<64, false>(a, stream, g_force);
+}
+
+}  // namespace ss

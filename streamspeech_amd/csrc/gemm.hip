@@ -231,6 +231,7 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
       case ACT_SILU: return v / (1.0f + expf(-v));
       case ACT_RELU: return fmaxf(v, 0.f);
       case ACT_TANH: return tanhf(v);
+      case ACT_LRELU: return v > 0.f ? v : v * p.act_slope;
       default: return v;
     }
   };
@@ -276,6 +277,7 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
             if (p.R2) v = p.R2[row * p.ldr2 + n] + v;
             if (p.div > 0.f) v = v / p.div;
             p.C[row * p.ldc + n] = v;
+            if (p.C2) p.C2[row * p.ldc2 + n] = v > 0.f ? v : v * p.c2_slope;
           }
         }
       }
@@ -429,8 +431,7 @@ static const char* kTileNames[kNumTileCfg] = {
     "conv_gemm<128,16,16,4,1>", "conv_gemm<128,32,32,4,1>", "conv_gemm<128,32,16,4,1>", "conv_gemm<16,128,32,1,4>",
     "conv_gemm<16,128,16,1,4>", "conv_gemm<128,128,16,2,2>", "conv_gemm<128,64,32,2,2>", "conv_gemm<64,64,32,2,2>",
     "conv_gemm<64,64,16,2,2>", "conv_gemm<32,64,32,2,2>", "conv_gemm<32,64,16,2,2>", "conv_gemm<32,32,32,2,2>",
-    "smallm_gemm<4,1>", "smallm_gemm<2,2>", "smallm_gemm<1,4>", "reserved"};
-struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int cls; };
+    "smallm_gemm<4,1>", "smallm_gemm<2,2>", "smallm_gemm<1,4>", "conv_sk<128,BN,32>"};
 static int g_prof_mask = 0;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
@@ -458,7 +459,7 @@ int prof_read(int cls, double* ms_total, double* flops_total, long long* launche
   return SS_OK;
 }
 
-static int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, bool& prof) {
+int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, bool& prof) {
   prof = (g_prof_mask >> cls) & 1;
   if (!prof) return SS_OK;
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -474,7 +475,7 @@ static int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& r
   SS_HIP_CHECK(hipEventRecord(rec.e0, stream));
   return SS_OK;
 }
-static int prof_end(hipStream_t stream, ProfRec& rec, bool prof) {
+int prof_end(hipStream_t stream, ProfRec& rec, bool prof) {
   if (prof) { SS_HIP_CHECK(hipEventRecord(rec.e1, stream)); std::lock_guard<std::mutex> lk(g_prof_mu); g_prof_recs.push_back(rec); }
   return SS_OK;
 }
@@ -529,13 +530,14 @@ static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
 }
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
+static double g_sk_min_flops = 4e9;   // below this the small-tile kernels win (tools/conv_bench.py sk)
 void debug_force_tile(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn; g_force_ks = ks; }
 
 bool smallm_eligible(const GemmArgs& a) {
-  if (g_force_bm) return false;
+  if (g_force_bm > 1) return false;
   const int M = a.nseg > 0 ? a.max_seg_out : a.M;
   const bool plain_linear = a.taps == 1 && a.stride == 1 && a.pad == 0 && !a.glu && a.nseg == 0 && a.chunk == 0 &&
-                            a.in_act == ACT_NONE && !a.R2 && a.div == 0.f &&
+                            a.in_act == ACT_NONE && !a.R2 && !a.C2 && a.div == 0.f &&
                             (a.act == ACT_NONE || a.act == ACT_SILU || a.act == ACT_RELU);
   return plain_linear && M <= 128 && M > 0 && a.Cin % 64 == 0 && (a.lda & 3) == 0;
 }
@@ -543,6 +545,7 @@ bool smallm_eligible(const GemmArgs& a) {
 #ifdef SS_ABLATE
 static int g_dbg = 0;
 void debug_set_ablate(int v) { g_dbg = v; }
+extern "C" int ss_debug_set_ablate(int v) { g_dbg = v; return 0; }
 #endif
 
 int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
@@ -553,7 +556,7 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   const int M = a.nseg > 0 ? a.max_seg_out : a.M;
   if (M <= 0 || a.N <= 0) return SS_OK;
   if (a.Cin % 16 != 0 || (a.lda & 3) != 0 || a.taps < 1) return SS_ERR_ARG;
-  if (a.glu && (a.N % 32 != 0)) return SS_ERR_ARG;
+  if (a.glu && (a.N % 32 != 0 || a.C2)) return SS_ERR_ARG;
   const bool k32 = (a.Cin % 32) == 0;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   if (smallm_eligible(a)) {
@@ -563,6 +566,17 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
     return launch_smallm<1, 4>(a, stream, 14);
   }
   if (a.ln_g) return SS_ERR_ARG;  // LayerNorm fusion exists only on the small-M path
+#ifdef SS_ABLATE
+  a.dbg = g_dbg;
+#endif
+  if (g_force_bm == 1 && conv_sk_eligible(a)) return launch_conv_sk(a, stream, g_force_ks);   // tuning hook: stream-K, grid = ks (0 = auto)
+  // Big long-K "same" convs (packed vocoder batches, k >= 7 at C >= 128): persistent stream-K
+  // 128x128 tiles, +13..16 % over the 32x64 kernel.  Short-K problems (k = 3) and N = 64 stay on the
+  // small tiles: the per-workgroup fix-up + epilogue (~30 us) is not amortised over ~13 k-steps
+  // (profiles/r01_sk_sweep.txt).
+  if (!g_force_bm && conv_sk_eligible(a) && a.N % 128 == 0 && a.taps * a.Cin >= 1024 &&
+      2.0 * (double)a.M * a.N * a.taps * a.Cin >= g_sk_min_flops)
+    return launch_conv_sk(a, stream);
   if (g_force_bm && a.N > 32 && k32) {   // tuning hook (tools/conv_bench.py): ks = KS*10 + PD
     const int f = g_force_bm * 10000 + (g_force_bn % 100) * 100 + g_force_ks;   // 128x128 -> bn code 28... see cases
     switch (f) {

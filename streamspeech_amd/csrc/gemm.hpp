@@ -30,6 +30,13 @@ struct GemmArgs {
   int act = ACT_NONE;         // epilogue activation on (acc + bias)
   float alpha = 1.0f;         // v *= alpha (after activation)
   float div = 0.0f;           // if > 0: v /= div at the very end (MRF mean)
+  float act_slope = 0.1f;     // slope of an ACT_LRELU epilogue activation
+  // Optional second output C2 = leaky_relu(C, c2_slope): lets the *consumer* conv read a
+  // pre-activated input (in_act = ACT_NONE) instead of applying the activation to every A fragment
+  // inside its MFMA loop (VALU issue slots there cost matrix-core time one for one).
+  float* C2 = nullptr;
+  int ldc2 = 0;
+  float c2_slope = 0.1f;
   int glu = 0;                // 1: W rows are interleaved [16 value | 16 gate] blocks, out has N/2 cols
   // ragged batch: nseg > 0 -> segs[4*s] = {out_start, out_len, in_start, in_len}; M/in_len ignored
   const int* segs = nullptr;
@@ -40,6 +47,11 @@ struct GemmArgs {
   // A' = (A - mean) * rstd * ln_g + ln_b, eps 1e-5 -- saves the separate LayerNorm launch.
   const float* ln_g = nullptr;
   const float* ln_b = nullptr;
+  // 1: the caller guarantees a "same" row mapping -- stride 1, output row m reads input rows
+  // m - pad + j*dil of the same packed buffer, segments (if any) are contiguous with
+  // out_start == in_start and out_len == in_len.  Makes the launch eligible for the persistent
+  // stream-K kernel (conv_sk.hip).
+  int same_rows = 0;
 #ifdef SS_ABLATE
   int dbg = 0;                // timing-only ablation switches (tools/, never in the product build)
 #endif
@@ -52,6 +64,18 @@ void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile confi
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
 const char* prof_cfg_name(int cls);
+
+// Event-profiler scope shared by the kernel launchers (gemm.hip, conv_sk.hip).
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int cls; };
+int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, bool& prof);
+int prof_end(hipStream_t stream, ProfRec& rec, bool prof);
+
+// Persistent stream-K conv-GEMM (conv_sk.hip): 128 x BN tiles, the (tile, k-step) space is cut into
+// equal contiguous ranges, one per resident workgroup, so every CU gets the same MFMA work whatever
+// the tile count.  g_force > 0 fixes the grid size (tuning hook).
+bool conv_sk_eligible(const GemmArgs& a);
+int launch_conv_sk(const GemmArgs& a, hipStream_t stream, int g_force = 0);
+int conv_sk_error_count();   // number of bounded-spin time-outs seen so far (must stay 0)
 
 // True when launch_conv_gemm would route `a` to the small-M kernel (the only one with the fused
 // LayerNorm prologue).

@@ -69,6 +69,7 @@ int linear(hipStream_t s, const float* A, int lda, int M, const Lin& l, int N, i
   GemmArgs a;
   a.A = A; a.lda = lda; a.W = l.w; a.bias = l.b; a.C = C; a.ldc = ldc; a.R = R; a.ldr = ldr;
   a.M = M; a.N = N; a.Cin = K; a.in_len = M; a.act = act; a.alpha = alpha; a.glu = glu;
+  a.same_rows = 1;   // a linear layer maps row m to row m
   return launch_conv_gemm(a, s);
 }
 
@@ -607,12 +608,88 @@ extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
   delete v;
 }
 
+// -------------------------------------------------------------------------------------------------
+// HiFi-GAN generator stack shared by the single-utterance and the ragged-batch entry points
+// (hifigan.py:154-170).  `conv(GemmArgs&, scale)` fills in the row geometry (rows = frames * scale,
+// segment table) and launches; `on_stage(scale)` is called when the row scale changes.
+//
+// Leaky-ReLU placement: the reference applies leaky_relu to the *input* of every conv.  On the
+// MFMA-bound stages (C >= 64) the producer writes the activated tensor instead (conv1: ACT_LRELU
+// epilogue; conv2 / up-conv: second output C2 = leaky_relu(C)), so the consumer's MFMA loop carries
+// no VALU work; the values are bit-identical (same f32 select on the same f32 number).  On the
+// HBM-bound late stages (C < 64) the extra write would cost more than the VALU, so the activation
+// stays on the consumer's A-fragment path there.
+// -------------------------------------------------------------------------------------------------
+struct GenBufs { float *bx, *bt, *br, *bs, *bxa, *bra, *bsa; };
+
+template <class ConvFn, class StageFn>
+static int hifigan_stack(const ss_vocoder* v, ConvFn&& conv, StageFn&& on_stage, const float* frames, int Ft,
+                         const GenBufs& b, int* out_scale, int* out_C) {
+  const ss_vocoder_config& c = v->cfg;
+  auto preact = [](int channels) { return channels >= 64; };
+  auto mk = [](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
+    GemmArgs a;
+    a.A = A; a.lda = Cin; a.W = cw.w; a.bias = cw.b; a.C = Cc; a.ldc = ldc; a.ldr = ldc; a.ldr2 = ldc; a.ldc2 = ldc;
+    a.N = Cout; a.Cin = Cin; a.taps = k; a.dil = dil; a.stride = 1; a.pad = dil * (k - 1) / 2; a.same_rows = 1;
+    return a;
+  };
+  int scale = 1, C = c.upsample_initial_channel;
+  RET(on_stage(scale));
+  {
+    GemmArgs a = mk(frames, c.model_in_dim, v->pre, C, 7, 1, b.bx, C);
+    if (preact(C)) a.C2 = b.bxa;
+    RET(conv(a, scale));
+  }
+  for (int i = 0; i < c.n_up; ++i) {
+    const int st = c.upsample_rates[i], Co = C / 2;
+    const bool pa_in = preact(C), pa = preact(Co);
+    {
+      // leaky_relu(0.1) -> ConvTranspose1d as a 3-tap polyphase conv with N = st*Co: row q of the
+      // [T, st*Co] result is rows q*st .. q*st+st-1 of the [T*st, Co] signal.
+      GemmArgs a = mk(pa_in ? b.bxa : b.bx, C, v->ups[i], st * Co, 3, 1, b.bs, st * Co);
+      if (!pa_in) { a.in_act = ACT_LRELU; a.in_slope = 0.1f; }
+      if (pa) a.C2 = b.bsa;
+      a.algo_flops = 2.0 * Ft * scale * C * Co * c.upsample_kernel_sizes[i];   // zero-padded polyphase slots are not work
+      RET(conv(a, scale));
+    }
+    scale *= st; C = Co;
+    RET(on_stage(scale));
+    const bool pa_next = (i + 1 < c.n_up) && preact(C);     // the next up-conv reads leaky_relu(x)
+    for (int j = 0; j < c.n_res; ++j) {
+      const int kr = c.resblock_kernel_sizes[j];
+      for (int dd = 0; dd < 3; ++dd) {
+        const int idx = (i * c.n_res + j) * 3 + dd;
+        const float* rin = dd == 0 ? b.bs : b.br;           // residual stream (un-activated)
+        const float* rin_act = dd == 0 ? b.bsa : b.bra;     // its leaky_relu, when pre-activated
+        GemmArgs a1 = mk(pa ? rin_act : rin, C, v->rb_c1[idx], C, kr, c.resblock_dilations[j][dd], b.bt, C);
+        if (pa) { a1.act = ACT_LRELU; a1.act_slope = 0.1f; }
+        else { a1.in_act = ACT_LRELU; a1.in_slope = 0.1f; }
+        RET(conv(a1, scale));
+        GemmArgs a2 = mk(b.bt, C, v->rb_c2[idx], C, kr, 1, dd < 2 ? b.br : b.bx, C);
+        if (!pa) { a2.in_act = ACT_LRELU; a2.in_slope = 0.1f; }
+        a2.R = rin;
+        if (dd < 2) {
+          if (pa) a2.C2 = b.bra;
+        } else {
+          // last conv of the resblock also folds the MRF sum: xs (+)= resblock_j(x); x = xs / n_res
+          a2.R2 = j == 0 ? nullptr : b.bx;
+          a2.div = (j == c.n_res - 1) ? (float)c.n_res : 0.f;
+          if (pa_next && j == c.n_res - 1) a2.C2 = b.bxa;
+        }
+        RET(conv(a2, scale));
+      }
+    }
+  }
+  *out_scale = scale; *out_C = C;
+  return SS_OK;
+}
+
 static int conv1d(hipStream_t s, const float* A, int T, int Cin, const ConvW& cw, int Cout, int k, int dil,
                   float* C, int in_act, float slope, int act, const float* R, const float* R2, float div) {
   GemmArgs a;
   a.A = A; a.lda = Cin; a.W = cw.w; a.bias = cw.b; a.C = C; a.ldc = Cout; a.R = R; a.ldr = Cout; a.R2 = R2; a.ldr2 = Cout;
   a.M = T; a.N = Cout; a.Cin = Cin; a.taps = k; a.dil = dil; a.stride = 1; a.pad = dil * (k - 1) / 2; a.in_len = T;
-  a.in_act = in_act; a.in_slope = slope; a.act = act; a.div = div;
+  a.in_act = in_act; a.in_slope = slope; a.act = act; a.div = div; a.same_rows = 1;
   return launch_conv_gemm(a, s);
 }
 
@@ -663,45 +740,22 @@ extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_
     int T = Fr, C = c.upsample_initial_channel;
     for (int i = 0; i < c.n_up; ++i) { T *= c.upsample_rates[i]; C /= 2; stage_max = std::max(stage_max, (size_t)T * C); }
   }
-  RET(v->ws.ensure((4 * stage_max + (size_t)Fr * E) * sizeof(float)));
+  RET(v->ws.ensure((7 * stage_max + (size_t)Fr * E) * sizeof(float)));
   float* frames = v->ws.f();
-  float* bx = frames + (size_t)Fr * E;   // stage input / MRF accumulator ping-pong
-  float* bt = bx + stage_max;            // conv1 output
-  float* br = bt + stage_max;            // running resblock state
-  float* bs = br + stage_max;            // x after the transposed conv
+  GenBufs gb;
+  gb.bx = frames + (size_t)Fr * E;       // stage input / MRF accumulator
+  gb.bt = gb.bx + stage_max;             // conv1 output
+  gb.br = gb.bt + stage_max;             // running resblock state
+  gb.bs = gb.br + stage_max;             // x after the transposed conv
+  gb.bxa = gb.bs + stage_max;            // leaky_relu twins of bx / br / bs (MFMA-bound stages only)
+  gb.bra = gb.bxa + stage_max;
+  gb.bsa = gb.bra + stage_max;
   RET(launch_repeat_rows(emb, cum, K, E, frames, Fr, s));
-  RET(conv1d(s, frames, Fr, c.model_in_dim, v->pre, c.upsample_initial_channel, 7, 1, bx, ACT_NONE, 0.f, ACT_NONE,
-             nullptr, nullptr, 0.f));
-  int T = Fr, C = c.upsample_initial_channel;
-  for (int i = 0; i < c.n_up; ++i) {
-    const int st = c.upsample_rates[i], Co = C / 2;
-    // leaky_relu(0.1) -> ConvTranspose1d as a 3-tap polyphase conv with N = st*Co: row q of the
-    // [T, st*Co] result is rows q*st .. q*st+st-1 of the [T*st, Co] signal.
-    GemmArgs a;
-    a.A = bx; a.lda = C; a.W = v->ups[i].w; a.bias = v->ups[i].b; a.C = bs; a.ldc = st * Co;
-    a.M = T; a.N = st * Co; a.Cin = C; a.taps = 3; a.dil = 1; a.stride = 1; a.pad = 1; a.in_len = T;
-    a.in_act = ACT_LRELU; a.in_slope = 0.1f;
-    a.algo_flops = 2.0 * T * C * Co * c.upsample_kernel_sizes[i];   // zero-padded polyphase slots are not work
-    RET(launch_conv_gemm(a, s));
-    T *= st; C = Co;
-    for (int j = 0; j < c.n_res; ++j) {
-      const int kr = c.resblock_kernel_sizes[j];
-      for (int dd = 0; dd < 3; ++dd) {
-        const int idx = (i * c.n_res + j) * 3 + dd;
-        const float* rin = dd == 0 ? bs : br;
-        RET(conv1d(s, rin, T, C, v->rb_c1[idx], C, kr, c.resblock_dilations[j][dd], bt, ACT_LRELU, 0.1f, ACT_NONE,
-                   nullptr, nullptr, 0.f));
-        if (dd < 2) {
-          RET(conv1d(s, bt, T, C, v->rb_c2[idx], C, kr, 1, br, ACT_LRELU, 0.1f, ACT_NONE, rin, nullptr, 0.f));
-        } else {
-          // last conv of the resblock also folds the MRF sum: xs (+)= resblock_j(x); x = xs / n_res
-          const float* R2 = j == 0 ? nullptr : bx;
-          const float div = (j == c.n_res - 1) ? (float)c.n_res : 0.f;
-          RET(conv1d(s, bt, T, C, v->rb_c2[idx], C, kr, 1, bx, ACT_LRELU, 0.1f, ACT_NONE, rin, R2, div));
-        }
-      }
-    }
-  }
+  int T = 1, C = 0;
+  RET(hifigan_stack(v, [&](GemmArgs& a, int scale) { a.M = Fr * scale; a.in_len = Fr * scale; return launch_conv_gemm(a, s); },
+                    [](int) { return SS_OK; }, frames, Fr, gb, &T, &C));
+  T *= Fr;
+  float* bx = gb.bx;
   // leaky_relu (default slope 0.01, hifigan.py:166) -> conv_post -> tanh
   return launch_conv_post_tanh(bx, T, C, v->post.w, v->post.b, 0.01f, d_wav, s);
 }
@@ -1067,12 +1121,16 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
     int T = Ft, C = c.upsample_initial_channel;
     for (int i = 0; i < c.n_up; ++i) { T *= c.upsample_rates[i]; C /= 2; stage_max = std::max(stage_max, (size_t)T * C); }
   }
-  RET(v->ws.ensure((4 * stage_max + (size_t)Ft * E) * sizeof(float)));
+  RET(v->ws.ensure((7 * stage_max + (size_t)Ft * E) * sizeof(float)));
   float* frames = v->ws.f();
-  float* bx = frames + (size_t)Ft * E;
-  float* bt = bx + stage_max;
-  float* br = bt + stage_max;
-  float* bs = br + stage_max;
+  GenBufs gb;
+  gb.bx = frames + (size_t)Ft * E;
+  gb.bt = gb.bx + stage_max;
+  gb.br = gb.bt + stage_max;
+  gb.bs = gb.br + stage_max;
+  gb.bxa = gb.bs + stage_max;
+  gb.bra = gb.bxa + stage_max;
+  gb.bsa = gb.bra + stage_max;
   // frame-axis tables, rebuilt per stage (rows scale by the running hop)
   int* dseg = dk + 6 * B;            // conv segs [B][4]
   int* drep = dseg + 4 * B;          // repeat_rows segs [B][4]
@@ -1088,42 +1146,14 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
     RET(upload(s, drep, t));
   }
   RET(launch_repeat_rows(emb, cum, 0, E, frames, of.mx, s, drep, B));
-  auto conv = [&](const float* A, int Trows, int maxrows, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc,
-                  int ldc, int in_act, float slope, const float* R, const float* R2, float div, double flops) {
-    GemmArgs a;
-    a.A = A; a.lda = Cin; a.W = cw.w; a.bias = cw.b; a.C = Cc; a.ldc = ldc; a.R = R; a.ldr = ldc; a.R2 = R2; a.ldr2 = ldc;
-    a.N = Cout; a.Cin = Cin; a.taps = k; a.dil = dil; a.pad = dil * (k - 1) / 2; a.in_act = in_act; a.in_slope = slope;
-    a.div = div; a.segs = dseg; a.nseg = B; a.max_seg_out = maxrows; a.M = Trows; a.in_len = Trows; a.algo_flops = flops;
-    return launch_conv_gemm(a, s);
-  };
-  RET(stage_segs(1));
-  RET(conv(frames, Ft, of.mx, c.model_in_dim, v->pre, c.upsample_initial_channel, 7, 1, bx, c.upsample_initial_channel,
-           ACT_NONE, 0.f, nullptr, nullptr, 0.f, 0.0));
-  int scale = 1, C = c.upsample_initial_channel;
-  for (int i = 0; i < c.n_up; ++i) {
-    const int st = c.upsample_rates[i], Co = C / 2;
-    RET(conv(bx, Ft * scale, of.mx * scale, C, v->ups[i], st * Co, 3, 1, bs, st * Co, ACT_LRELU, 0.1f, nullptr, nullptr,
-             0.f, 2.0 * Ft * scale * C * Co * c.upsample_kernel_sizes[i]));
-    scale *= st; C = Co;
-    RET(stage_segs(scale));
-    const int T = Ft * scale, mxr = of.mx * scale;
-    for (int j = 0; j < c.n_res; ++j) {
-      const int kr = c.resblock_kernel_sizes[j];
-      for (int dd = 0; dd < 3; ++dd) {
-        const int idx = (i * c.n_res + j) * 3 + dd;
-        const float* rin = dd == 0 ? bs : br;
-        RET(conv(rin, T, mxr, C, v->rb_c1[idx], C, kr, c.resblock_dilations[j][dd], bt, C, ACT_LRELU, 0.1f, nullptr,
-                 nullptr, 0.f, 0.0));
-        if (dd < 2) {
-          RET(conv(bt, T, mxr, C, v->rb_c2[idx], C, kr, 1, br, C, ACT_LRELU, 0.1f, rin, nullptr, 0.f, 0.0));
-        } else {
-          const float* R2 = j == 0 ? nullptr : bx;
-          const float div = (j == c.n_res - 1) ? (float)c.n_res : 0.f;
-          RET(conv(bt, T, mxr, C, v->rb_c2[idx], C, kr, 1, bx, C, ACT_LRELU, 0.1f, rin, R2, div, 0.0));
-        }
-      }
-    }
-  }
+  int scale = 1, C = 0;
+  RET(hifigan_stack(v,
+                    [&](GemmArgs& a, int sc) {
+                      a.segs = dseg; a.nseg = B; a.max_seg_out = of.mx * sc; a.M = Ft * sc; a.in_len = Ft * sc;
+                      return launch_conv_gemm(a, s);
+                    },
+                    stage_segs, frames, Ft, gb, &scale, &C));
+  float* bx = gb.bx;
   {
     std::vector<int> t(2 * B);
     for (int b = 0; b < B; ++b) { t[2 * b] = of.off[b] * scale; t[2 * b + 1] = Fr[b] * scale; }
@@ -1143,6 +1173,7 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
   a.A = dA; a.lda = lda; a.W = dW; a.bias = dbias; a.R = dR; a.ldr = ldr; a.R2 = dR2; a.ldr2 = ldr2; a.C = dC; a.ldc = ldc;
   a.M = M; a.N = N; a.Cin = Cin; a.taps = taps; a.dil = dil; a.stride = stride; a.pad = pad; a.in_len = in_len;
   a.chunk = chunk; a.in_act = in_act; a.in_slope = in_slope; a.act = act; a.alpha = alpha; a.div = div; a.glu = glu;
+  a.same_rows = (stride == 1 && M == in_len) ? 1 : 0;
   return launch_conv_gemm(a, (hipStream_t)stream);
 }
 
@@ -1179,3 +1210,4 @@ extern "C" int ss_prof_num_classes(void) { return kNumTileCfg; }
 extern "C" const char* ss_prof_class_name(int cls) { return prof_cfg_name(cls); }
 
 extern "C" int ss_debug_force_tile(int bm, int bn, int ks) { debug_force_tile(bm, bn, ks); return SS_OK; }
+extern "C" int ss_debug_sk_errors(void) { return conv_sk_error_count(); }

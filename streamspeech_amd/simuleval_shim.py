@@ -12,7 +12,7 @@ from inspect import signature
 from typing import List, Optional, Union
 
 try:  # pragma: no cover - depends on the environment
-    from simuleval.agents import SpeechToSpeechAgent  # type: ignore
+    from simuleval.agents import SpeechToSpeechAgent, SpeechToTextAgent  # type: ignore
     from simuleval.agents.actions import Action, ReadAction, WriteAction  # type: ignore
     from simuleval.agents.states import AgentStates  # type: ignore
     from simuleval.data.segments import EmptySegment, Segment, SpeechSegment, TextSegment  # type: ignore
@@ -169,6 +169,10 @@ except Exception:  # noqa: BLE001
     class SpeechToSpeechAgent(GenericAgent):
         source_type = "speech"
         target_type = "speech"
+
+    class SpeechToTextAgent(GenericAgent):
+        source_type = "speech"
+        target_type = "text"
 
     EVALUATION_SYSTEM_LIST = []
 

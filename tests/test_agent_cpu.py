@@ -94,3 +94,40 @@ def test_whole_word_mode_runs(synth_weights):
     assert agent.whole_word and model.encoder.chunk_size == 16 and model.encoder._conv_chunk() == 16
     wav, actions = stream(agent, synth.synth_pcm(4, 16000 * 2), segment_ms=640)
     assert "W" in actions and len(wav) % 320 == 0 and np.isfinite(wav).all()
+
+
+def _stream_text(agent, pcm, segment_ms=320, sr=16000):
+    step = sr * segment_ms // 1000
+    out, pos = [], 0
+    while True:
+        chunk = pcm[pos:pos + step]
+        pos += step
+        finished = pos >= len(pcm)
+        seg = agent.pushpop(SpeechSegment(content=chunk.tolist(), sample_rate=sr, finished=finished))
+        if not seg.is_empty:
+            out.append(seg.content)
+        if finished:
+            return out
+
+
+def test_asr_and_s2tt_agents_are_prefixes_of_the_s2st_path(synth_weights):
+    """agent/speech_to_text.{asr,s2tt}.streamspeech.agent.py surface over the same engine."""
+    from streamspeech_amd.agent_text import StreamSpeechASRAgent, StreamSpeechS2TTAgent
+    cfg, vcfg, sd, vsd = synth_weights
+    eng = OracleEngine(sd, cfg)
+    pcm = synth.synth_pcm(3, 16000 * 2)
+    p = argparse.ArgumentParser()
+    StreamSpeechASRAgent.add_args(p)
+    a = p.parse_args(["--model-path", "synthetic:0", "--data-bin", "/nonexistent", "--sample-rate", "16000"])
+    a.source_segment_size, a.device = 320, "gpu"
+    asr = StreamSpeechASRAgent(a, model=StreamSpeechModel.from_engine(eng))
+    words = _stream_text(asr, pcm)
+    assert len(words) >= 1 and all(isinstance(w, str) for w in words)
+    # fed as ONE finished segment the agent emits the offline CTC transcript of the whole utterance
+    whole = _stream_text(asr, pcm, segment_ms=2000)
+    fb = asr.feature_extractor.__class__(a, eng)(pcm.tolist())
+    toks = eng.ctc_greedy(0, eng.encoder_forward(fb, 320 // 40, 8))[0]
+    assert "".join(whole) == " ".join(asr.dict["source_unigram"][int(c)] for c in toks)
+    s2tt = StreamSpeechS2TTAgent(a, model=StreamSpeechModel.from_engine(eng))
+    outs = _stream_text(s2tt, pcm)
+    assert len(outs) >= 1 and all(isinstance(w, str) for w in outs)

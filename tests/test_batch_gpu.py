@@ -92,3 +92,28 @@ def test_batch_vocoder_forced_durations_vs_oracle(hip_vocoder, synth_weights):
         assert wavs[b].numel() == rw.numel()
         rms = float(torch.sqrt(torch.mean((wavs[b].cpu() - rw) ** 2)))
         assert rms < 1e-3, f"rms {rms}"
+
+
+def test_batch_vocoder_on_stream_k_kernels_vs_oracle(hip_vocoder, synth_weights):
+    """Same ragged batch with every eligible conv forced through the persistent stream-K kernel
+    (segment edges inside 128-row tiles, tiles shared by several workgroups)."""
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import lib as L, synth
+    lib = L.load()
+    _, vcfg, _, vsd = synth_weights
+    codes = [[int(c) for c in synth.uniform(5, f"bv/{i}", (k,), 0, 1000)] for i, k in enumerate((30, 7, 55, 1))]
+    durs = [[1 + (j % 3 == 2) for j in range(len(c))] for c in codes]
+    lib.ss_debug_force_tile(1, 0, 0)
+    try:
+        wavs, dur, K = hip_vocoder.batch_forward(codes, True, forced_dur=durs)
+        single, _ = hip_vocoder.forward(torch.tensor(codes[2], dtype=torch.int32, device="cuda:0"), True,
+                                        forced_dur=torch.tensor(durs[2], dtype=torch.int32, device="cuda:0"))
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)
+    assert lib.ss_debug_sk_errors() == 0
+    for b in range(4):
+        rw, rd = O.vocoder_forward(vsd, codes[b], vcfg, True, forced_dur=durs[b])
+        assert wavs[b].numel() == rw.numel()
+        rms = float(torch.sqrt(torch.mean((wavs[b].cpu() - rw) ** 2)))
+        assert rms < 1e-3, f"utt {b}: rms {rms}"
+    assert float(torch.sqrt(torch.mean((single.cpu() - wavs[2].cpu()) ** 2))) < 1e-5

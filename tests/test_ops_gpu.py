@@ -213,3 +213,39 @@ def test_dwconv_bn_silu(lib, T, chunk):
                                      chunk), "dw")
     torch.cuda.synchronize()
     assert (out.cpu() - ref).abs().max() < 2e-5
+
+
+# ---- persistent stream-K conv kernel (conv_sk.hip) ----------------------------------------------
+def _conv_ref(A, W, b, taps, dil, slope=None):
+    x = A if slope is None else F.leaky_relu(A, slope)
+    N, Cin = W.shape[0], A.shape[1]
+    return F.conv1d(x.t()[None], W.view(N, Cin, taps), b, dilation=dil, padding=dil * (taps - 1) // 2)[0].t()
+
+
+@pytest.mark.parametrize("M,N,Cin,taps,dil,G", [
+    (1000, 256, 256, 11, 5, 0), (1000, 256, 256, 11, 5, 37), (1000, 256, 256, 3, 1, 512), (777, 128, 128, 7, 3, 200),
+    (5001, 64, 64, 11, 1, 0), (5001, 64, 64, 3, 5, 97), (300, 1280, 512, 3, 1, 0), (129, 128, 64, 1, 1, 3),
+    (40, 64, 32, 1, 1, 1)])
+def test_stream_k_conv_matches_torch(lib, M, N, Cin, taps, dil, G):
+    """Every fix-up shape: tiles split over 2..many workgroups, ranges inside one tile, G = 1 (no split),
+    ragged last M tile; leaky-ReLU input, bias, both residuals and the MRF division in the epilogue."""
+    from streamspeech_amd.weights import conv_tap_major
+    A = rnd(M, Cin, seed=11)
+    W = rnd(N, Cin, taps, seed=12, scale=(Cin * taps) ** -0.5)
+    b, R, R2 = rnd(N, seed=13, scale=0.1), rnd(M, N, seed=14), rnd(M, N, seed=15)
+    Wp = conv_tap_major(W) if taps > 1 else W.view(N, Cin)
+    lib.ss_debug_force_tile(1, 0, G)
+    try:
+        got = run_conv_gemm(lib, A, Wp, b, M, N, Cin, taps=taps, dil=dil, pad=dil * (taps - 1) // 2, in_act=3, slope=0.1,
+                            div=3.0, R=R, R2=R2)
+        got2 = run_conv_gemm(lib, A, Wp, b, M, N, Cin, taps=taps, dil=dil, pad=dil * (taps - 1) // 2, in_act=3, slope=0.1,
+                             div=3.0, R=R, R2=R2)
+        plain = run_conv_gemm(lib, A, Wp, None, M, N, Cin, taps=taps, dil=dil, pad=dil * (taps - 1) // 2)
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)
+    assert lib.ss_debug_sk_errors() == 0
+    ref = (R2 + (_conv_ref(A, W.reshape(N, -1) if taps == 1 else W, b, taps, dil, 0.1) + R)) / 3.0
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() < TOL, f"max err {(got - ref).abs().max()}"
+    assert torch.equal(got, got2), "stream-K must be deterministic run to run"
+    assert (plain - _conv_ref(A, W.reshape(N, -1) if taps == 1 else W, None, taps, dil)).abs().max() < TOL

@@ -213,3 +213,30 @@ def test_streaming_agent_matches_oracle_agent(hip_model, hip_vocoder, synth_weig
     assert w_hip.shape == w_ora.shape
     rms = float(np.sqrt(np.mean((w_hip - w_ora) ** 2)))
     assert rms < WAV_RMS_TOL, f"rms {rms}"
+
+
+@pytest.mark.parametrize("kind", ["asr", "s2tt"])
+def test_text_agents_match_oracle_agents(hip_model, synth_weights, kind):
+    """§8f-2: streaming-ASR / simultaneous-S2TT agents (agent/speech_to_text.{asr,s2tt}.streamspeech.agent.py)
+    over the HIP engine emit exactly the text increments of the same agent over the CPU oracle."""
+    import argparse
+    from streamspeech_amd import synth
+    from streamspeech_amd.agent_text import StreamSpeechASRAgent, StreamSpeechS2TTAgent
+    from streamspeech_amd.modules import StreamSpeechModel
+    from tests.oracle_engine import OracleEngine
+    from tests.test_agent_cpu import _stream_text
+    cfg, vcfg, sd, vsd = synth_weights
+    cls = StreamSpeechASRAgent if kind == "asr" else StreamSpeechS2TTAgent
+
+    def mk(engine):
+        p = argparse.ArgumentParser()
+        cls.add_args(p)
+        a = p.parse_args(["--model-path", "synthetic:0", "--data-bin", "/nonexistent", "--sample-rate", "16000"])
+        a.source_segment_size, a.device = 320, "gpu"
+        return cls(a, model=StreamSpeechModel.from_engine(engine))
+
+    ora = OracleEngine(sd, cfg)
+    ora.fbank_cmvn = lambda pcm, scale=32768.0: hip_model.fbank_cmvn(pcm.to(hip_model.device), scale).cpu()
+    pcm = synth.synth_pcm(23, int(16000 * 2.9))
+    got, want = _stream_text(mk(hip_model), pcm), _stream_text(mk(ora), pcm)
+    assert got == want and len(got) >= 1

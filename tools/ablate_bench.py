@@ -22,6 +22,22 @@ def bench(M, N, Cin, taps, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / reps
 
+if len(sys.argv) > 1 and sys.argv[1] == "sk":
+    # stream-K kernel: 1 no glds in the loop, 2 no ds_read/MFMA, 8 no waitcnt/barrier, 16 no fix-up, 32 no fix-up/epilogue
+    shapes = [("stage0 k11", 18000, 256, 256, 11), ("stage0 k3", 18000, 256, 256, 3), ("stage2 k11", 288000, 64, 64, 11),
+              ("unit fc2", 6800, 512, 2048, 1)]
+    masks = [0, 1, 2, 8, 16, 32, 1 | 8, 1 | 8 | 32, 2 | 32, 1 | 2 | 8 | 32]
+    print("%-12s %-6s" % ("shape", "G") + "".join("%9s" % f"m{m}" for m in masks))
+    for name, M, N, Cin, taps in shapes:
+        for G in (0, 256):
+            lib.ss_debug_force_tile(1, 0, G)
+            line = "%-12s %-6d" % (name, G)
+            for m in masks:
+                lib.ss_debug_set_ablate(m)
+                line += "%9.1f" % bench(M, N, Cin, taps, reps=5)
+            print(line, flush=True)
+    sys.exit(0)
+
 shapes = [("stage2 k11", 288000, 64, 64, 11), ("stage0 k11", 18000, 256, 256, 11), ("unit fc2", 6800, 512, 2048, 1)]
 tiles = [(64, 64, 11), (32, 64, 11)]
 masks = [0, 1, 2, 4, 8, 1 | 4, 1 | 4 | 8, 2 | 4 | 8, 1 | 2, 1 | 2 | 4 | 8]

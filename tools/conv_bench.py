@@ -75,7 +75,32 @@ def sweep_big():
     lib.ss_debug_force_tile(0, 0, 0)
 
 
+def sweep_sk():
+    """persistent stream-K kernel (force code bm=1, ks = grid) against the 32x64 kernel, batch and
+    single-utterance scale."""
+    shapes = [("stage0 k11 b32", 36000, 256, 256, 11), ("stage0 k11 b16", 18000, 256, 256, 11), ("stage0 k3 b16", 18000, 256, 256, 3),
+              ("stage1 k11 b16", 72000, 128, 128, 11), ("stage1 k3 b16", 72000, 128, 128, 3), ("stage2 k11 b16", 288000, 64, 64, 11),
+              ("stage2 k3 b16", 288000, 64, 64, 3), ("up0 b16", 3600, 1280, 512, 3), ("up1 b16", 18000, 512, 256, 3),
+              ("up2 b16", 72000, 256, 128, 3), ("stage0 k11 b4", 4500, 256, 256, 11), ("stage0 k11 b1", 1125, 256, 256, 11),
+              ("stage1 k7 b1", 4500, 128, 128, 7), ("stage2 k3 b1", 18000, 64, 64, 3), ("up0 b1", 225, 1280, 512, 3),
+              ("unit fc1 b16", 6800, 2048, 512, 1), ("unit fc2 b16", 6800, 512, 2048, 1)]
+    cfgs = [("heur", 0, 0, 0), ("32x64", 32, 64, 11), ("sk auto", 1, 0, 0), ("sk 256", 1, 0, 256), ("sk 384", 1, 0, 384)]
+    print("%-16s" % "shape" + "".join("%10s" % c[0] for c in cfgs) + "   GFLOP   best TF")
+    for name, M, N, Cin, taps in shapes:
+        line, best = "%-16s" % name, 1e9
+        for _, bm, bn, ks in cfgs:
+            lib.ss_debug_force_tile(bm, bn, ks)
+            r = bench(name, M, N, Cin, taps, 1, reps=5)
+            line += "%10.1f" % r["us"]
+            best = min(best, r["us"])
+        print(line + "   %6.2f  %6.1f" % (r["gflop"], r["gflop"] / best * 1e3), flush=True)
+    lib.ss_debug_force_tile(0, 0, 0)
+    print("sk errors:", lib.ss_debug_sk_errors())
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "sk":
+        return sweep_sk()
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         return sweep()
     if len(sys.argv) > 1 and sys.argv[1] == "sweep_big":
