@@ -157,7 +157,11 @@ def main():
 
     K, Wn = args.steps, args.warmup
     all_utts = workload.make_utterances((K + Wn) * world)
-    mine = dp.shard(all_utts, rank, world)                  # weak scaling: K + W utterances per rank
+    # weak scaling: K + W utterances per rank.  The timed set is length-sorted before the round-robin
+    # deal, so every rank gets the same number of utterances AND ~the same audio seconds.
+    warm_all, timed_all = all_utts[:Wn * world], all_utts[Wn * world:]
+    timed_all = sorted(timed_all, key=lambda u: -u.seconds)
+    mine = dp.shard(warm_all, rank, world) + dp.shard(timed_all, rank, world)
     pcms = [torch.from_numpy(synth.synth_pcm(1234 + u.idx, u.n_samples)).to(dev) for u in mine]
     torch.cuda.synchronize()
 
@@ -192,11 +196,12 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nlat = 1 if args.no_latency_pass else min(K, 8)
-    for u, p in zip(mine[Wn:Wn + nlat], pcms[Wn:Wn + nlat]):
-        run_utterance(model, voc, p, u)
+    lat_idx = list(range(Wn, Wn + K))[::max(1, K // nlat)][:nlat]   # evenly spread over the length-sorted timed set
+    for i in lat_idx:
+        run_utterance(model, voc, pcms[i], mine[i])
     torch.cuda.synchronize()
     single_ms = 1e3 * (time.perf_counter() - t0) / nlat
-    single_rtfx = sum(u.seconds for u in mine[Wn:Wn + nlat]) / (single_ms * 1e-3 * nlat)
+    single_rtfx = sum(mine[i].seconds for i in lat_idx) / (single_ms * 1e-3 * nlat)
 
     # S concurrent utterance streams: worker threads (ctypes releases the GIL inside the C ABI),
     # each with its own HIP stream and its own scratch/KV-cache context over the shared weights

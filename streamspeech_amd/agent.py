@@ -31,6 +31,25 @@ def _detok(symbols):
     return text[1:] if len(text) > 0 and text[0] == " " else text
 
 
+def synthesize_tail(vocoder, unit, n_new, dur_prediction, ctx=0, rf=None):
+    """Speech of the last ``n_new`` units of ``unit`` (agent :743-753: vocoder over all units, keep
+    ``wav[-dur[-n_new:].sum()*320:]``).  With ``ctx`` > 0 only the last ``n_new + ctx`` units are
+    synthesised: identical tail, because the frames further left than the
+    generator's receptive field ``rf`` cannot reach it.  Returns (tail, wav of what was synthesised)."""
+    wav = dur = None
+    if ctx > 0 and len(unit) > n_new + ctx:
+        x = {"code": torch.tensor(unit[-(n_new + ctx):], dtype=torch.long).view(1, -1)}
+        wav, dur = vocoder(x, dur_prediction)
+        # frames left of the new units whose durations are exact (the 2 left-most context units see a
+        # truncated duration-predictor window) must cover the generator's receptive field
+        if int(dur[:, 2:ctx].sum()) < rf + 2:
+            wav = None
+    if wav is None:
+        x = {"code": torch.tensor(unit, dtype=torch.long).view(1, -1)}
+        wav, dur = vocoder(x, dur_prediction)
+    return wav[-int(dur[:, -n_new:].sum()) * 320:], wav
+
+
 @entrypoint
 class StreamSpeechS2STAgent(SpeechToSpeechAgent):
     """Simultaneous speech-to-speech translation agent for StreamSpeech on the HIP backend."""
@@ -66,6 +85,15 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
                     vcfg = json.load(f)
             self.vocoder = CodeHiFiGANVocoderWithDur(args.vocoder, vcfg, device=self.device)
         self.dur_prediction = args.dur_prediction
+        # Incremental synthesis: the reference re-synthesises ALL units at every write
+        # and keeps the tail (agent :743-753).  The generator has a finite receptive field, so the same
+        # tail comes out of the last (new + context) units only; context = receptive field + the +-2
+        # units the duration predictor looks at + slack.  0 restores the full re-synthesis.
+        vcfg = getattr(getattr(self.vocoder, "hip", self.vocoder), "cfg", None)
+        rf = vcfg.receptive_field_frames() if vcfg is not None and hasattr(vcfg, "receptive_field_frames") else None
+        want = getattr(args, "vocoder_context_units", -1)
+        self.vocoder_rf = rf
+        self.vocoder_ctx = 0 if (rf is None or want == 0) else (want if want > 0 else rf + 8)
         self.lagging_k1, self.lagging_k2 = args.lagging_k1, args.lagging_k2
         self.segment_size = args.segment_size
         self.stride_n, self.stride_n2 = args.stride_n, args.stride_n2
@@ -108,6 +136,8 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
         a("--stride-n", type=int, default=1, help="lagging number")
         a("--stride-n2", type=int, default=1, help="lagging number")
         a("--unit-per-subword", type=int, default=15, help="lagging number")
+        a("--vocoder-context-units", type=int, default=-1,
+          help="left-context units re-synthesised with each new unit tail (-1: receptive field + 8, 0: all units like the reference)")
         a("--extra-output-dir", type=str, default=None, help="extra output dir")
         a("--output-asr-translation", type=bool, default=False, help="extra output dir")
 
@@ -316,10 +346,8 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
             return self._finish_empty()
 
         # 4. vocoder over ALL units so far; emit the tail that belongs to the new units (agent :743-753)
-        x = {"code": torch.tensor(unit, dtype=torch.long).view(1, -1)}
-        wav, dur = self.vocoder(x, self.dur_prediction)
-        cur_wav_length = int(dur[:, -len(cur_unit):].sum()) * 320
-        new_wav = wav[-cur_wav_length:]
+        new_wav, wav = synthesize_tail(self.vocoder, unit, len(cur_unit), self.dur_prediction, self.vocoder_ctx,
+                                       self.vocoder_rf)
         if self.unfinished_wav is not None and len(self.unfinished_wav) > 0:
             new_wav = torch.cat((self.unfinished_wav, new_wav), dim=0)
         self.wav = wav

@@ -69,6 +69,18 @@ class VocoderConfig:
     def channels(self, stage: int) -> int:
         return self.upsample_initial_channel // (2 ** (stage + 1))
 
+    def receptive_field_frames(self) -> int:
+        """One-sided receptive field of the generator in input frames (hifigan.py:154-170): how many
+        frames to the left of frame f can influence the samples of frame f.  Walked from the output
+        back to the input: conv_post k7, per stage the widest resblock (sum over its dilated conv1 +
+        plain conv2 pairs), the transposed conv (a 3-tap polyphase filter on the stage input), conv_pre k7."""
+        r = 3
+        for i in reversed(range(len(self.upsample_rates))):
+            r += max(sum((k - 1) // 2 * (d + 1) for d in dil)
+                     for k, dil in zip(self.resblock_kernel_sizes, self.resblock_dilation_sizes))
+            r = -(-r // self.upsample_rates[i]) + 1
+        return r + 3
+
     def as_dict(self):
         """The JSON the reference ``CodeHiFiGANVocoderWithDur`` is constructed from."""
         return {

@@ -66,9 +66,12 @@ class OracleEngine:
 class OracleVocoder:
     def __init__(self, vsd, vcfg):
         self.vsd, self.vcfg = O.SD(vsd), vcfg
+        self.cfg = vcfg
+        self.call_lengths = []
 
     def __call__(self, x, dur_prediction=False):
         code = x["code"]
         code = code[code >= 0].view(-1).tolist()
+        self.call_lengths.append(len(code))
         wav, dur = O.vocoder_forward(self.vsd, code, self.vcfg, dur_prediction)
         return wav, dur.view(1, -1)

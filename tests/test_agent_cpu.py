@@ -131,3 +131,25 @@ def test_asr_and_s2tt_agents_are_prefixes_of_the_s2st_path(synth_weights):
     s2tt = StreamSpeechS2TTAgent(a, model=StreamSpeechModel.from_engine(eng))
     outs = _stream_text(s2tt, pcm)
     assert len(outs) >= 1 and all(isinstance(w, str) for w in outs)
+
+
+def test_incremental_vocoder_tail_equals_full_resynthesis(synth_weights):
+    """§8f-1: synthesising only the last (new + receptive-field context) units emits the same speech as
+    the reference's re-synthesis of all units at every write (agent :743-753)."""
+    from streamspeech_amd.agent import synthesize_tail
+    cfg, vcfg, sd, vsd = synth_weights
+    rf = vcfg.receptive_field_frames()
+    assert rf == 21
+    units = [int(u) for u in synth.uniform(3, "inc_units", (140,), 0, 1000)]
+    for dur_pred in (True, False):
+        voc = OracleVocoder(vsd, vcfg)
+        for upto, n_new in ((60, 7), (61, 1), (100, 30), (140, 12)):
+            full, _ = synthesize_tail(voc, units[:upto], n_new, dur_pred, 0, rf)
+            n_full = voc.call_lengths[-1]
+            inc, _ = synthesize_tail(voc, units[:upto], n_new, dur_pred, rf + 8, rf)
+            assert inc.shape == full.shape and inc.numel() > 0
+            assert float(torch.sqrt(torch.mean((inc - full) ** 2))) < 1e-6
+            assert voc.call_lengths[-1] == min(n_full, n_new + rf + 8)
+        # a context shorter than the receptive field is detected and falls back to the full pass
+        inc, _ = synthesize_tail(voc, units[:100], 5, False, 10, rf)
+        assert voc.call_lengths[-1] == 100

@@ -240,3 +240,26 @@ def test_text_agents_match_oracle_agents(hip_model, synth_weights, kind):
     pcm = synth.synth_pcm(23, int(16000 * 2.9))
     got, want = _stream_text(mk(hip_model), pcm), _stream_text(mk(ora), pcm)
     assert got == want and len(got) >= 1
+
+
+def test_incremental_vocoder_tail_on_hip(hip_vocoder, synth_weights):
+    """§8f-1 on the HIP vocoder: tail-only synthesis == tail of the full re-synthesis (RMS <= 1e-5; not
+    bit-exact because tile/stream-K decompositions depend on the row count)."""
+    from streamspeech_amd import synth
+    from streamspeech_amd.agent import synthesize_tail
+    from streamspeech_amd.modules import CodeHiFiGANVocoderWithDur
+    _, vcfg, _, _ = synth_weights
+
+    class HipVocSurface:
+        def __init__(self, hv):
+            self.hip = hv
+        __call__ = CodeHiFiGANVocoderWithDur.__call__
+
+    voc, rf = HipVocSurface(hip_vocoder), vcfg.receptive_field_frames()
+    units = [int(u) for u in synth.uniform(3, "inc_units", (220,), 0, 1000)]
+    for dur_pred in (True, False):
+        for upto, n_new in ((60, 7), (150, 30), (220, 1)):
+            full, _ = synthesize_tail(voc, units[:upto], n_new, dur_pred, 0, rf)
+            inc, _ = synthesize_tail(voc, units[:upto], n_new, dur_pred, rf + 8, rf)
+            assert inc.shape == full.shape and inc.numel() > 0
+            assert float(torch.sqrt(torch.mean((inc - full) ** 2))) < 1e-5
