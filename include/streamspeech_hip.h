@@ -72,6 +72,18 @@ int ss_encoder_out_len(int T);
 int ss_encoder_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
                        int conv_chunk, float* d_enc_out);
 
+/* Incremental twin for streaming (replaces the full recompute of the encoder at
+ * every policy() call, agent :425-435): same inputs and output as ss_encoder_forward for the
+ * fbank of ALL audio received so far, but rows that were final at the previous call (nothing they
+ * can see -- chunk attention, chunk-causal convs -- can still change) are served from the handle's
+ * cache and only the remaining rows go through the conformer layers.  *n_final = rows final after
+ * this call, *n_computed = rows recomputed by this call (either may be NULL).  The cache belongs to
+ * the handle: one utterance at a time, ss_encoder_stream_reset between utterances (the agent's
+ * reset()); a change of chunk sizes or a shorter input resets it implicitly. */
+int ss_encoder_stream_reset(ss_model* m);
+int ss_encoder_stream_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
+                              int conv_chunk, float* d_enc_out, int32_t* n_final, int32_t* n_computed);
+
 /* ---- a8: CTCDecoder.generate (agent/ctc_decoder.py:39-111): head 0 = source_unigram (ASR),
  * 1 = ctc_target_unigram (ST).  Outputs (device int32): raw argmax per frame [Tp], collapsed
  * tokens / frame index [<=Tp], *d_count.  d_logits may be NULL (else [Tp,vocab] is written). */

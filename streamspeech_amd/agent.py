@@ -136,6 +136,8 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
         a("--stride-n", type=int, default=1, help="lagging number")
         a("--stride-n2", type=int, default=1, help="lagging number")
         a("--unit-per-subword", type=int, default=15, help="lagging number")
+        a("--full-recompute-encoder", default=False, action="store_true",
+          help="re-encode all received audio at every policy() call like the reference (default: reuse final rows)")
         a("--vocoder-context-units", type=int, default=-1,
           help="left-context units re-synthesised with each new unit tail (-1: receptive field + 8, 0: all units like the reference)")
         a("--extra-output-dir", type=str, default=None, help="extra output dir")
@@ -156,6 +158,9 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
         self.post_transcription = ""
         self.unfinished_wav = None
         self.states.reset()
+        enc = getattr(getattr(self, "model", None), "encoder", None)
+        if enc is not None and hasattr(enc, "reset_stream"):
+            enc.reset_stream()                     # incremental encoder cache: one utterance at a time
         try:
             self.generator_mt.reset_incremental_states()
             self.ctc_generator.reset_incremental_states()
@@ -193,6 +198,8 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
             conv.chunk_size = conv_chunk
         for layer in model.encoder.conformer_layers:
             layer.conv_module.depthwise_conv.chunk_size = conv_chunk
+        if hasattr(model.encoder, "incremental"):
+            model.encoder.incremental = not getattr(args, "full_recompute_encoder", False)
 
         # dictionaries: target units + the three multitask text dictionaries
         self.dict = {"tgt": Dictionary.units(1000)}

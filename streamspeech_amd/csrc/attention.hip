@@ -39,6 +39,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
   const int i0 = blockIdx.x * QB;
   const int hoff = h * DH;
   const int qoff = p.Tk - p.Tq;
+  const int q0 = p.q0;               // absolute position of query row 0 (chunk mask / relative offsets)
 
   // query rows of this wave in registers: lane d holds element d
   float qu[4], qv[4];
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
   int kmax = p.Tk - p.k_mask_tail;
   const int ilast = min(i0 + QB, p.Tq) - 1;
   if (p.causal) kmax = min(kmax, ilast + qoff + 1);
-  if (p.chunk > 0) kmax = min(kmax, (ilast / p.chunk + 1) * p.chunk);
+  if (p.chunk > 0) kmax = min(kmax, ((ilast + q0) / p.chunk + 1) * p.chunk);
 
   for (int j0 = 0; j0 < kmax; j0 += KT) {
     __syncthreads();  // previous tile fully consumed
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
     }
     if (RELPOS) {
       // local row lr <-> table row pbase + lr, pbase = j0 - (i0 + QB - 1) + Tk - 1
-      const int pbase = j0 - (i0 + QB - 1) + p.Tk - 1;
+      const int pbase = j0 - (i0 + q0 + QB - 1) + p.Tk - 1;
       for (int f = t; f < (KT + QB - 1) * (DH / 4); f += 256) {
         const int row = f >> 4, c4 = (f & 15) * 4;
         const int pr = pbase + row;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnArgs p) {
       const int i = i0 + wave * 4 + rr;
       bool vis = (j < p.Tk - p.k_mask_tail) && (i < p.Tq);
       if (p.causal) vis = vis && (j <= i + qoff);
-      if (p.chunk > 0) vis = vis && (j < (i / p.chunk + 1) * p.chunk);
+      if (p.chunk > 0) vis = vis && (j < ((i + q0) / p.chunk + 1) * p.chunk);
       const float sv = vis ? s[rr] * p.scale : -INFINITY;
       const float mt = wave_max(sv);
       const float mn = fmaxf(m_run[rr], mt);
@@ -230,14 +231,15 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if (tq <= 0 || (a.nseg == 0 && a.Tk <= 0)) return SS_OK;
   if ((a.ldk & 3) || (a.ldv & 3)) return SS_ERR_ARG;
   const int gz = a.nseg > 0 ? a.nseg : 1;
-  if (!a.P && tq <= 8) {
+  if (a.q0 != 0 && (a.nseg > 0 || a.causal)) return SS_ERR_ARG;
+  if (!a.P && tq <= 8 && a.q0 == 0) {
     hipLaunchKernelGGL(attention_decode_kernel, dim3(tq, a.H, gz), dim3(256), 0, stream, a);
     SS_LAUNCH_CHECK();
     return SS_OK;
   }
   dim3 grid(cdiv(tq, QB), a.H, gz);
   if (a.P) {
-    if ((a.nseg == 0 && a.Tq != a.Tk) || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
+    if ((a.nseg == 0 && a.q0 + a.Tq != a.Tk) || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
     if (a.nseg > 0 && a.p_tmax <= 0) return SS_ERR_ARG;
     hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, stream, a);
   } else {

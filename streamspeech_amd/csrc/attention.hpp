@@ -18,8 +18,10 @@ struct AttnArgs {
   float scale = 1.0f;        // scores *= scale
   int causal = 0;            // key j visible iff j <= i + (Tk - Tq)
   int chunk = 0;             // > 0: key j visible iff j < (i/chunk + 1)*chunk
+  int q0 = 0;                // single-utterance rel-pos/chunk form only: query row i is absolute position q0 + i
+                             // (keys are 0..Tk-1); used by the incremental streaming encoder (tail queries over all keys)
   int k_mask_tail = 0;       // the last k_mask_tail keys are padding (fairseq key_padding_mask on trailing <pad>)
-  // rel-pos extras (null => plain attention); requires Tq == Tk
+  // rel-pos extras (null => plain attention); requires q0 + Tq == Tk
   const float* P = nullptr; int ldp = 0;   // projected positional table [2*Tk-1, H*64]
   const float* bias_u = nullptr; const float* bias_v = nullptr;  // [H*64]
   // Ragged batch (nseg > 0): independent utterances packed along the row axis.  segs[4*s] =

@@ -55,9 +55,10 @@ int launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* ga
 __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
     const float* __restrict__ x, int ldx, float* y, int ldy, const float* __restrict__ wt, int K,
     const float* __restrict__ bn_mean, const float* __restrict__ bn_var, const float* __restrict__ bn_gamma,
-    const float* __restrict__ bn_beta, float bn_eps, int T, int C, int chunk, const int* __restrict__ segs) {
+    const float* __restrict__ bn_beta, float bn_eps, int T, int C, int chunk, const int* __restrict__ segs,
+    int t_begin) {
   const int c = blockIdx.x * 256 + threadIdx.x;
-  const int t = blockIdx.y;
+  const int t = blockIdx.y + t_begin;
   if (segs) {   // ragged batch: {row_start, len} per utterance
     const int st = segs[2 * blockIdx.z];
     T = segs[2 * blockIdx.z + 1];
@@ -79,11 +80,11 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
 int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const float* wt, int K,
                           const float* bn_mean, const float* bn_var, const float* bn_gamma,
                           const float* bn_beta, float bn_eps, int T, int C, int chunk, hipStream_t stream,
-                          const int* segs, int nseg) {
-  if (T <= 0) return SS_OK;
-  dim3 grid(cdiv(C, 256), T, nseg > 0 ? nseg : 1);
+                          const int* segs, int nseg, int t_begin) {
+  if (T - t_begin <= 0) return SS_OK;
+  dim3 grid(cdiv(C, 256), T - t_begin, nseg > 0 ? nseg : 1);
   hipLaunchKernelGGL(dwconv_bn_silu_kernel, grid, dim3(256), 0, stream, x, ldx, y, ldy, wt, K, bn_mean,
-                     bn_var, bn_gamma, bn_beta, bn_eps, T, C, chunk, nseg > 0 ? segs : nullptr);
+                     bn_var, bn_gamma, bn_beta, bn_eps, T, C, chunk, nseg > 0 ? segs : nullptr, t_begin);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }

@@ -17,7 +17,8 @@ int launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* ga
 int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const float* wt, int K,
                           const float* bn_mean, const float* bn_var, const float* bn_gamma,
                           const float* bn_beta, float bn_eps, int T, int C, int chunk, hipStream_t stream,
-                          const int* segs = nullptr, int nseg = 0);  // segs {row_start,len}; T = max len
+                          const int* segs = nullptr, int nseg = 0,   // segs {row_start,len}; T = max len
+                          int t_begin = 0);   // single utterance: only rows t_begin..T-1 are computed (rows before are context)
 
 // out[i,:] = scale * emb[tok[i],:] + pos_table[pos0 + i, :]     (MT decoder input embedding,
 // reference ctc_unity/modules/transformer_decoder.py:297-326)

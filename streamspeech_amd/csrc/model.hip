@@ -139,6 +139,12 @@ struct ss_model {
   DevBuf seg_buf;                // ragged-batch segment tables / batched token chain
   DevBuf bmt_self;               // batched MT self-attention cache [layer][B][Lcap][3D]
   int32_t* mt_tok_host = nullptr;  // pinned staging of the same
+  // incremental streaming encoder (ss_encoder_stream_*): per-layer fused q|k|v rows and GLU outputs
+  // of every frame so far + the finished output rows; rows < es_final are final
+  DevBuf es_qkv;        // [layers][es_cap][3d]
+  DevBuf es_glu;        // [layers][es_cap][d]
+  DevBuf es_out;        // [es_cap][d]
+  int es_cap = 0, es_final = 0, es_achunk = -1, es_cchunk = -1;
 };
 
 static int load_dec_layers(ss_model* m, std::vector<DecLayer>& v, const std::string& pfx, int n, int D, int F,
@@ -261,6 +267,7 @@ extern "C" void ss_model_destroy(ss_model* m) {
   if (!m) return;
   m->pos_proj.release(); m->ws.release(); m->mt_cross.release(); m->mt_self.release(); m->mt_ws.release();
   m->mt_tok.release(); m->seg_buf.release(); m->bmt_self.release();
+  m->es_qkv.release(); m->es_glu.release(); m->es_out.release();
   if (m->mt_tok_host) (void)hipHostFree(m->mt_tok_host);
   delete m;
 }
@@ -346,6 +353,150 @@ extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fban
     RET(linear(s, ff, f, T2, e.ffn2_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
     RET(layernorm(s, x, x, e.final_ln, T2, d));
   }
+  return SS_OK;
+}
+
+
+// ---- incremental streaming encoder -------------------------------------------
+// The reference re-runs the whole encoder on all audio received so far at every policy() call
+// (agent/speech_to_speech.streamspeech.agent.py:425-435).  With chunk attention and chunk-causal
+// convs a frame cannot see anything beyond the end of its chunk, so once the input that a chunk
+// can reach has arrived its rows are FINAL: later calls reproduce them exactly.  This entry point
+// keeps, per layer, the q|k|v rows and the conv-module GLU rows of every frame (the only things a
+// later frame reads from an earlier one) plus the finished output rows, and runs the 12 conformer
+// layers only on the rows that are not final yet.  The subsampler (6 % of the encoder FLOPs) is
+// re-run in full: its chunk grid is in fbank-frame coordinates and re-running it keeps the code
+// path identical.  Output == ss_encoder_forward on the same fbank up to GEMM summation order
+// (tile / split-K choices depend on the row count).
+//
+// Finality: a frame i of the 40-ms grid reaches, in one layer, keys up to the end of its attention
+// chunk and conv taps up to min(i+15, end of its conv chunk); through the subsampler it reaches
+// conv1 rows a(i) = min(2i+2, chunk end) and fbank rows b(a(i)).  The final prefix [0, n) is the
+// largest one that is closed under "reaches" and whose subsampler inputs all exist.
+static int stream_final_rows(int T, int T1, int T2, int k, int achunk, int cchunk, int dwk) {
+  if (achunk <= 0) return 0;                       // full attention: every frame sees the future
+  auto reach = [&](int i, int half, int stride) {  // last input row a stride-`stride` conv output i can read
+    int r = i * stride + half;
+    if (cchunk > 0) r = std::min(r, ((i * stride) / cchunk + 1) * cchunk - 1);
+    return r;
+  };
+  int n = 0;
+  for (int i = 0; i < T2; ++i) {                   // subsampler level: frames whose whole cone exists
+    const int a = reach(i, k / 2, 2);
+    if (a > T1 - 1) break;
+    if (reach(a, k / 2, 2) > T - 1) break;
+    n = i + 1;
+  }
+  while (n > 0) {                                  // closure under one layer's reach (monotone in i)
+    const int i = n - 1;
+    const int e_att = (i / achunk + 1) * achunk - 1;
+    const int e_conv = reach(i, dwk / 2, 1);
+    if (std::max(e_att, e_conv) <= n - 1) break;
+    --n;
+  }
+  return n;
+}
+
+extern "C" int ss_encoder_stream_reset(ss_model* m) {
+  if (!m) return SS_ERR_ARG;
+  m->es_final = 0; m->es_achunk = -1; m->es_cchunk = -1;
+  return SS_OK;
+}
+
+extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
+                                         int conv_chunk, float* d_enc_out, int32_t* n_final, int32_t* n_computed) {
+  if (!m || T <= 0) return SS_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  const ss_config& c = m->cfg;
+  const int d = c.enc_dim, f = c.enc_ffn, k = c.conv_kernel, Ld = c.enc_layers * d, L = c.enc_layers;
+  const int T1 = conv_out_len(T, k, 2), T2 = conv_out_len(T1, k, 2);
+  if (T2 <= 0 || T2 > c.max_rel_pos) return SS_ERR_CAPACITY;
+  const int cchunk = (conv_chunk > 0 && conv_chunk < 999) ? conv_chunk : 0;
+  const int achunk_cfg = (attn_chunk > 0 && attn_chunk < 999999) ? attn_chunk : 0;   // as configured (not clipped by T2)
+  const int achunk = (achunk_cfg > 0 && achunk_cfg < T2) ? achunk_cfg : 0;
+  if (m->es_achunk != achunk_cfg || m->es_cchunk != cchunk) { m->es_final = 0; m->es_achunk = achunk_cfg; m->es_cchunk = cchunk; }
+  if (m->es_final > T2) m->es_final = 0;           // audio got shorter: a new utterance without reset
+  if (m->es_cap < T2) {                             // grow (contents are only needed below es_final: keep them)
+    const int cap = std::min(c.max_rel_pos, std::max(2 * T2, 256));
+    DevBuf nq, ng, no;
+    RET(nq.ensure((size_t)L * cap * 3 * d * sizeof(float)));
+    RET(ng.ensure((size_t)L * cap * d * sizeof(float)));
+    RET(no.ensure((size_t)cap * d * sizeof(float)));
+    if (m->es_final > 0) {
+      for (int l = 0; l < L; ++l) {
+        SS_HIP_CHECK(hipMemcpyAsync(nq.f() + (size_t)l * cap * 3 * d, m->es_qkv.f() + (size_t)l * m->es_cap * 3 * d,
+                                    (size_t)m->es_final * 3 * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+        SS_HIP_CHECK(hipMemcpyAsync(ng.f() + (size_t)l * cap * d, m->es_glu.f() + (size_t)l * m->es_cap * d,
+                                    (size_t)m->es_final * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+      }
+      SS_HIP_CHECK(hipMemcpyAsync(no.f(), m->es_out.f(), (size_t)m->es_final * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+      SS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    m->es_qkv.release(); m->es_glu.release(); m->es_out.release();
+    m->es_qkv = nq; m->es_glu = ng; m->es_out = no;
+    nq.p = nullptr; ng.p = nullptr; no.p = nullptr;
+    m->es_cap = cap;
+  }
+  const int cap = m->es_cap;
+  const int r0 = m->es_final;                       // first row to (re)compute
+  const int n = T2 - r0;
+  if (n_computed) *n_computed = n;
+
+  const size_t n_h1 = (size_t)T1 * (c.conv_channels / 2);
+  const size_t n_x = (size_t)T2 * d, n_f = (size_t)n * f;
+  RET(m->ws.ensure((n_h1 + 3 * n_x + n_f) * sizeof(float)));
+  float* h1 = m->ws.f();
+  float* g0 = h1 + n_h1;                // subsampler output [T2, d]
+  float* h = g0 + n_x;                  // LN output / attention context (tail rows, indexed from 0)
+  float* g2 = h + n_x;                  // depthwise output, absolute rows
+  float* ff = g2 + n_x;                 // FFN hidden (tail rows)
+  float* x = d_enc_out + (size_t)r0 * d;  // running activations of the tail rows live in the output buffer
+
+  {
+    GemmArgs a;
+    a.A = d_fbank; a.lda = c.input_feat; a.W = m->sub0.w; a.bias = m->sub0.b; a.C = h1; a.ldc = c.conv_channels / 2;
+    a.M = T1; a.N = c.conv_channels; a.Cin = c.input_feat; a.taps = k; a.stride = 2; a.pad = k / 2;
+    a.in_len = T; a.chunk = cchunk; a.glu = 1;
+    RET(launch_conv_gemm(a, s));
+    GemmArgs b;
+    b.A = h1; b.lda = c.conv_channels / 2; b.W = m->sub1.w; b.bias = m->sub1.b; b.C = g0; b.ldc = d;
+    b.M = T2; b.N = 2 * d; b.Cin = c.conv_channels / 2; b.taps = k; b.stride = 2; b.pad = k / 2;
+    b.in_len = T1; b.chunk = cchunk; b.glu = 1;
+    RET(launch_conv_gemm(b, s));
+  }
+  if (r0 > 0)
+    SS_HIP_CHECK(hipMemcpyAsync(d_enc_out, m->es_out.f(), (size_t)r0 * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (n > 0) {
+    RET(linear(s, g0 + (size_t)r0 * d, d, n, m->enc_linear, d, d, x, d));
+    const float* P = m->pos_proj.f() + (size_t)(c.max_rel_pos - T2) * Ld;
+    for (int l = 0; l < L; ++l) {
+      const EncLayer& e = m->enc[l];
+      float* qkv = m->es_qkv.f() + (size_t)l * cap * 3 * d;      // absolute rows
+      float* glu = m->es_glu.f() + (size_t)l * cap * d;
+      RET(ln_linear(s, x, n, e.ffn1_ln, e.ffn1_w1, f, d, ff, f, h, ACT_SILU));
+      RET(linear(s, ff, f, n, e.ffn1_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
+      RET(ln_linear(s, x, n, e.attn_ln, e.qkv, 3 * d, d, qkv + (size_t)r0 * 3 * d, 3 * d, h));
+      AttnArgs at;
+      at.Q = qkv + (size_t)r0 * 3 * d; at.K = qkv + d; at.V = qkv + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
+      at.O = h; at.ldo = d; at.Tq = n; at.Tk = T2; at.q0 = r0; at.H = c.enc_heads; at.scale = 0.125f;
+      at.chunk = achunk; at.P = P + (size_t)l * d; at.ldp = Ld; at.bias_u = e.u; at.bias_v = e.v;
+      RET(launch_attention(at, s));
+      RET(linear(s, h, d, n, e.out, d, d, x, d, ACT_NONE, 1.f, x, d));
+      RET(ln_linear(s, x, n, e.conv_ln, e.pw1, 2 * d, d, glu + (size_t)r0 * d, d, h, ACT_NONE, 1.f, 1));
+      RET(launch_dwconv_bn_silu(glu, d, g2, d, e.dw_wt, c.dw_kernel, e.bn_mean, e.bn_var, e.bn_g, e.bn_b, 1e-5f,
+                                T2, d, cchunk, s, nullptr, 0, r0));
+      RET(linear(s, g2 + (size_t)r0 * d, d, n, e.pw2, d, d, x, d, ACT_NONE, 1.f, x, d));
+      RET(ln_linear(s, x, n, e.ffn2_ln, e.ffn2_w1, f, d, ff, f, h, ACT_SILU));
+      RET(linear(s, ff, f, n, e.ffn2_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
+      RET(layernorm(s, x, x, e.final_ln, n, d));
+    }
+  }
+  const int nf = std::max(r0, stream_final_rows(T, T1, T2, k, achunk_cfg, cchunk, c.dw_kernel));
+  if (nf > r0)
+    SS_HIP_CHECK(hipMemcpyAsync(m->es_out.f() + (size_t)r0 * d, d_enc_out + (size_t)r0 * d, (size_t)(nf - r0) * d * sizeof(float),
+                                hipMemcpyDeviceToDevice, s));
+  m->es_final = nf;
+  if (n_final) *n_final = nf;
   return SS_OK;
 }
 

@@ -177,6 +177,26 @@ class HipModel(BatchMixin):
                                             int(min(conv_chunk, 1 << 30)), _ptr(out)), "ss_encoder_forward")
         return out
 
+    def encoder_stream_reset(self):
+        """Forget the incremental-encoder cache (new utterance)."""
+        L.check(self.lib.ss_encoder_stream_reset(self.h), "ss_encoder_stream_reset")
+        self.stream_stats = (0, 0)
+
+    def encoder_stream_forward(self, fbank: torch.Tensor, attn_chunk: int, conv_chunk: int) -> torch.Tensor:
+        """Incremental twin of :meth:`encoder_forward` for streaming: same input (fbank
+        of all audio so far) and output, but only the rows that are not final yet are recomputed.
+        ``self.stream_stats`` = (rows final after the call, rows recomputed by it)."""
+        assert fbank.is_cuda and fbank.dtype == torch.float32 and fbank.is_contiguous()
+        T = fbank.shape[0]
+        Tp = self.lib.ss_encoder_out_len(T)
+        out = torch.empty((Tp, self.cfg.enc_dim), dtype=torch.float32, device=self.device)
+        nf, nc = C.c_int32(0), C.c_int32(0)
+        L.check(self.lib.ss_encoder_stream_forward(self.h, _stream(), _ptr(fbank), T, int(min(attn_chunk, 1 << 30)),
+                                                   int(min(conv_chunk, 1 << 30)), _ptr(out), C.byref(nf), C.byref(nc)),
+                "ss_encoder_stream_forward")
+        self.stream_stats = (nf.value, nc.value)
+        return out
+
     # ---- a8 -------------------------------------------------------------------------------
     def ctc_greedy(self, head: int, enc_out: torch.Tensor, want_logits: bool = False):
         """-> (tokens list, frame index list, raw argmax tensor, logits or None)."""

@@ -40,6 +40,8 @@ SIGNATURES = {
     "ss_fbank_cmvn": (_i, [_vp, _vp, _vp, _i, _f, _vp, C.POINTER(_i)]),
     "ss_encoder_out_len": (_i, [_i]),
     "ss_encoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "ss_encoder_stream_reset": (_i, [_vp]),
+    "ss_encoder_stream_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ss_ctc_greedy": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ss_mt_begin": (_i, [_vp, _vp, _vp, _i]),
     "ss_mt_append": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i]),

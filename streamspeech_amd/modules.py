@@ -75,6 +75,9 @@ class HipChunkConformerEncoder:
         self.hip = hip
         self.chunk_size = 999999
         self.chunk = True
+        # streaming: reuse the rows that are already final instead of re-encoding all audio at every
+        # policy() call; the agent switches it on and calls reset_stream() per utterance
+        self.incremental = False
         self.subsample = _SubsampleView()
         self.conformer_layers = [_LayerView() for _ in range(hip.cfg.enc_layers)]
 
@@ -88,11 +91,18 @@ class HipChunkConformerEncoder:
     def __call__(self, src_tokens: torch.Tensor, src_lengths: torch.Tensor = None, **kw):
         assert src_tokens.dim() == 3 and src_tokens.size(0) == 1, "one utterance per call (B = 1)"
         fb = src_tokens[0].to(self.hip.device, torch.float32).contiguous()
-        out = self.hip.encoder_forward(fb, self.chunk_size, self._conv_chunk())
+        if self.incremental and hasattr(self.hip, "encoder_stream_forward"):
+            out = self.hip.encoder_stream_forward(fb, self.chunk_size, self._conv_chunk())
+        else:
+            out = self.hip.encoder_forward(fb, self.chunk_size, self._conv_chunk())
         return {"encoder_out": [out.unsqueeze(1)], "encoder_padding_mask": [], "encoder_embedding": [],
                 "encoder_states": [], "src_tokens": [], "src_lengths": []}
 
     forward = __call__
+
+    def reset_stream(self):
+        if hasattr(self.hip, "encoder_stream_reset"):
+            self.hip.encoder_stream_reset()
 
 
 class HipCTCDecoder:

@@ -263,3 +263,35 @@ def test_incremental_vocoder_tail_on_hip(hip_vocoder, synth_weights):
             inc, _ = synthesize_tail(voc, units[:upto], n_new, dur_pred, rf + 8, rf)
             assert inc.shape == full.shape and inc.numel() > 0
             assert float(torch.sqrt(torch.mean((inc - full) ** 2))) < 1e-5
+
+
+@pytest.mark.parametrize("ac,cc,step", [(8, 8, 32), (16, 16, 64), (24, 16, 96), (8, 8, 45), (999999, 999999, 100)])
+def test_incremental_encoder_equals_full_recompute(hip_model, ac, cc, step):
+    """§8f-1: the streaming encoder entry point (cache of final rows) returns, for every prefix of the
+    audio, what ss_encoder_forward returns on that prefix; rows reported final never change again; and it
+    really skips work (rows recomputed per call stay bounded instead of growing with the prefix)."""
+    from streamspeech_amd import synth
+    fb_all = torch.from_numpy(synth.synth_fbank(41, 700)).to(hip_model.device)
+    hip_model.encoder_stream_reset()
+    prev, prev_final, recomputed = None, 0, []
+    for T in list(range(30, 700, step)) + [700]:
+        fb = fb_all[:T].contiguous()
+        full = hip_model.encoder_forward(fb, ac, cc)
+        inc = hip_model.encoder_stream_forward(fb, ac, cc)
+        nf, nc = hip_model.stream_stats
+        assert inc.shape == full.shape
+        assert (inc - full).abs().max().item() < 5e-5, f"T={T}: {(inc - full).abs().max().item()}"
+        if prev is not None and prev_final > 0:
+            assert torch.equal(inc[:prev_final], prev[:prev_final]), "final rows must be served unchanged"
+        assert nc == full.shape[0] - prev_final and nf >= prev_final
+        prev, prev_final = inc, nf
+        recomputed.append(nc)
+    if ac < 999:
+        assert prev_final > 0 and max(recomputed[2:]) <= ac + cc + step // 4 + 16, recomputed
+        assert hip_model.ctc_greedy(0, inc)[0] == hip_model.ctc_greedy(0, full)[0]
+    else:
+        assert prev_final == 0                     # offline (full attention): nothing is ever final
+    # a shorter input (new utterance without reset) must not reuse stale rows
+    fb = fb_all[100:260].contiguous()
+    assert (hip_model.encoder_stream_forward(fb, ac, cc) - hip_model.encoder_forward(fb, ac, cc)).abs().max().item() < 5e-5
+    hip_model.encoder_stream_reset()
