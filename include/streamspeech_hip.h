@@ -64,6 +64,15 @@ int ss_fbank_num_frames(int n_samples);
 int ss_fbank_cmvn(ss_model* m, void* stream, const float* d_pcm16k, int n_samples, float pcm_scale,
                   float* d_feat, int* h_n_frames);
 
+/* Waveform front-end: rational polyphase resampling on the device, standing in for
+ * the sox `rate` effect of convert_waveform (fairseq/data/audio/audio_utils.py:53-62; third-party
+ * arithmetic outside the fbank-input parity contract).  d_out[k] = sum_m d_in[m] *
+ * d_taps[half_len + k*down - m*up] for k < n_out; n_out is normally ceil(n_in*up/down), up/down in
+ * lowest terms, d_taps [2*half_len+1] is the host-designed low-pass with gain `up`
+ * (streamspeech_amd/frontend.py design_filter). */
+int ss_resample(void* stream, const float* d_in, int64_t n_in, int up, int down, const float* d_taps,
+                int half_len, float* d_out, int64_t n_out);
+
 /* ---- a2-a7: model.encoder(src_tokens, src_lengths) for one utterance (agent :433-435 ->
  * chunk_unity/models/s2t_conformer.py:111-163).  d_fbank [T,80] -> d_enc_out [T',256].
  * attn_chunk = encoder.chunk_size, conv_chunk = ChunkCausalConv1d.chunk_size as the agent sets

@@ -111,4 +111,43 @@ int launch_fbank_cmvn_batch(const float* pcm, float pcm_scale, const float* wind
   return SS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Rational polyphase resampler (48 kHz -> 16 kHz in the agent).  Replaces the sox `rate` effect
+// the reference applies to the whole sample history at every chunk
+// (fairseq/data/audio/audio_utils.py:53-62 <- convert_waveform <- agent :66-98) with a zero-phase
+// windowed-sinc FIR: y[k] = sum_m x[m] * h[half + k*down - m*up].  The taps (host-designed, gain
+// `up`) are ~60/output sample for 3:1: a thread per output sample, taps through LDS when they fit.
+// HBM-bound by construction: 4*(n_in + n_out) bytes.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, long long n_in, int up, int down,
+                                                       const float* __restrict__ h, int half, float* __restrict__ y,
+                                                       long long n_out) {
+  extern __shared__ float hs[];
+  const int ntaps = 2 * half + 1;
+  for (int i = threadIdx.x; i < ntaps; i += 256) hs[i] = h[i];
+  __syncthreads();
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= n_out) return;
+  const long long c = k * down;
+  long long m_lo = c - half;                          // ceil((c - half) / up), clamped at 0
+  m_lo = m_lo <= 0 ? 0 : (m_lo + up - 1) / up;
+  long long m_hi = (c + half) / up;
+  if (m_hi > n_in - 1) m_hi = n_in - 1;
+  float acc = 0.f;
+  for (long long m = m_lo; m <= m_hi; ++m) acc = fmaf(x[m], hs[half + (int)(c - m * up)], acc);
+  y[k] = acc;
+}
+
+int launch_resample(const float* x, long long n_in, int up, int down, const float* taps, int half_len, float* y,
+                    long long n_out, hipStream_t stream) {
+  if (n_in <= 0 || n_out <= 0) return SS_OK;
+  if (up <= 0 || down <= 0 || half_len < 0) return SS_ERR_ARG;
+  const size_t lds = (size_t)(2 * half_len + 1) * sizeof(float);
+  if (lds > 64 * 1024) return SS_ERR_ARG;             // 16 K taps: ratios up to ~800:1 in lowest terms
+  hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((n_out + 255) / 256)), dim3(256), lds, stream, x, n_in, up, down,
+                     taps, half_len, y, n_out);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
 }  // namespace ss

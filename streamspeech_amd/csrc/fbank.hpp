@@ -17,4 +17,9 @@ int launch_fbank_cmvn_batch(const float* pcm, float pcm_scale, const float* wind
                             const float* cmvn_mean, const float* cmvn_std, float* feat, const int* segs, int nseg,
                             int max_frames, hipStream_t stream);
 
+// y[k] = sum_m x[m] * taps[half_len + k*down - m*up] for k < n_out (zero-phase polyphase FIR; `up`/`down`
+// in lowest terms, taps [2*half_len+1] on the device with gain `up`).
+int launch_resample(const float* x, long long n_in, int up, int down, const float* taps, int half_len, float* y,
+                    long long n_out, hipStream_t stream);
+
 }  // namespace ss

@@ -273,6 +273,12 @@ extern "C" void ss_model_destroy(ss_model* m) {
 }
 
 // ---- front-end ---------------------------------------------------------------------------------
+extern "C" int ss_resample(void* stream, const float* d_in, int64_t n_in, int up, int down, const float* d_taps,
+                           int half_len, float* d_out, int64_t n_out) {
+  if (!d_in || !d_out || !d_taps) return SS_ERR_ARG;
+  return launch_resample(d_in, n_in, up, down, d_taps, half_len, d_out, n_out, (hipStream_t)stream);
+}
+
 extern "C" int ss_fbank_num_frames(int n) { return n < 400 ? 0 : 1 + (n - 400) / 160; }
 
 extern "C" int ss_fbank_cmvn(ss_model* m, void* stream, const float* d_pcm, int n_samples, float pcm_scale,

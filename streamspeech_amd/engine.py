@@ -152,6 +152,27 @@ class HipModel(BatchMixin):
         except Exception:
             pass
 
+    # ---- waveform front-end (§8f-3) --------------------------------------------------------
+    def resample(self, pcm: torch.Tensor, sr_in: int, sr_out: int = 16000) -> torch.Tensor:
+        """float32 [n] on the device at sr_in -> [ceil(n*sr_out/sr_in)] at sr_out (polyphase FIR kernel)."""
+        import math
+        from .frontend import design_filter
+        g = math.gcd(int(sr_in), int(sr_out))
+        up, down = int(sr_out) // g, int(sr_in) // g
+        if up == down:
+            return pcm
+        key = (up, down)
+        cache = self.__dict__.setdefault("_resample_taps", {})
+        if key not in cache:
+            cache[key] = torch.from_numpy(design_filter(up, down).astype(np.float32)).to(self.device)
+        taps = cache[key]
+        n_in = pcm.numel()
+        n_out = -(-n_in * up // down)
+        out = torch.empty((n_out,), dtype=torch.float32, device=self.device)
+        L.check(self.lib.ss_resample(_stream(), _ptr(pcm), n_in, up, down, _ptr(taps), (taps.numel() - 1) // 2,
+                                     _ptr(out), n_out), "ss_resample")
+        return out
+
     # ---- a1 -------------------------------------------------------------------------------
     def fbank_cmvn(self, pcm16k: torch.Tensor, pcm_scale: float = 32768.0) -> torch.Tensor:
         """pcm16k: float32 [n] on the device -> [T, 80]."""

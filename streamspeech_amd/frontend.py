@@ -1,15 +1,59 @@
 """OnlineFeatureExtractor of the agent (reference agent/speech_to_speech.streamspeech.agent.py:43-98)
-over the fused fbank+CMVN HIP kernel.
+over the fused fbank+CMVN HIP kernel, plus the waveform front-end.
 
 The reference resamples the whole 48 kHz sample history to 16 kHz with sox ("rate", via
 torchaudio.sox_effects, fairseq/data/audio/audio_utils.py:53-62) -- third-party arithmetic outside
-the parity contract (BASELINE.json: "on the same fbank input").  Here a polyphase
-FIR (scipy.signal.resample_poly) stands in on the host when the source is not already 16 kHz.
+the parity contract (BASELINE.json: "on the same fbank input").  Here a zero-phase
+polyphase FIR with the published design of scipy.signal.resample_poly runs on the device
+(ss_resample, csrc/fbank.hip) when the source is not already 16 kHz.
 """
 import math
+import wave
 
 import numpy as np
 import torch
+
+
+def design_filter(up: int, down: int) -> np.ndarray:
+    """Low-pass of the polyphase resampler, float64 [2*10*max(up,down)+1]: windowed sinc, cutoff
+    1/max(up,down) of Nyquist, Kaiser beta 5, unit DC gain, times `up` (the design
+    scipy.signal.resample_poly documents; `up`/`down` in lowest terms)."""
+    max_rate = max(up, down)
+    half_len = 10 * max_rate
+    n = np.arange(2 * half_len + 1, dtype=np.float64) - half_len
+    fc = 1.0 / max_rate
+    h = fc * np.sinc(fc * n) * np.kaiser(2 * half_len + 1, 5.0)
+    return h / h.sum() * up
+
+
+def read_wav(path: str):
+    """PCM WAV (8/16/32-bit integer) -> (float32 mono samples in [-1, 1), sample rate): the `list[float]`
+    the SimulEval dataloader hands the agent (SimulEval/simuleval/data/dataloader/s2t_dataloader.py).
+    MP3 (example/wavs/*.mp3) needs a decoder this image does not have; convert to WAV first."""
+    if str(path).lower().endswith(".mp3"):
+        raise IOError("no MP3 decoder is available here; convert %s to PCM WAV" % path)
+    with wave.open(str(path), "rb") as w:
+        sr, nch, sw, n = w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()
+        raw = w.readframes(n)
+    if sw == 2:
+        x = np.frombuffer(raw, "<i2").astype(np.float32) / 32768.0
+    elif sw == 4:
+        x = np.frombuffer(raw, "<i4").astype(np.float32) / 2147483648.0
+    elif sw == 1:
+        x = (np.frombuffer(raw, "u1").astype(np.float32) - 128.0) / 128.0
+    else:
+        raise IOError("unsupported WAV sample width %d" % sw)
+    if nch > 1:
+        x = x.reshape(-1, nch).mean(axis=1)          # convert_waveform(to_mono=True): channel mean
+    return x, sr
+
+
+def write_wav(path: str, samples, sr: int = 16000):
+    """float samples in [-1, 1] -> 16-bit PCM WAV (generate_waveform_from_code.py dumps soundfile PCM_16)."""
+    x = np.clip(np.asarray(samples, np.float32), -1.0, 1.0)
+    with wave.open(str(path), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(int(sr))
+        w.writeframes(np.round(x * 32767.0).astype("<i2").tobytes())
 
 SHIFT_SIZE, WINDOW_SIZE, ORG_SAMPLE_RATE, SAMPLE_RATE, FEATURE_DIM = 10, 25, 48000, 16000, 80
 
@@ -39,9 +83,7 @@ class OnlineFeatureExtractor:
         effective = int(num_frames * self.len_ms_to_samples(self.shift_size)
                         + self.len_ms_to_samples(self.window_size - self.shift_size))
         x = np.asarray(samples[:effective], dtype=np.float32)
-        if sr != SAMPLE_RATE:
-            from scipy.signal import resample_poly
-            g = math.gcd(int(sr), SAMPLE_RATE)
-            x = resample_poly(x, SAMPLE_RATE // g, int(sr) // g).astype(np.float32)
         pcm = torch.from_numpy(x).to(self.engine.device)
+        if sr != SAMPLE_RATE:
+            pcm = self.engine.resample(pcm, int(sr), SAMPLE_RATE)
         return self.engine.fbank_cmvn(pcm, 32768.0)

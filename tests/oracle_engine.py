@@ -15,6 +15,10 @@ class OracleEngine:
         self.std = np.ones(80, np.float32) if cmvn_std is None else np.asarray(cmvn_std, np.float32)
         self._tokens, self._enc = [], None
 
+    def resample(self, pcm, sr_in, sr_out=16000):
+        from oracle.resample import resample_poly_ref
+        return torch.from_numpy(resample_poly_ref(pcm.cpu().numpy(), sr_out, sr_in))
+
     def fbank_cmvn(self, pcm, pcm_scale=32768.0):
         x = pcm.cpu().numpy().astype(np.float32) * np.float32(pcm_scale)
         return torch.from_numpy(K.global_cmvn(K.fbank(x), self.mean, self.std))

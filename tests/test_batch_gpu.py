@@ -117,3 +117,42 @@ def test_batch_vocoder_on_stream_k_kernels_vs_oracle(hip_vocoder, synth_weights)
         rms = float(torch.sqrt(torch.mean((wavs[b].cpu() - rw) ** 2)))
         assert rms < 1e-3, f"utt {b}: rms {rms}"
     assert float(torch.sqrt(torch.mean((single.cpu() - wavs[2].cpu()) ** 2))) < 1e-5
+
+
+def test_offline_driver_writes_fairseq_generate_format(hip_model, hip_vocoder, tmp_path):
+    """§8f-4: generate-<subset>.log/.txt in the reference's line format, the files pred.offline-s2st.sh
+    cuts out of them, <n>_pred.wav dumps; hypotheses equal the single-utterance path."""
+    from streamspeech_amd import frontend, offline, synth
+    from streamspeech_amd.modules import Dictionary
+    cfg = hip_model.cfg
+    dicts = {k: Dictionary.placeholder(n) for k, n in (("source_unigram", cfg.src_vocab), ("ctc_target_unigram", cfg.tgt_vocab),
+                                                       ("target_unigram", cfg.tgt_vocab))}
+    secs = [1.3, 2.9, 0.8, 2.1, 1.7]
+    items = [(10 + i, torch.from_numpy(synth.synth_pcm(70 + i, int(16000 * s))).to(hip_model.device)) for i, s in enumerate(secs)]
+    hyps = offline.generate(hip_model, hip_vocoder, items, dicts, str(tmp_path), "test", batch_size=3, max_len_a=0.0,
+                            max_len_b=12, dur_prediction=True, dump_wav=True)
+    assert sorted(hyps) == [10, 11, 12, 13, 14]
+    log = (tmp_path / "generate-test.log").read_text().splitlines()
+    assert sorted(ln.split("\t")[0] for ln in log) == sorted(f"{p}-{i}" for p in "ASD" for i in range(10, 15))
+    res = (tmp_path / "generate-test.txt").read_text().splitlines()
+    units = {}
+    for ln in res:
+        tag, score, u = ln.split("\t")
+        assert tag[:2] in ("H-", "D-") and float(score) == 0.0
+        units[int(tag[2:])] = [int(x) for x in u.split()]
+    unit_file = (tmp_path / "generate-test.unit").read_text().splitlines()
+    assert [[int(x) for x in ln.split()] for ln in unit_file] == [units[i] for i in range(10, 15)]
+    assert len((tmp_path / "generate-test.asr").read_text().splitlines()) == 5
+    # same hypotheses as the one-utterance-at-a-time path, wav dump = that path's waveform as PCM16
+    for n, (sid, pcm) in enumerate(items[:3]):
+        fb = hip_model.fbank_cmvn(pcm)
+        enc = hip_model.encoder_forward(fb)
+        from streamspeech_amd.pipeline import mt_greedy, units_from_tokens
+        toks, feats = mt_greedy(hip_model, enc, max_new_tokens=12)
+        u_toks, _, _ = hip_model.t2u_units(feats[: len(toks)], mask_eos=True)
+        assert units_from_tokens(u_toks, cfg) == hyps[sid]["units"]
+        if hyps[sid]["units"]:
+            y, sr = frontend.read_wav(tmp_path / "pred_wav" / f"{n}_pred.wav")
+            w = hyps[sid]["wav"].cpu().numpy()
+            assert sr == 16000 and y.shape == w.shape and np.abs(np.clip(w, -1, 1) - y).max() < 1e-4
+

@@ -1,0 +1,62 @@
+"""Waveform front-end: resampler oracle pinned against scipy.signal.resample_poly,
+the product filter design equals the oracle's, WAV read/write round trip."""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle.resample import design_filter as oracle_design, resample_poly_ref
+from streamspeech_amd import frontend, synth
+
+
+@pytest.mark.parametrize("sr_in", [48000, 44100, 22050, 8000, 16000])
+def test_resampler_oracle_matches_scipy(sr_in):
+    from scipy.signal import resample_poly
+    x = synth.synth_pcm(3, 4801)
+    g = math.gcd(16000, sr_in)
+    want = resample_poly(x.astype(np.float64), 16000 // g, sr_in // g)
+    got = resample_poly_ref(x, 16000, sr_in)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 5e-7
+
+
+def test_product_filter_design_is_the_oracle_design():
+    for up, down in ((1, 3), (160, 441), (2, 1)):
+        assert np.array_equal(frontend.design_filter(up, down), oracle_design(up, down))
+    h = frontend.design_filter(1, 3)
+    assert len(h) == 61 and abs(h.sum() - 1.0) < 1e-12 and np.allclose(h, h[::-1])
+
+
+def test_resampler_properties():
+    # linearity, and a 1 kHz tone at 48 kHz stays a 1 kHz tone of the same amplitude at 16 kHz
+    a, b = synth.synth_pcm(1, 3000), synth.synth_pcm(2, 3000)
+    lhs = resample_poly_ref(2.0 * a + b, 16000, 48000)
+    rhs = 2.0 * resample_poly_ref(a, 16000, 48000) + resample_poly_ref(b, 16000, 48000)
+    assert np.abs(lhs - rhs).max() < 1e-6
+    t = np.arange(48000) / 48000.0
+    y = resample_poly_ref(np.sin(2 * np.pi * 1000 * t).astype(np.float32), 16000, 48000)
+    ref = np.sin(2 * np.pi * 1000 * np.arange(16000) / 16000.0)
+    assert np.abs(y[200:-200] - ref[200:-200]).max() < 2e-3
+    assert resample_poly_ref(a[:0], 16000, 48000).shape == (0,)
+
+
+def test_wav_round_trip(tmp_path):
+    x = synth.synth_pcm(5, 1234)
+    p = tmp_path / "a.wav"
+    frontend.write_wav(p, x, 16000)
+    y, sr = frontend.read_wav(p)
+    assert sr == 16000 and y.shape == x.shape and np.abs(x - y).max() <= 1e-4
+    with pytest.raises(IOError):
+        frontend.read_wav("example.mp3")
+
+
+def test_ordered_batches_are_length_sorted_and_bounded():
+    from streamspeech_amd.offline import detok, ordered_batches
+    b = ordered_batches([5, 50, 7, 49, 48, 6], 2)
+    assert b == [[1, 3], [4, 2], [5, 0]]
+    b = ordered_batches([10, 10, 10, 10], 8, max_tokens=25)
+    assert b == [[0, 1], [2, 3]]
+    assert detok(["▁he", "llo", "▁wor", "ld", "</s>"]) == "hello world"

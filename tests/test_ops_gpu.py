@@ -249,3 +249,4 @@ def test_stream_k_conv_matches_torch(lib, M, N, Cin, taps, dil, G):
     assert (got - ref).abs().max() < TOL, f"max err {(got - ref).abs().max()}"
     assert torch.equal(got, got2), "stream-K must be deterministic run to run"
     assert (plain - _conv_ref(A, W.reshape(N, -1) if taps == 1 else W, None, taps, dil)).abs().max() < TOL
+

@@ -295,3 +295,15 @@ def test_incremental_encoder_equals_full_recompute(hip_model, ac, cc, step):
     fb = fb_all[100:260].contiguous()
     assert (hip_model.encoder_stream_forward(fb, ac, cc) - hip_model.encoder_forward(fb, ac, cc)).abs().max().item() < 5e-5
     hip_model.encoder_stream_reset()
+
+
+@pytest.mark.parametrize("sr_in,n", [(48000, 48000 * 3 + 17), (44100, 30001), (8000, 5000), (48000, 2)])
+def test_resample_kernel_matches_oracle(hip_model, sr_in, n):
+    """§8f-3: ss_resample (polyphase FIR on the device) vs the numpy oracle pinned against scipy."""
+    from oracle.resample import resample_poly_ref
+    from streamspeech_amd import synth
+    x = synth.synth_pcm(9, n)
+    got = hip_model.resample(torch.from_numpy(x).to(hip_model.device), sr_in).cpu().numpy()
+    want = resample_poly_ref(x, 16000, sr_in)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-6
