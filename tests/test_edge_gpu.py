@@ -1,0 +1,107 @@
+"""Edge cases of the hot path on the GPU: empty / minimal / maximal / ragged inputs and the error
+conventions of the C ABI (codes -> StreamSpeechHipError), as the reference's call sites exercise them."""
+import numpy as np
+import pytest
+import torch
+
+from streamspeech_amd import lib as L
+from streamspeech_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_too_short_audio_gives_zero_frames_and_agent_reads(hip_model, hip_vocoder, synth_weights):
+    from streamspeech_amd.agent import StreamSpeechS2STAgent
+    from streamspeech_amd.modules import CodeHiFiGANVocoderWithDur, StreamSpeechModel
+    from streamspeech_amd.simuleval_shim import SpeechSegment
+    from tests.test_agent_cpu import make_args
+    assert hip_model.lib.ss_fbank_num_frames(399) == 0 and hip_model.lib.ss_fbank_num_frames(400) == 1
+    assert hip_model.fbank_cmvn(torch.zeros(100, device=hip_model.device)).shape == (0, 80)
+
+    class Surf:
+        def __init__(self, hv):
+            self.hip = hv
+        __call__ = CodeHiFiGANVocoderWithDur.__call__
+
+    agent = StreamSpeechS2STAgent(make_args(320), model=StreamSpeechModel.from_engine(hip_model), vocoder=Surf(hip_vocoder))
+    seg = agent.pushpop(SpeechSegment(content=[0.0] * 200, sample_rate=16000, finished=False))
+    assert seg.is_empty                                   # ReadAction: not even one fbank frame yet
+    seg = agent.pushpop(SpeechSegment(content=[], sample_rate=16000, finished=True))
+    assert seg.finished                                   # an utterance that never reached one frame still finishes
+
+
+@pytest.mark.parametrize("T", [7, 9, 10, 11, 12, 13])
+def test_minimal_encoder_lengths(hip_model, synth_weights, T):
+    """T' = ((T-1)//2+1 -1)//2+1 down to a single frame (SURVEY lens formula)."""
+    from oracle import streamspeech_oracle as O
+    cfg, _, sd, _ = synth_weights
+    fb = torch.from_numpy(synth.synth_fbank(3, T))
+    got = hip_model.encoder_forward(fb.to(hip_model.device), 8, 8).cpu()
+    ref = O.encoder_forward(O.SD(sd), fb, cfg, 8, 8)
+    assert got.shape == ref.shape and got.shape[0] == hip_model.lib.ss_encoder_out_len(T)
+    assert (got - ref).abs().max() < 5e-4
+    toks = hip_model.ctc_greedy(0, got.to(hip_model.device))[0]
+    assert toks == O.ctc_head(O.SD(sd), ref, "source_unigram", cfg)[0]
+
+
+def test_capacity_errors_are_reported_not_overrun(hip_model):
+    cap = 2048                                            # max_rel_pos of the fixture model
+    T = 4 * (cap + 8)
+    fb = torch.zeros((T, 80), device=hip_model.device)
+    with pytest.raises(L.StreamSpeechHipError, match="capacity|CAPACITY"):
+        hip_model.encoder_forward(fb)
+    enc = hip_model.encoder_forward(torch.from_numpy(synth.synth_fbank(1, 60)).to(hip_model.device))
+    with pytest.raises(L.StreamSpeechHipError):
+        hip_model.mt_greedy(enc, [], 5000, 1)             # beyond max_target_positions
+
+
+def test_longest_supported_utterance_offline_and_chunked(hip_model, synth_weights):
+    """T' = 2048 = the positional-table capacity (82 s of audio), chunked and offline, vs the oracle on the
+    last frames only (the oracle takes ~10 s for the full thing, so compare a property: chunked rows of the first
+    chunks equal the same rows computed on a prefix)."""
+    T = 4 * 2048 - 1
+    fb = torch.from_numpy(synth.synth_fbank(5, T)).to(hip_model.device)
+    full = hip_model.encoder_forward(fb, 8, 8)
+    assert full.shape == (2048, 256) and torch.isfinite(full).all()
+    pre = hip_model.encoder_forward(fb[:640].contiguous(), 8, 8)
+    n_final = (640 // 32 - 1) * 8
+    assert (full[:n_final] - pre[:n_final]).abs().max() < 5e-5      # chunk-causality: the future cannot reach them
+    off = hip_model.encoder_forward(fb)
+    assert torch.isfinite(off).all() and (off - full).abs().max() > 1e-3   # offline really sees the future
+
+
+def test_single_unit_and_extreme_ragged_vocoder_batch(hip_vocoder, synth_weights):
+    from oracle import streamspeech_oracle as O
+    _, vcfg, _, vsd = synth_weights
+    w1, d1 = hip_vocoder.forward(torch.tensor([7], dtype=torch.int32, device="cuda:0"), True)
+    rw, rd = O.vocoder_forward(O.SD(vsd), [7], vcfg, True)
+    assert d1.cpu().tolist() == rd.view(-1).tolist() and w1.numel() == rw.numel()
+    assert float(torch.sqrt(torch.mean((w1.cpu() - rw) ** 2))) < 1e-3
+    codes = [[5], [int(c) for c in synth.uniform(1, "edge/long", (400,), 0, 1000)], [9, 9]]
+    wavs, dur, K = hip_vocoder.batch_forward(codes, True)
+    for b, c in enumerate(codes):
+        one, _ = hip_vocoder.forward(torch.tensor(c, dtype=torch.int32, device="cuda:0"), True)
+        assert wavs[b].shape == one.shape
+        assert float(torch.sqrt(torch.mean((wavs[b] - one) ** 2))) < 1e-5
+
+
+def test_ragged_batch_one_second_next_to_fifteen(hip_model):
+    lens = [16000 * 15, 16000 * 1, 410, 16000 * 7]
+    pcm = [torch.from_numpy(synth.synth_pcm(20 + i, n)).to(hip_model.device) for i, n in enumerate(lens)]
+    feat, T = hip_model.batch_fbank_cmvn(torch.cat(pcm), lens)
+    enc, Tp = hip_model.batch_encoder_forward(feat, T)
+    off = 0
+    for b, p in enumerate(pcm):
+        one = hip_model.encoder_forward(hip_model.fbank_cmvn(p))
+        assert one.shape[0] == Tp[b]
+        assert (enc[off:off + Tp[b]] - one).abs().max() < 5e-5
+        off += Tp[b]
+
+
+def test_missing_weight_slot_is_an_error(synth_weights):
+    from streamspeech_amd.config import ModelConfig
+    from streamspeech_amd.engine import HipModel
+    cfg, _, sd, _ = synth_weights
+    bad = {k: v for k, v in sd.items() if not k.startswith("encoder.conformer_layers.3.ffn1.w_1")}
+    with pytest.raises((L.StreamSpeechHipError, KeyError)):
+        HipModel(bad, ModelConfig())
