@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // D = W.A^T: see epilogue
       }
     }
 
@@ -271,33 +271,57 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
     }
 
     // ---- epilogue (same operation order as conv_gemm_kernel) ----
+    // The MFMAs were issued with the operands swapped (D = W_tile . A_tile^T), so in the C/D layout
+    // (col = lane&15, row = 4*(lane>>4) + reg) a lane holds 4 CONSECUTIVE output channels of ONE row:
+    // bias / residual loads and the stores are float4 (4x fewer memory instructions than the scalar
+    // column-per-lane form, same 64-B segments).  Needs ldc/ldr/ldr2/ldc2 % 4 == 0 (checked on the host).
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i) {
+      const int m = m0 + wm * 64 + i * 16 + r;
+      if (m >= p.M) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 16 + r;
-        const float b = p.bias ? p.bias[n] : 0.f;
+        const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
+        f32x4 v = acc[i][j];
+        if (p.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int m = m0 + wm * 64 + i * 16 + g * 4 + e;
-          if (m < p.M) {
-            float v = acc[i][j][e] + b;
-            switch (p.act) {
-              case ACT_SILU: v = v / (1.0f + expf(-v)); break;
-              case ACT_RELU: v = fmaxf(v, 0.f); break;
-              case ACT_TANH: v = tanhf(v); break;
-              case ACT_LRELU: v = v > 0.f ? v : v * p.act_slope; break;
-              default: break;
-            }
-            v *= p.alpha;
-            if (p.R) v += p.R[(size_t)m * p.ldr + n];
-            if (p.R2) v = p.R2[(size_t)m * p.ldr2 + n] + v;
-            if (p.div > 0.f) v = v / p.div;
-            p.C[(size_t)m * p.ldc + n] = v;
-            if (p.C2) p.C2[(size_t)m * p.ldc2 + n] = v > 0.f ? v : v * p.c2_slope;
+          switch (p.act) {
+            case ACT_SILU: v[e] = v[e] / (1.0f + expf(-v[e])); break;
+            case ACT_RELU: v[e] = fmaxf(v[e], 0.f); break;
+            case ACT_TANH: v[e] = tanhf(v[e]); break;
+            case ACT_LRELU: v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope; break;
+            default: break;
           }
+          v[e] *= p.alpha;
+        }
+        if (p.R) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rr[e];
+        }
+        if (p.R2) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+        }
+        if (p.div > 0.f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / p.div;
+        }
+        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+        if (p.C2) {
+          f32x4 w2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w2[e] = v[e] > 0.f ? v[e] : v[e] * p.c2_slope;
+          *reinterpret_cast<f32x4*>(p.C2 + (size_t)m * p.ldc2 + n) = w2;
         }
       }
+    }
   }
 #endif
 }
@@ -334,7 +358,8 @@ static int sk_state(hipStream_t stream, SkState** out) {
 
 bool conv_sk_eligible(const GemmArgs& a) {
   return a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && a.Cin % SK_BK == 0 && (a.lda & 3) == 0 &&
-         a.N % 64 == 0 && a.M > 0 && ((size_t)(a.M + a.pad + 128) * a.lda + a.Cin) * 4 < 0x7ff00000ull &&
+         a.N % 64 == 0 && a.M > 0 && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && (!a.R2 || (a.ldr2 & 3) == 0) &&
+         (!a.C2 || (a.ldc2 & 3) == 0) && ((size_t)(a.M + a.pad + 128) * a.lda + a.Cin) * 4 < 0x7ff00000ull &&
          (size_t)a.N * a.taps * a.Cin * 4 < 0x7ff00000ull && (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f));
 }
 

@@ -570,13 +570,16 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   a.dbg = g_dbg;
 #endif
   if (g_force_bm == 1 && conv_sk_eligible(a)) return launch_conv_sk(a, stream, g_force_ks);   // tuning hook: stream-K, grid = ks (0 = auto)
-  // Big long-K "same" convs (packed vocoder batches, k >= 7 at C >= 128): persistent stream-K
-  // 128x128 tiles, +13..16 % over the 32x64 kernel.  Short-K problems (k = 3) and N = 64 stay on the
-  // small tiles: the per-workgroup fix-up + epilogue (~30 us) is not amortised over ~13 k-steps
-  // (profiles/r01_sk_sweep.txt).
-  if (!g_force_bm && conv_sk_eligible(a) && a.N % 128 == 0 && a.taps * a.Cin >= 1024 &&
-      2.0 * (double)a.M * a.N * a.taps * a.Cin >= g_sk_min_flops)
-    return launch_conv_sk(a, stream);
+  // Big "same" convs / linears (packed vocoder batches, unit-decoder FFN): persistent stream-K
+  // 128-wide tiles, 95-110 TFLOP/s against 75-90 for the 32x64 kernel (profiles/r01_sk_sweep.txt).
+  // They need enough k-steps per workgroup to amortise the fix-up + epilogue: >= 12 at BN = 128;
+  // at BN = 64 (half the MFMA work per k-step) only the k >= 7 convs qualify.
+  if (!g_force_bm && conv_sk_eligible(a) && 2.0 * (double)a.M * a.N * a.taps * a.Cin >= g_sk_min_flops) {
+    const long long nk = (long long)a.taps * (a.Cin / 32);
+    const bool wide = a.N % 128 == 0;
+    const long long units = (long long)cdiv(a.M, 128) * (a.N / (wide ? 128 : 64)) * nk;
+    if (wide ? units >= 12 * 512 : a.taps * a.Cin >= 448) return launch_conv_sk(a, stream);
+  }
   if (g_force_bm && a.N > 32 && k32) {   // tuning hook (tools/conv_bench.py): ks = KS*10 + PD
     const int f = g_force_bm * 10000 + (g_force_bn % 100) * 100 + g_force_ks;   // 128x128 -> bn code 28... see cases
     switch (f) {
