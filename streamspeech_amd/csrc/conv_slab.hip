@@ -1,0 +1,247 @@
+// Slab Conv1d for the narrow HiFi-GAN stages (C = 32 / 16 channels, 160x / 320x the frame rate;
+// reference fairseq/models/text_to_speech/hifigan.py:52-172).
+//
+// These convs have K = taps*C <= 352 and N <= 32: an LDS-tiled GEMM spends its time on prologue
+// and epilogue (3..11 k-steps per tile) and re-reads every input row once per tap from L2, while
+// the arithmetic intensity (30-90 FLOP/B) sits right at the machine balance -- they should run at
+// the HBM/MFMA corner.  Here:
+//   * persistent workgroups (2 per CU); the whole weight matrix [N][taps*C] is loaded into LDS once
+//     per workgroup (<= 45 KB, padded rows, conflict-free B fragments);
+//   * per block of 128 output rows the input slab (128 + (taps-1)*dil rows x C) goes global -> LDS
+//     ONCE (coalesced float4 loads, rows outside the utterance = the conv's zero padding, the input
+//     leaky-ReLU applied here, once per element instead of once per tap) into rows padded to C+4
+//     floats: tap-shifted ds_read_b128 A fragments are conflict-free and their addresses are linear
+//     in the tap, so the MFMA loop carries ~2 VALU per 16 MFMAs (VALU issue costs matrix-core time);
+//   * all taps are contracted out of LDS with v_mfma_f32_16x16x4_f32 (operands swapped, D = W.A^T,
+//     so the epilogue is float4 along the channels);
+//   * HBM traffic = input once (+ halo) + output once + residual operands: the algorithmic minimum.
+// Blocks never straddle utterances (per-segment block table), so validity is uniform per block.
+#include "gemm.hpp"
+
+namespace ss {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int SL_BM = 128;
+constexpr int SL_MAXSEG = 256;
+
+template <int C, int N, bool LRELU>
+__global__ __launch_bounds__(256, 2) void conv_slab_kernel(const GemmArgs p, const int slab_rows_max) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int BM = SL_BM;
+  constexpr int Q = C / 4;                    // 16-B chunks per row
+  constexpr int TM = BM / 64, TN = N / 16;    // wave tile: 32 rows x N
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = p.taps * C;
+  const int LDW = K + 4;
+  float* sW = smem;                                        // [N][K+4]
+  float* sA = smem + ((N * LDW + 255) & ~255);             // slab [rows][C+4]
+  int* s_blk = reinterpret_cast<int*>(sA + ((slab_rows_max * (C + 4) + 255) & ~255));   // block prefix per segment
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+
+  // weights -> LDS (once per workgroup)
+  for (int idx = t; idx < N * (K / 4); idx += 256) {
+    const int n = idx / (K / 4), k4 = idx - n * (K / 4);
+    *reinterpret_cast<f32x4*>(sW + n * LDW + k4 * 4) = *reinterpret_cast<const f32x4*>(p.W + (size_t)n * K + k4 * 4);
+  }
+  // block table: s_blk[s] = first block of segment s, s_blk[nseg] = total
+  const int nseg = p.nseg > 0 ? p.nseg : 1;
+  if (t == 0) {
+    int acc = 0;
+    for (int s = 0; s < nseg; ++s) {
+      s_blk[s] = acc;
+      const int len = p.nseg > 0 ? p.segs[4 * s + 1] : p.M;
+      acc += (len + BM - 1) / BM;
+    }
+    s_blk[nseg] = acc;
+  }
+  __syncthreads();
+  const int nblocks = s_blk[nseg];
+
+  constexpr int LDA = C + 4;                   // padded slab row (floats): 16 consecutive rows x 16 B hit 16 distinct slots
+  const int slab_rows = BM + (p.taps - 1) * p.dil;
+  const float slope = p.in_slope;
+
+  // The slab of the NEXT block is fetched into registers before the current block is computed, so
+  // the global-load latency hides under the MFMAs (a second LDS slab would halve the occupancy).
+  constexpr int NP = Q;                        // float4 per thread: (BM + 128 halo rows) * Q / 256
+  f32x4 pre[NP];
+  int seg = 0, seg_lo = 0, seg_hi = 0, m0 = 0;
+  auto locate = [&](int blk) {                 // blocks ascend per workgroup
+    while (blk >= s_blk[seg + 1]) ++seg;
+    seg_lo = p.nseg > 0 ? p.segs[4 * seg] : 0;
+    seg_hi = seg_lo + (p.nseg > 0 ? p.segs[4 * seg + 1] : p.in_len);
+    m0 = seg_lo + (blk - s_blk[seg]) * BM;     // first output row (packed coordinates)
+  };
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int idx = t + u * 256;             // Q consecutive threads read one 4C-byte row
+      const int rho = idx / Q, c4 = idx - rho * Q;
+      const int gin = m0 - p.pad + rho;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (rho < slab_rows && gin >= seg_lo && gin < seg_hi)
+        v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gin * p.lda + c4 * 4);
+      pre[u] = v;
+    }
+  };
+  int blk = blockIdx.x;
+  if (blk < nblocks) { locate(blk); prefetch(); }
+  for (; blk < nblocks; blk += gridDim.x) {
+    const int cm0 = m0;
+    const int m_hi = p.nseg > 0 ? seg_hi : min(seg_hi, p.M);
+    __syncthreads();                                       // previous block's slab reads are done
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int idx = t + u * 256;
+      const int rho = idx / Q, c4 = idx - rho * Q;
+      if (rho < slab_rows) {
+        f32x4 v = pre[u];
+        if (LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        }
+        *reinterpret_cast<f32x4*>(sA + rho * LDA + c4 * 4) = v;
+      }
+    }
+    __syncthreads();
+    if (blk + (int)gridDim.x < nblocks) { locate(blk + gridDim.x); prefetch(); }
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const float* pa = sA + (wave * 32 + r) * LDA + 4 * g;  // + i*16*LDA + tap*dil*LDA + cc*16
+    const float* pw = sW + r * LDW + 4 * g;                // + j*16*LDW + tap*C + cc*16
+    const int a_step = p.dil * LDA;
+    for (int tap = 0; tap < p.taps; ++tap) {
+#pragma unroll
+      for (int cc = 0; cc < C / 16; ++cc) {
+        f32x4 af[TM], bf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(pa + i * 16 * LDA + cc * 16);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(pw + j * 16 * LDW + cc * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // D = W.A^T
+      }
+      pa += a_step;
+      pw += C;
+    }
+
+    // epilogue: lane holds 4 consecutive channels (4g..4g+3 of n-tile j) of row r (see conv_sk.hip)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int m = cm0 + wave * 32 + i * 16 + r;
+      if (m >= m_hi) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = j * 16 + g * 4;
+        f32x4 v = acc[i][j];
+        if (p.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          switch (p.act) {
+            case ACT_SILU: v[e] = v[e] / (1.0f + expf(-v[e])); break;
+            case ACT_RELU: v[e] = fmaxf(v[e], 0.f); break;
+            case ACT_TANH: v[e] = tanhf(v[e]); break;
+            case ACT_LRELU: v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope; break;
+            default: break;
+          }
+          v[e] *= p.alpha;
+        }
+        if (p.R) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rr[e];
+        }
+        if (p.R2) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+        }
+        if (p.div > 0.f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / p.div;
+        }
+        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+        if (p.C2) {
+          f32x4 w2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w2[e] = v[e] > 0.f ? v[e] : v[e] * p.c2_slope;
+          *reinterpret_cast<f32x4*>(p.C2 + (size_t)m * p.ldc2 + n) = w2;
+        }
+      }
+    }
+  }
+#endif
+}
+
+bool conv_slab_eligible(const GemmArgs& a) {
+  return a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && (a.Cin == 32 || a.Cin == 16) &&
+         (a.N == 32 || a.N == 16) && a.lda == a.Cin && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) &&
+         (!a.R2 || (a.ldr2 & 3) == 0) && (!a.C2 || (a.ldc2 & 3) == 0) && a.taps >= 1 && a.taps * a.Cin <= 512 &&
+         (a.taps - 1) * a.dil <= 128 &&   // slab <= 256 rows (register prefetch budget)
+         a.nseg <= SL_MAXSEG && a.M > 0 &&
+         ((size_t)(a.M + a.pad + 256) * a.lda) * 4 < 0x7ff00000ull &&
+         (a.in_act == ACT_NONE || a.in_act == ACT_LRELU);
+}
+
+static int g_slab_cus = 0;
+
+template <int C, int N, bool LRELU>
+static int launch_slab_t(const GemmArgs& a, hipStream_t stream, int cls) {
+  const int K = a.taps * C;
+  const int slab_rows = SL_BM + (a.taps - 1) * a.dil;
+  const size_t lds = ((size_t)((N * (K + 4) + 255) & ~255) + (size_t)((slab_rows * (C + 4) + 255) & ~255)) * sizeof(float) +
+                     (SL_MAXSEG + 2) * sizeof(int);
+  if (lds > 80 * 1024) return SS_ERR_ARG;
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_slab_kernel<C, N, LRELU>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_lds = 80 * 1024;
+  }
+  if (!g_slab_cus) {
+    int dev = 0;
+    SS_HIP_CHECK(hipGetDevice(&dev));
+    SS_HIP_CHECK(hipDeviceGetAttribute(&g_slab_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (g_slab_cus <= 0) g_slab_cus = 256;
+  }
+  const int nseg = a.nseg > 0 ? a.nseg : 1;
+  const long long max_blocks = (long long)cdiv(a.M, SL_BM) + nseg;      // upper bound (per-segment round-up)
+  const int occ = (int)std::max<size_t>(2, std::min<size_t>(6, (150 * 1024) / lds));   // resident workgroups per CU (LDS-limited)
+  const int grid = (int)std::min<long long>((long long)occ * g_slab_cus, std::max<long long>(1, max_blocks));
+  ProfRec rec{}; bool prof = false;
+  int rc = prof_begin(a, stream, cls, rec, prof);
+  if (rc != SS_OK) return rc;
+  hipLaunchKernelGGL((conv_slab_kernel<C, N, LRELU>), dim3(grid), dim3(256), lds, stream, a, slab_rows);
+  SS_LAUNCH_CHECK();
+  return prof_end(stream, rec, prof);
+}
+
+int launch_conv_slab(const GemmArgs& a, hipStream_t stream) {
+  if (!conv_slab_eligible(a)) return SS_ERR_ARG;
+  const bool lr = a.in_act == ACT_LRELU;
+#define SS_SLAB(C_, N_, CLS_) \
+  if (a.Cin == C_ && a.N == N_) return lr ? launch_slab_t<C_, N_, true>(a, stream, CLS_) : launch_slab_t<C_, N_, false>(a, stream, CLS_);
+  SS_SLAB(32, 32, 16) SS_SLAB(16, 16, 17) SS_SLAB(32, 16, 16) SS_SLAB(16, 32, 17)
+#undef SS_SLAB
+  return SS_ERR_ARG;
+}
+
+}  // namespace ss

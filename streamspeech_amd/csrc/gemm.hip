@@ -431,7 +431,8 @@ static const char* kTileNames[kNumTileCfg] = {
     "conv_gemm<128,16,16,4,1>", "conv_gemm<128,32,32,4,1>", "conv_gemm<128,32,16,4,1>", "conv_gemm<16,128,32,1,4>",
     "conv_gemm<16,128,16,1,4>", "conv_gemm<128,128,16,2,2>", "conv_gemm<128,64,32,2,2>", "conv_gemm<64,64,32,2,2>",
     "conv_gemm<64,64,16,2,2>", "conv_gemm<32,64,32,2,2>", "conv_gemm<32,64,16,2,2>", "conv_gemm<32,32,32,2,2>",
-    "smallm_gemm<4,1>", "smallm_gemm<2,2>", "smallm_gemm<1,4>", "conv_sk<128,BN,32>"};
+    "smallm_gemm<4,1>", "smallm_gemm<2,2>", "smallm_gemm<1,4>", "conv_sk<128,BN,32>",
+    "conv_slab<32>", "conv_slab<16>"};
 static int g_prof_mask = 0;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
@@ -596,6 +597,8 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
       default: break;
     }
   }
+  // narrow vocoder stages: weights + input slab in LDS, one HBM pass (conv_slab.hip)
+  if (g_force_bm != 2 && conv_slab_eligible(a) && a.M >= 2048) return launch_conv_slab(a, stream);
   if (a.N <= 16) return launch_cfg_ks<128, 16, 16, 4, 1, 2>(a, stream, 0, (long)cdiv(M, 128) * nseg);
   if (a.N <= 32 && !a.glu) {
     const long tl = (long)cdiv(M, 128) * nseg;

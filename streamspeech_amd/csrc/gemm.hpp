@@ -59,7 +59,7 @@ struct GemmArgs {
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 16;
+constexpr int kNumTileCfg = 18;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
@@ -75,7 +75,12 @@ int prof_end(hipStream_t stream, ProfRec& rec, bool prof);
 // the tile count.  g_force > 0 fixes the grid size (tuning hook).
 bool conv_sk_eligible(const GemmArgs& a);
 int launch_conv_sk(const GemmArgs& a, hipStream_t stream, int g_force = 0);
-int conv_sk_error_count();   // number of bounded-spin time-outs seen so far (must stay 0)
+int conv_sk_error_count();
+
+// Slab conv for the narrow vocoder stages (conv_slab.hip): C, N in {16, 32}, weights + input slab in LDS.
+bool conv_slab_eligible(const GemmArgs& a);
+int launch_conv_slab(const GemmArgs& a, hipStream_t stream);
+   // number of bounded-spin time-outs seen so far (must stay 0)
 
 // True when launch_conv_gemm would route `a` to the small-M kernel (the only one with the fused
 // LayerNorm prologue).

@@ -250,3 +250,31 @@ def test_stream_k_conv_matches_torch(lib, M, N, Cin, taps, dil, G):
     assert torch.equal(got, got2), "stream-K must be deterministic run to run"
     assert (plain - _conv_ref(A, W.reshape(N, -1) if taps == 1 else W, None, taps, dil)).abs().max() < TOL
 
+
+
+# ---- slab conv for the narrow vocoder stages (conv_slab.hip) -------------------------------------
+@pytest.mark.parametrize("M,C,N,taps,dil,lrelu", [
+    (5000, 32, 32, 11, 5, True), (5000, 32, 32, 3, 1, False), (4099, 16, 16, 11, 5, True), (2048, 16, 16, 7, 3, True),
+    (3001, 32, 32, 3, 1, True), (2500, 16, 16, 3, 5, False), (70000, 16, 16, 7, 1, True)])
+def test_slab_conv_matches_torch(lib, M, C, N, taps, dil, lrelu):
+    """Default dispatch routes these (C, N in {16,32}, same-length) to conv_slab; all epilogue options on."""
+    from streamspeech_amd.weights import conv_tap_major
+    A = rnd(M, C, seed=21)
+    W = rnd(N, C, taps, seed=22, scale=(C * taps) ** -0.5)
+    b, R, R2 = rnd(N, seed=23, scale=0.1), rnd(M, N, seed=24), rnd(M, N, seed=25)
+    Wp = conv_tap_major(W)
+    pad = dil * (taps - 1) // 2
+    got = run_conv_gemm(lib, A, Wp, b, M, N, C, taps=taps, dil=dil, pad=pad, in_act=3 if lrelu else 0, slope=0.1,
+                        div=3.0, R=R, R2=R2)
+    ref = (R2 + (_conv_ref(A, W, b, taps, dil, 0.1 if lrelu else None) + R)) / 3.0
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() < TOL, f"max err {(got - ref).abs().max()}"
+    lib.ss_debug_force_tile(2, 0, 0)       # same call on the LDS-tiled kernel: results agree to rounding
+    try:
+        old = run_conv_gemm(lib, A, Wp, b, M, N, C, taps=taps, dil=dil, pad=pad, in_act=3 if lrelu else 0, slope=0.1,
+                            div=3.0, R=R, R2=R2)
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)
+    assert (got - old).abs().max() < 1e-5
+    plain = run_conv_gemm(lib, A, Wp, None, M, N, C, taps=taps, dil=dil, pad=pad, act=3)   # LRELU epilogue, no bias
+    assert (plain - F.leaky_relu(_conv_ref(A, W, None, taps, dil), 0.1)).abs().max() < TOL

@@ -3,7 +3,7 @@
 set -e
 cd "$(dirname "$0")/../streamspeech_amd/csrc"
 mkdir -p build/ablate
-for f in gemm conv_sk attention elementwise fbank model; do
+for f in gemm conv_sk conv_slab attention elementwise fbank model; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DSS_ABLATE -c $f.hip -o build/ablate/$f.o 2>/dev/null &
 done
 wait

@@ -98,7 +98,25 @@ def sweep_sk():
     print("sk errors:", lib.ss_debug_sk_errors())
 
 
+def sweep_slab():
+    """narrow vocoder stages: slab kernel (default dispatch) vs the LDS-tiled kernels (force code 2)."""
+    shapes = [("stage3 k11 b16", 576000, 32, 32, 11), ("stage3 k7 b16", 576000, 32, 32, 7), ("stage3 k3 b16", 576000, 32, 32, 3),
+              ("stage4 k11 b16", 1152000, 16, 16, 11), ("stage4 k7 b16", 1152000, 16, 16, 7), ("stage4 k3 b16", 1152000, 16, 16, 3),
+              ("up4 b16", 576000, 32, 32, 3), ("stage3 k11 b1", 36000, 32, 32, 11), ("stage4 k3 b1", 72000, 16, 16, 3)]
+    print("%-16s%10s%10s   GFLOP  slab TF  slab GB/s (in+out)" % ("shape", "slab", "tiled"))
+    for name, M, N, Cin, taps in shapes:
+        lib.ss_debug_force_tile(0, 0, 0)
+        a = bench(name, M, N, Cin, taps, 1, reps=5)
+        lib.ss_debug_force_tile(2, 0, 0)
+        b = bench(name, M, N, Cin, taps, 1, reps=5)
+        print("%-16s%10.1f%10.1f   %5.2f   %6.1f   %7.0f" % (name, a["us"], b["us"], a["gflop"], a["tflops"],
+                                                            4.0 * M * (N + Cin) / (a["us"] * 1e-6) / 1e9), flush=True)
+    lib.ss_debug_force_tile(0, 0, 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "slab":
+        return sweep_slab()
     if len(sys.argv) > 1 and sys.argv[1] == "sk":
         return sweep_sk()
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
