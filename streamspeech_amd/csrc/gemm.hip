@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // D = W.A^T (see epilogue)
         }
 #ifdef SS_ABLATE
         if (!(p.dbg & 4))
@@ -235,53 +235,96 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
       default: return v;
     }
   };
+  // The MFMAs are issued with the operands swapped (D = W_tile . A_tile^T): in the C/D layout
+  // (col = lane&15, row = 4*(lane>>4) + reg) a lane then holds 4 CONSECUTIVE output channels
+  // n = 4g..4g+3 of ONE row m = r, so bias / residual / output move as float4 whenever the leading
+  // dimensions allow it (4x fewer memory instructions; scalar fallback otherwise, e.g. N = 1005).
   if (p.glu) {
     if constexpr (TN % 2 == 0) {
+      const bool vec = (p.ldc & 3) == 0;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + r;
+        if (m >= out_len) continue;
+        float* crow = p.C + (size_t)(out_start + m) * p.ldc;
 #pragma unroll
         for (int j = 0; j < TN; j += 2) {
           const int ncol = n0 + wn * WTN + j * 16;      // start of the [value|gate] 32-col block
-          const int oc = ncol / 2 + r;                    // output channel
-          if (ncol + 16 + r < p.N) {
-            const float bv = p.bias ? p.bias[ncol + r] : 0.f;
-            const float bg = p.bias ? p.bias[ncol + 16 + r] : 0.f;
+          if (ncol + 31 >= p.N) continue;
+          const int oc = ncol / 2 + g * 4;              // first of this lane's 4 output channels
+          f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int m = m0 + wm * WTM + i * 16 + g * 4 + e;
-              if (m < out_len) {
-                const float val = acc[i][j][e] + bv;
-                const float gate = acc[i][j + 1][e] + bg;
-                p.C[(size_t)(out_start + m) * p.ldc + oc] = val * (1.0f / (1.0f + expf(-gate)));
-              }
-            }
+          for (int e = 0; e < 4; ++e) {
+            const float bv = p.bias ? p.bias[ncol + g * 4 + e] : 0.f;
+            const float bg = p.bias ? p.bias[ncol + 16 + g * 4 + e] : 0.f;
+            const float val = acc[i][j][e] + bv;
+            const float gate = acc[i][j + 1][e] + bg;
+            o[e] = val * (1.0f / (1.0f + expf(-gate)));
           }
-        }
-    }
-    return;
-  }
+          if (vec) *reinterpret_cast<f32x4*>(crow + oc) = o;
+          else {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = n0 + wn * WTN + j * 16 + r;
-      if (n < p.N) {
-        const float b = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int m = m0 + wm * WTM + i * 16 + g * 4 + e;
-          if (m < out_len) {
-            const size_t row = (size_t)(out_start + m);
-            float v = activate(acc[i][j][e] + b) * p.alpha;
-            if (p.R) v += p.R[row * p.ldr + n];
-            if (p.R2) v = p.R2[row * p.ldr2 + n] + v;
-            if (p.div > 0.f) v = v / p.div;
-            p.C[row * p.ldc + n] = v;
-            if (p.C2) p.C2[row * p.ldc2 + n] = v > 0.f ? v : v * p.c2_slope;
+            for (int e = 0; e < 4; ++e) crow[oc + e] = o[e];
           }
         }
       }
     }
+    return;
+  }
+  const bool vec = ((p.ldc | (p.R ? p.ldr : 0) | (p.R2 ? p.ldr2 : 0) | (p.C2 ? p.ldc2 : 0) | p.N) & 3) == 0;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = m0 + wm * WTM + i * 16 + r;
+    if (m >= out_len) continue;
+    const size_t row = (size_t)(out_start + m);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + g * 4;
+      if (n >= p.N) continue;
+      f32x4 v = acc[i][j];
+      if (vec) {
+        if (p.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += b[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = activate(v[e]) * p.alpha;
+        if (p.R) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + row * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += rr[e];
+        }
+        if (p.R2) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R2 + row * p.ldr2 + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+        }
+        if (p.div > 0.f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / p.div;
+        }
+        *reinterpret_cast<f32x4*>(p.C + row * p.ldc + n) = v;
+        if (p.C2) {
+          f32x4 w2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w2[e] = v[e] > 0.f ? v[e] : v[e] * p.c2_slope;
+          *reinterpret_cast<f32x4*>(p.C2 + row * p.ldc2 + n) = w2;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= p.N) continue;
+          float x = activate(v[e] + (p.bias ? p.bias[n + e] : 0.f)) * p.alpha;
+          if (p.R) x += p.R[row * p.ldr + n + e];
+          if (p.R2) x = p.R2[row * p.ldr2 + n + e] + x;
+          if (p.div > 0.f) x = x / p.div;
+          p.C[row * p.ldc + n + e] = x;
+          if (p.C2) p.C2[row * p.ldc2 + n + e] = x > 0.f ? x : x * p.c2_slope;
+        }
+      }
+    }
+  }
 }
 
 
