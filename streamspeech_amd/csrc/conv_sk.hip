@@ -33,11 +33,12 @@ typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
 struct SkArgs {
   float* ws;            // [G][128*BN] partial tiles
-  unsigned* sync;       // [0] ticket counter, [1] time-out counter, [16 + w] flag of logical workgroup w
+  unsigned* sync;       // [0..7] ticket counter of XCD group x, [8] time-out counter, [16 + w] flag of logical workgroup w
   const float* zeros;   // >= 16 B of zeros
-  unsigned base;        // ticket value of logical workgroup 0 of this launch
+  unsigned base[8];     // ticket value of rank 0 of each group for this launch
   unsigned epoch;       // flag value meaning "partial of this launch is in place"
-  int G;
+  int G;                // workgroups (multiple of NG)
+  int NG;               // 8: tiles are split over the 8 XCDs first (workgroup i runs on XCD i % 8), 1: no grouping
 };
 
 constexpr int SK_BM = 128, SK_BK = 32, SK_FLAG0 = 16, SK_MAXG = 512;
@@ -62,18 +63,29 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 15, g = lane >> 4;
 
-  if (t == 0) s_misc[0] = (int)(atomicAdd(q.sync, 1u) - q.base);
+  // XCD grouping: the hardware deals workgroup i to XCD i % 8, each XCD has its own L2.  Whole tiles
+  // are first split over 8 groups and stream-K runs inside a group, so the N tiles of an M tile and
+  // the neighbouring M tiles (shared conv halo rows, the tile's A rows re-read per tap) hit one L2,
+  // and no fix-up crosses XCDs.  The grouping only steers locality: correctness needs nothing from
+  // the hardware mapping (each group has its own ticket counter and exactly G/NG members).
+  const int grp = q.NG > 1 ? (int)(blockIdx.x & 7) : 0;
+  const int Gg = q.G / q.NG;
+  if (t == 0) s_misc[0] = (int)(atomicAdd(q.sync + grp, 1u) - q.base[grp]);
   __syncthreads();
-  const int w = __builtin_amdgcn_readfirstlane(s_misc[0]);
+  const int rank = __builtin_amdgcn_readfirstlane(s_misc[0]);
+  const int w = grp * Gg + rank;                 // logical id: workspace slot / flag index
 
   const int kpt = p.Cin / BK;
   const int nk = p.taps * kpt;
   const int Ktot = p.taps * p.Cin;
   const int tiles_n = p.N / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
-  const long long U = (long long)tiles_m * tiles_n * nk;
-  const long long u0 = (long long)w * U / q.G;
-  long long ue = (long long)(w + 1) * U / q.G;     // the range is walked from its END: see below
+  const long long tiles = (long long)tiles_m * tiles_n;
+  const long long t_lo = tiles * grp / q.NG, t_hi = tiles * (grp + 1) / q.NG;
+  const long long ubase = t_lo * nk;               // first unit of the group
+  const long long U = (t_hi - t_lo) * nk;          // units of the group, split over its Gg workgroups
+  const long long u0 = ubase + (long long)rank * U / Gg;
+  long long ue = ubase + (long long)(rank + 1) * U / Gg;     // the range is walked from its END: see below
 
   const float slope = p.in_slope;
   // Buffer resources for the LDS-DMA loads: per-lane byte offsets stay constant over a tile and the
@@ -144,7 +156,10 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
       const int nrow = wave * (BN / 4) + j * 8 + st_row;
       w_off[j] = (unsigned)(((n0 + nrow) * Ktot + ((st_pos ^ ((nrow >> 1) & 7)) << 2)) * 4);
     }
-    int ntap = ka / kpt, nci = (ka - ntap * kpt) * BK;     // (tap, channel offset) of the next step to stage
+    // k-step s = (channel block s / taps, tap s % taps): the taps of one 32-channel block run back to
+    // back, so the (128 + halo) x 128-B slab of A rows they share is re-read from L1/L2 while it is
+    // still there (tap-major order put 2 MB of other traffic per XCD between two reads of a row).
+    int nci = (ka / p.taps) * BK, ntap = ka - (ka / p.taps) * p.taps;     // of the next step to stage
     auto issue = [&](int kstep, int stage) {
       float* sA = smem + stage * STAGE + (wave * 32) * BK;
       float* sW = smem + stage * STAGE + BM * BK + (wave * (BN / 4)) * BK;
@@ -156,12 +171,11 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
         const bool ok = rin >= a_lo[j] && rin < a_hi[j];
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + j * 8 * BK), 16, ok ? a_off[j] : SK_OOB, soffA, 0, 0);
       }
-      const int soffW = kstep * BK * 4;
+      const int soffW = (ntap * p.Cin + nci) * 4;
 #pragma unroll
       for (int j = 0; j < NWI; ++j)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sW + j * 8 * BK), 16, w_off[j], soffW, 0, 0);
-      nci += BK;
-      if (nci >= p.Cin) { nci = 0; ++ntap; }
+      if (++ntap >= p.taps) { ntap = 0; nci += BK; }
     };
 
     f32x4 acc[TM][TN];
@@ -241,13 +255,13 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
 #endif
     if (ka > 0) {
       // ---- finisher: collect the partials of the workgroups that own k-steps [0, ka) of this tile ----
-      const int wf = (int)(((ut0 + 1) * q.G - 1) / U);                // workgroup that owns the tile's first unit
+      const int wf = grp * Gg + (int)(((ut0 - ubase + 1) * Gg - 1) / U);   // workgroup (of this group) that owns the tile's first unit
       if (t == 0) {
         for (int ww = wf; ww < w; ++ww) {
           unsigned spins = 0;
           while (__hip_atomic_load(q.sync + SK_FLAG0 + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q.epoch) {
             __builtin_amdgcn_s_sleep(8);
-            if (++spins > SK_SPIN_LIMIT) { atomicAdd(q.sync + 1, 1u); break; }
+            if (++spins > SK_SPIN_LIMIT) { atomicAdd(q.sync + 8, 1u); break; }
           }
         }
       }
@@ -330,11 +344,15 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
 struct SkState {
   float* ws = nullptr;
   unsigned* sync = nullptr;
-  unsigned base = 0, epoch = 0;
+  unsigned base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned epoch = 0;
 };
 static std::map<hipStream_t, SkState> g_sk;
 static std::mutex g_sk_mu;
 static int g_sk_cus = 0;
+static int g_sk_groups = 0;   // XCD tile grouping: measured neutral on time and -6 % on L2 misses (profiles/r01_sk_sweep.txt), so off;
+                              // tools: debug_force_tile(1, 8, g) switches it on
+void conv_sk_set_groups(int on) { g_sk_groups = on; }
 constexpr size_t SK_SYNC_BYTES = (SK_FLAG0 + SK_MAXG) * sizeof(unsigned) + 256;
 
 static int sk_state(hipStream_t stream, SkState** out) {
@@ -368,7 +386,7 @@ int conv_sk_error_count() {
   int total = 0;
   for (auto& kv : g_sk) {
     unsigned v = 0;
-    if (kv.second.sync && hipMemcpy(&v, kv.second.sync + 1, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) total += (int)v;
+    if (kv.second.sync && hipMemcpy(&v, kv.second.sync + 8, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) total += (int)v;
   }
   return total;
 }
@@ -392,11 +410,15 @@ static int launch_sk(const GemmArgs& a, hipStream_t stream, int g_force) {
   if (G > U / 8) G = U / 8;
   if (G < 1) G = 1;
   if (G > SK_MAXG) G = SK_MAXG;
+  const long long tiles = (long long)cdiv(a.M, SK_BM) * (a.N / BN);
+  const int NG = (g_sk_groups && G >= 64 && tiles >= 64) ? 8 : 1;
+  if (NG > 1) G -= G % NG;
   SkArgs q;
   q.ws = st->ws; q.sync = st->sync;
   q.zeros = reinterpret_cast<const float*>(st->sync + SK_FLAG0 + SK_MAXG);
-  q.base = st->base; q.epoch = ++st->epoch; q.G = (int)G;
-  st->base += (unsigned)G;
+  q.epoch = ++st->epoch; q.G = (int)G; q.NG = NG;
+  for (int x = 0; x < 8; ++x) q.base[x] = st->base[x];
+  for (int x = 0; x < NG; ++x) st->base[x] += (unsigned)(G / NG);
   ProfRec rec{}; bool prof = false;
   rc = prof_begin(a, stream, 15, rec, prof);
   if (rc != SS_OK) return rc;

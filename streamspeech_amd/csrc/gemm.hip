@@ -575,7 +575,7 @@ static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 static double g_sk_min_flops = 4e9;   // below this the small-tile kernels win (tools/conv_bench.py sk)
-void debug_force_tile(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn; g_force_ks = ks; }
+void debug_force_tile(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn; g_force_ks = ks; conv_sk_set_groups(bm == 1 && bn == 8); }
 
 bool smallm_eligible(const GemmArgs& a) {
   if (g_force_bm > 1) return false;

@@ -76,6 +76,7 @@ int prof_end(hipStream_t stream, ProfRec& rec, bool prof);
 bool conv_sk_eligible(const GemmArgs& a);
 int launch_conv_sk(const GemmArgs& a, hipStream_t stream, int g_force = 0);
 int conv_sk_error_count();
+void conv_sk_set_groups(int on);   // tuning hook: XCD tile grouping on/off
 
 // Slab conv for the narrow vocoder stages (conv_slab.hip): C, N in {16, 32}, weights + input slab in LDS.
 bool conv_slab_eligible(const GemmArgs& a);

@@ -225,7 +225,7 @@ def _conv_ref(A, W, b, taps, dil, slope=None):
 @pytest.mark.parametrize("M,N,Cin,taps,dil,G", [
     (1000, 256, 256, 11, 5, 0), (1000, 256, 256, 11, 5, 37), (1000, 256, 256, 3, 1, 512), (777, 128, 128, 7, 3, 200),
     (5001, 64, 64, 11, 1, 0), (5001, 64, 64, 3, 5, 97), (300, 1280, 512, 3, 1, 0), (129, 128, 64, 1, 1, 3),
-    (40, 64, 32, 1, 1, 1)])
+    (40, 64, 32, 1, 1, 1), (9000, 256, 128, 7, 3, -8)])
 def test_stream_k_conv_matches_torch(lib, M, N, Cin, taps, dil, G):
     """Every fix-up shape: tiles split over 2..many workgroups, ranges inside one tile, G = 1 (no split),
     ragged last M tile; leaky-ReLU input, bias, both residuals and the MRF division in the epilogue."""
@@ -234,7 +234,7 @@ def test_stream_k_conv_matches_torch(lib, M, N, Cin, taps, dil, G):
     W = rnd(N, Cin, taps, seed=12, scale=(Cin * taps) ** -0.5)
     b, R, R2 = rnd(N, seed=13, scale=0.1), rnd(M, N, seed=14), rnd(M, N, seed=15)
     Wp = conv_tap_major(W) if taps > 1 else W.view(N, Cin)
-    lib.ss_debug_force_tile(1, 0, G)
+    lib.ss_debug_force_tile(1, 8 if G < 0 else 0, max(G, 0))     # G = -8: XCD tile grouping on
     try:
         got = run_conv_gemm(lib, A, Wp, b, M, N, Cin, taps=taps, dil=dil, pad=dil * (taps - 1) // 2, in_act=3, slope=0.1,
                             div=3.0, R=R, R2=R2)

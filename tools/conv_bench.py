@@ -84,7 +84,7 @@ def sweep_sk():
               ("up2 b16", 72000, 256, 128, 3), ("stage0 k11 b4", 4500, 256, 256, 11), ("stage0 k11 b1", 1125, 256, 256, 11),
               ("stage1 k7 b1", 4500, 128, 128, 7), ("stage2 k3 b1", 18000, 64, 64, 3), ("up0 b1", 225, 1280, 512, 3),
               ("unit fc1 b16", 6800, 2048, 512, 1), ("unit fc2 b16", 6800, 512, 2048, 1)]
-    cfgs = [("heur", 0, 0, 0), ("32x64", 32, 64, 11), ("sk auto", 1, 0, 0), ("sk 256", 1, 0, 256), ("sk 384", 1, 0, 384)]
+    cfgs = [("heur", 0, 0, 0), ("32x64", 32, 64, 11), ("sk auto", 1, 0, 0), ("sk XCDgrp", 1, 8, 0), ("sk 256", 1, 0, 256)]
     print("%-16s" % "shape" + "".join("%10s" % c[0] for c in cfgs) + "   GFLOP   best TF")
     for name, M, N, Cin, taps in shapes:
         line, best = "%-16s" % name, 1e9

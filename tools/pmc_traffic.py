@@ -1,0 +1,54 @@
+"""Summarise two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, each collected alone with
+--kernel-trace --output-format csv, as MI355X_MICROARCH.md §HBM prescribes) into per-kernel and
+per-profiler-class HBM bytes per launch -> profiles/*_pmc_traffic.json (read by bench.py).
+
+  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<note>"
+
+Units: the counters report KB.  gfx950 correction (guide): FETCH_SIZE counts 128-B requests as 64 B
+for wide coalesced reads -> HBM read bytes ~= 2 * FETCH_SIZE * 1024; WRITE_SIZE is taken as is."""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+CLASSES = [("void ss::conv_sk_kernel", "conv_sk<128,BN,32>"), ("void ss::conv_slab_kernel<32", "conv_slab<32>"),
+           ("void ss::conv_slab_kernel<16", "conv_slab<16>"),
+           ("void ss::conv_gemm_kernel<32, 64, 32", "conv_gemm<32,64,32,2,2>"), ("void ss::conv_gemm_kernel<32, 32, 32", "conv_gemm<32,32,32,2,2>"),
+           ("void ss::conv_gemm_kernel<128, 32, 32", "conv_gemm<128,32,32,4,1>"), ("void ss::conv_gemm_kernel<128, 16, 16", "conv_gemm<128,16,16,4,1>"),
+           ("void ss::smallm_gemm_kernel<4, 1", "smallm_gemm<4,1>")]
+
+
+def read(path, counter):
+    tot, n = defaultdict(float), defaultdict(int)
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == counter:
+                tot[row["Kernel_Name"]] += float(row["Counter_Value"])
+                n[row["Kernel_Name"]] += 1
+    return tot, n
+
+
+def main():
+    fetch, nf = read(sys.argv[1], "FETCH_SIZE")
+    write, nw = read(sys.argv[2], "WRITE_SIZE")
+    kernels, classes = {}, {}
+    for k in fetch:
+        if not k.startswith(("void ss::", "ss::")) or nf[k] == 0:
+            continue
+        f_kb = fetch[k] / nf[k]
+        w_kb = write.get(k, 0.0) / max(1, nw.get(k, 0))
+        kernels[k] = {"launches": nf[k], "fetch_kb_per_launch": round(f_kb, 1), "write_kb_per_launch": round(w_kb, 1),
+                      "hbm_mbytes_per_launch_corrected": round((2 * f_kb + w_kb) * 1024 / 1e6, 2)}
+    for prefix, cls in CLASSES:
+        ks = [k for k in kernels if k.startswith(prefix)]
+        n = sum(kernels[k]["launches"] for k in ks)
+        if n:
+            classes[cls] = {"launches": n, "hbm_mbytes_per_launch_corrected": round(
+                sum(kernels[k]["hbm_mbytes_per_launch_corrected"] * kernels[k]["launches"] for k in ks) / n, 2)}
+    top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_mbytes_per_launch_corrected"] * kv[1]["launches"])[:16])
+    json.dump({"note": sys.argv[4] if len(sys.argv) > 4 else "", "classes": classes, "kernels": top}, open(sys.argv[3], "w"), indent=1)
+    print(json.dumps(classes, indent=1))
+
+
+if __name__ == "__main__":
+    main()
