@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
 #ifdef SS_ABLATE
       if (!(p.dbg & 1))
 #endif
-      if (valid && w_ok[i]) v = *reinterpret_cast<const f32x4*>(p.W + w_off[i] + (size_t)kb * BK);
+      if (valid && w_ok[i]) v = *reinterpret_cast<const f32x4*>(p.W + w_off[i] + (size_t)tap * p.Cin + ci0);
       rw[sl][i] = v;
     }
   };
@@ -143,9 +143,11 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
   const int kper = (nk + KS - 1) / KS;
   const int kb0 = kg * kper;
   const int kb1 = min(nk, kb0 + kper);
-  int ntap = kb0 / kpt;                      // (tap, channel offset) of the next step to load
-  int nci = (kb0 - ntap * kpt) * BK;
-  auto advance = [&]() { nci += BK; if (nci >= p.Cin) { nci = 0; ++ntap; } };
+  // k-step s = (channel block s / taps, tap s % taps): the taps of one channel block run back to back
+  // so the tile's A rows are re-read while still in L1/L2 (see conv_sk.hip)
+  int nci = (kb0 / p.taps) * BK;             // (tap, channel offset) of the next step to load
+  int ntap = kb0 - (kb0 / p.taps) * p.taps;
+  auto advance = [&]() { if (++ntap >= p.taps) { ntap = 0; nci += BK; } };
   auto for_slots = [&](auto&& fn) {          // fn(integral_constant<u>) for u = 0..PD-1
     fn(std::integral_constant<int, 0>{});
     if constexpr (PD > 1) fn(std::integral_constant<int, 1>{});
