@@ -11,6 +11,9 @@
 
 namespace ss {
 
+static int g_attn_no_mfma = 0;   // test hook: route plain attention to the VALU kernel
+void attention_debug_no_mfma(int v) { g_attn_no_mfma = v; }
+
 constexpr int QB = 16;     // query rows per workgroup
 constexpr int KT = 64;     // keys per tile
 constexpr int DH = 64;     // head dim
@@ -226,6 +229,151 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(AttnArgs p) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// MFMA form (plain attention, Tq > 8): QK^T and PV on v_mfma_f32_16x16x4_f32, online softmax on the
+// accumulator fragments.  Workgroup = 64 queries x 1 head (4 waves x 16 queries), 64-key tiles of K
+// and V^T in LDS shared by the 4 waves.
+//
+// Fragment algebra (C/D layout: col = lane&15, row = 4*(lane>>4) + reg; lane = (r, g)):
+//   S^T = K . Q^T : A = K rows (lane (r,g) reads K[key r][16kk+4g .. +3] with one ds_read_b128 --
+//     MFMA e then contracts d = {16kk+4g'+e}, a permutation of d shared with the Q operand),
+//     B = Q rows held in registers.  The tile comes out as lane (r = query, g) holding the scores of
+//     keys 4g..4g+3: a query's row lives in the 4 lanes {r, r+16, r+32, r+48} -> row max / sum are
+//     2 shuffles, no LDS.
+//   O^T = V^T . P^T : B = P^T is EXACTLY what the lane already holds (MFMA e takes keys {4g'+e}),
+//     A = V^T[d = r][keys 4g..4g+3] is one ds_read_b128 from the transposed V tile.  The output
+//     comes out as lane (r = query, g) holding d = 16dt+4g..+3 -> float4 stores.
+// Same arithmetic as the reference fairseq MHA (ctc_unity/modules/multihead_attention.py:544-760):
+// fp32 scores, -inf masks (causal / key padding), softmax, PV; only the summation order differs.
+// -------------------------------------------------------------------------------------------------
+constexpr int MQ = 64;              // queries per workgroup
+constexpr int LDT = 68;             // padded LDS row (floats): 17 sixteen-byte slots -> conflict-free b128 fragments
+
+__global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs p) {
+  if (p.nseg > 0) {
+    const int* sg = p.segs + 4 * blockIdx.z;
+    p.Tq = sg[1]; p.Tk = sg[3];
+    if ((int)blockIdx.x * MQ >= p.Tq) return;
+    p.Q += (size_t)sg[0] * p.ldq; p.O += (size_t)sg[0] * p.ldo;
+    p.K += (size_t)sg[2] * p.ldk; p.V += (size_t)sg[2] * p.ldv;
+  }
+  __shared__ __attribute__((aligned(16))) float Ks[KT * LDT];     // [key][d]
+  __shared__ __attribute__((aligned(16))) float Vt[DH * LDT];     // [d][key]
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, hoff = h * DH;
+  const int i0 = blockIdx.x * MQ;
+  const int qoff = p.Tk - p.Tq;
+  const int iq = i0 + wave * 16 + r;                 // this lane's query row
+  const bool q_ok = iq < p.Tq;
+
+  f32x4 qf[4];                                        // Q[iq][16kk + 4g .. +3]
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    qf[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (q_ok) qf[kk] = *reinterpret_cast<const f32x4*>(p.Q + (size_t)iq * p.ldq + hoff + 16 * kk + 4 * g);
+  }
+  f32x4 o[4];                                         // O^T fragments: d = 16dt + 4g + e for query r
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  int kmax = p.Tk - p.k_mask_tail;                    // block-uniform loop bound
+  const int ilast = min(i0 + MQ, p.Tq) - 1;
+  if (p.causal) kmax = min(kmax, ilast + qoff + 1);
+  if (p.chunk > 0) kmax = min(kmax, (ilast / p.chunk + 1) * p.chunk);
+  int lim = p.Tk - p.k_mask_tail;                     // this lane's own visibility bound
+  if (p.causal) lim = min(lim, iq + qoff + 1);
+  if (p.chunk > 0) lim = min(lim, (iq / p.chunk + 1) * p.chunk);
+  if (!q_ok) lim = 0;
+
+  for (int j0 = 0; j0 < kmax; j0 += KT) {
+    __syncthreads();                                  // previous tile fully consumed
+    for (int f = t; f < KT * (DH / 4); f += 256) {
+      const int row = f >> 4, c4 = (f & 15) * 4;      // 16 threads per key row (256 contiguous bytes)
+      const int j = j0 + row;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+      if (j < p.Tk) {
+        kv = *reinterpret_cast<const f32x4*>(p.K + (size_t)j * p.ldk + hoff + c4);
+        vv = *reinterpret_cast<const f32x4*>(p.V + (size_t)j * p.ldv + hoff + c4);
+      }
+      *reinterpret_cast<f32x4*>(Ks + row * LDT + c4) = kv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Vt[(c4 + c) * LDT + row] = vv[c];
+    }
+    __syncthreads();
+
+    // S^T tiles: s[kt][e] = score(query iq, key j0 + 16kt + 4g + e)
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (kt * 16 + r) * LDT + 16 * kk + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[kk][e], s[kt], 0, 0, 0);
+      }
+    }
+    // mask, running max / sum over the query's 4 lanes
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + kt * 16 + 4 * g + e;
+        s[kt][e] = (j < lim) ? s[kt][e] * p.scale : -INFINITY;
+        mt = fmaxf(mt, s[kt][e]);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m_run, mt);
+    float corr = 1.f, ls = 0.f;
+    if (mn > -INFINITY) {
+      corr = (m_run > -INFINITY) ? expf(m_run - mn) : 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = (s[kt][e] > -INFINITY) ? expf(s[kt][e] - mn) : 0.f;
+          s[kt][e] = pe;
+          ls += pe;
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * corr + ls;
+    m_run = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[dt][e] *= corr;
+    // O^T += V^T . P^T
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (dt * 16 + r) * LDT + kt * 16 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], s[kt][e], o[dt], 0, 0, 0);
+      }
+  }
+  if (q_ok) {
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 v = o[dt];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= inv;
+      *reinterpret_cast<f32x4*>(p.O + (size_t)iq * p.ldo + hoff + 16 * dt + 4 * g) = v;
+    }
+  }
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   const int tq = a.nseg > 0 ? a.max_q : a.Tq;
   if (tq <= 0 || (a.nseg == 0 && a.Tk <= 0)) return SS_OK;
@@ -234,6 +382,11 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if (a.q0 != 0 && (a.nseg > 0 || a.causal)) return SS_ERR_ARG;
   if (!a.P && tq <= 8 && a.q0 == 0) {
     hipLaunchKernelGGL(attention_decode_kernel, dim3(tq, a.H, gz), dim3(256), 0, stream, a);
+    SS_LAUNCH_CHECK();
+    return SS_OK;
+  }
+  if (!a.P && a.q0 == 0 && !g_attn_no_mfma && ((a.ldq | a.ldo) & 3) == 0) {
+    hipLaunchKernelGGL(attention_mfma_kernel, dim3(cdiv(tq, MQ), a.H, gz), dim3(256), 0, stream, a);
     SS_LAUNCH_CHECK();
     return SS_OK;
   }

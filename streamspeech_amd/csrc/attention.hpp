@@ -32,5 +32,6 @@ struct AttnArgs {
 };
 
 int launch_attention(const AttnArgs& a, hipStream_t stream);
+void attention_debug_no_mfma(int v);   // test hook: 1 routes plain attention to the VALU kernel
 
 }  // namespace ss
