@@ -2,7 +2,11 @@
 --kernel-trace --output-format csv, as MI355X_MICROARCH.md §HBM prescribes) into per-kernel and
 per-profiler-class HBM bytes per launch -> profiles/*_pmc_traffic.json (read by bench.py).
 
-  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<note>"
+  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<note>" [<mfma_counter_collection.csv>]
+
+The optional third pass (--pmc MfmaUtil, the derived metric rocprofv3 -L documents:
+100 * sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) * SIMD_NUM)) adds the matrix-core busy
+fraction per kernel (mean over its launches).
 
 Units: the counters report KB.  gfx950 correction (guide): FETCH_SIZE counts 128-B requests as 64 B
 for wide coalesced reads -> HBM read bytes ~= 2 * FETCH_SIZE * 1024; WRITE_SIZE is taken as is."""
@@ -45,6 +49,16 @@ def main():
         if n:
             classes[cls] = {"launches": n, "hbm_mbytes_per_launch_corrected": round(
                 sum(kernels[k]["hbm_mbytes_per_launch_corrected"] * kernels[k]["launches"] for k in ks) / n, 2)}
+    if len(sys.argv) > 5:      # third pass: rocprofv3 --pmc MfmaUtil (derived: MFMA busy cycles / (active cycles * SIMDs))
+        util, nu = read(sys.argv[5], "MfmaUtil")
+        for prefix, cls in CLASSES:
+            ks = [k for k in util if k.startswith(prefix)]
+            n = sum(nu[k] for k in ks)
+            if n and cls in classes:
+                classes[cls]["mfma_util_pct"] = round(sum(util[k] for k in ks) / n, 1)
+        for k in kernels:
+            if nu.get(k, 0):
+                kernels[k]["mfma_util_pct"] = round(util[k] / nu[k], 1)
     top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_mbytes_per_launch_corrected"] * kv[1]["launches"])[:16])
     json.dump({"note": sys.argv[4] if len(sys.argv) > 4 else "", "classes": classes, "kernels": top}, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(classes, indent=1))
