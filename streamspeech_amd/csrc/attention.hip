@@ -374,6 +374,174 @@ __global__ __launch_bounds__(256) void attention_mfma_kernel(AttnArgs p) {
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// MFMA form of the Conformer's relative-position attention (espnet_multihead_attention.py:154-209):
+//   score[i,j] = ((q_i+u).k_j + (q_i+v).p[j-i+T-1]) / 8, chunk mask, softmax, PV.
+// AC = K.(Q+u)^T and PV are the tiles of attention_mfma_kernel.  BD is Toeplitz in (i, j): for a wave's
+// 16 queries and a 16-key sub-tile only 31 table rows can occur, so G^T = Pwin.(Q+v)^T is computed for
+// the 32-row window starting at the sub-tile's smallest offset (two more MFMA tiles) and the skewed
+// read BD[i][j] = G[i][15 - (i - ib) + (j - jb)] goes through a 2.3 KB per-wave LDS patch (the
+// rel_shift of the reference, never materialised beyond 16 x 32).  The projected table rows a
+// (64 query x 64 key) block can touch (127) are staged in LDS next to the K and V^T tiles.
+// -------------------------------------------------------------------------------------------------
+constexpr int PWIN = 2 * KT;          // staged table rows (127 used, last one zero)
+constexpr int LDG = 36;               // per-wave G patch row stride
+constexpr size_t kRelposLds = (size_t)(KT * LDT + DH * LDT + PWIN * LDT + 4 * 16 * LDG) * sizeof(float);
+
+__global__ __launch_bounds__(256) void attention_relpos_mfma_kernel(AttnArgs p) {
+  if (p.nseg > 0) {
+    const int* sg = p.segs + 4 * blockIdx.z;
+    p.Tq = sg[1]; p.Tk = sg[3];
+    if ((int)blockIdx.x * MQ >= p.Tq) return;
+    p.Q += (size_t)sg[0] * p.ldq; p.O += (size_t)sg[0] * p.ldo;
+    p.K += (size_t)sg[2] * p.ldk; p.V += (size_t)sg[2] * p.ldv;
+    p.P += (size_t)(p.p_tmax - p.Tk) * p.ldp;
+  }
+  extern __shared__ __attribute__((aligned(16))) float smem_rp[];
+  float* Ks = smem_rp;                  // [key][d]
+  float* Vt = Ks + KT * LDT;            // [d][key]
+  float* Ps = Vt + DH * LDT;            // [table row][d]
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  float* Gs = Ps + PWIN * LDT + wave * 16 * LDG;
+  const int r = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, hoff = h * DH;
+  const int i0 = blockIdx.x * MQ;
+  const int q0 = p.q0;
+  const int iq = i0 + wave * 16 + r;                 // this lane's query row (relative to Q); absolute position q0 + iq
+  const bool q_ok = iq < p.Tq;
+
+  f32x4 quf[4], qvf[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (q_ok) q = *reinterpret_cast<const f32x4*>(p.Q + (size_t)iq * p.ldq + hoff + 16 * kk + 4 * g);
+    const f32x4 bu = *reinterpret_cast<const f32x4*>(p.bias_u + hoff + 16 * kk + 4 * g);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias_v + hoff + 16 * kk + 4 * g);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { quf[kk][e] = q[e] + bu[e]; qvf[kk][e] = q[e] + bv[e]; }
+  }
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m_run = -INFINITY, l_run = 0.f;
+
+  int kmax = p.Tk;
+  const int ilast = min(i0 + MQ, p.Tq) - 1;
+  if (p.chunk > 0) kmax = min(kmax, ((ilast + q0) / p.chunk + 1) * p.chunk);
+  int lim = p.Tk;
+  if (p.chunk > 0) lim = min(lim, ((iq + q0) / p.chunk + 1) * p.chunk);
+  if (!q_ok) lim = 0;
+
+  for (int j0 = 0; j0 < kmax; j0 += KT) {
+    __syncthreads();
+    for (int f = t; f < KT * (DH / 4); f += 256) {
+      const int row = f >> 4, c4 = (f & 15) * 4;
+      const int j = j0 + row;
+      f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+      if (j < p.Tk) {
+        kv = *reinterpret_cast<const f32x4*>(p.K + (size_t)j * p.ldk + hoff + c4);
+        vv = *reinterpret_cast<const f32x4*>(p.V + (size_t)j * p.ldv + hoff + c4);
+      }
+      *reinterpret_cast<f32x4*>(Ks + row * LDT + c4) = kv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Vt[(c4 + c) * LDT + row] = vv[c];
+    }
+    {
+      // local row lr <-> table row pbase + lr, pbase = j0 - (q0 + i0 + MQ - 1) + Tk - 1
+      const int pbase = j0 - (q0 + i0 + MQ - 1) + p.Tk - 1;
+      for (int f = t; f < PWIN * (DH / 4); f += 256) {
+        const int row = f >> 4, c4 = (f & 15) * 4;
+        const int pr = pbase + row;
+        f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+        if (row < PWIN - 1 && pr >= 0 && pr < 2 * p.Tk - 1)
+          pv = *reinterpret_cast<const f32x4*>(p.P + (size_t)pr * p.ldp + hoff + c4);
+        *reinterpret_cast<f32x4*>(Ps + row * LDT + c4) = pv;
+      }
+    }
+    __syncthreads();
+
+    f32x4 s[4];
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt) {
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 ga = {0.f, 0.f, 0.f, 0.f}, gb = {0.f, 0.f, 0.f, 0.f};
+      const int lrow0 = 16 * (kt - wave) + (MQ - 16);          // first window row of this (wave, sub-tile)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const f32x4 kf = *reinterpret_cast<const f32x4*>(Ks + (kt * 16 + r) * LDT + 16 * kk + 4 * g);
+        const f32x4 pa = *reinterpret_cast<const f32x4*>(Ps + (lrow0 + r) * LDT + 16 * kk + 4 * g);
+        const f32x4 pb = *reinterpret_cast<const f32x4*>(Ps + (lrow0 + 16 + r) * LDT + 16 * kk + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], quf[kk][e], s[kt], 0, 0, 0);
+          ga = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[e], qvf[kk][e], ga, 0, 0, 0);
+          gb = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[e], qvf[kk][e], gb, 0, 0, 0);
+        }
+      }
+      // G[query r][window offset x]: x = 4g+e in ga, 16+4g+e in gb; BD for key 4g+e is x = 15 - r + 4g + e
+      *reinterpret_cast<f32x4*>(Gs + r * LDG + 4 * g) = ga;
+      *reinterpret_cast<f32x4*>(Gs + r * LDG + 16 + 4 * g) = gb;
+      const float* gr = Gs + r * LDG + 15 - r + 4 * g;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[kt][e] += gr[e];
+    }
+    float mt = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + kt * 16 + 4 * g + e;
+        s[kt][e] = (j < lim) ? s[kt][e] * p.scale : -INFINITY;
+        mt = fmaxf(mt, s[kt][e]);
+      }
+    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+    const float mn = fmaxf(m_run, mt);
+    float corr = 1.f, ls = 0.f;
+    if (mn > -INFINITY) {
+      corr = (m_run > -INFINITY) ? expf(m_run - mn) : 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = (s[kt][e] > -INFINITY) ? expf(s[kt][e] - mn) : 0.f;
+          s[kt][e] = pe;
+          ls += pe;
+        }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < 4; ++kt) s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    ls += __shfl_xor(ls, 16, 64);
+    ls += __shfl_xor(ls, 32, 64);
+    l_run = l_run * corr + ls;
+    m_run = mn;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[dt][e] *= corr;
+#pragma unroll
+    for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const f32x4 vf = *reinterpret_cast<const f32x4*>(Vt + (dt * 16 + r) * LDT + kt * 16 + 4 * g);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], s[kt][e], o[dt], 0, 0, 0);
+      }
+  }
+  if (q_ok) {
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 v = o[dt];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= inv;
+      *reinterpret_cast<f32x4*>(p.O + (size_t)iq * p.ldo + hoff + 16 * dt + 4 * g) = v;
+    }
+  }
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   const int tq = a.nseg > 0 ? a.max_q : a.Tq;
   if (tq <= 0 || (a.nseg == 0 && a.Tk <= 0)) return SS_OK;
@@ -394,6 +562,17 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if (a.P) {
     if ((a.nseg == 0 && a.q0 + a.Tq != a.Tk) || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
     if (a.nseg > 0 && a.p_tmax <= 0) return SS_ERR_ARG;
+    if (!g_attn_no_mfma && ((a.ldq | a.ldo) & 3) == 0 && a.k_mask_tail == 0 && !a.causal) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_relpos_mfma_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRelposLds));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(attention_relpos_mfma_kernel, dim3(cdiv(tq, MQ), a.H, gz), dim3(256), kRelposLds, stream, a);
+      SS_LAUNCH_CHECK();
+      return SS_OK;
+    }
     hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), 0, stream, a);
   } else {
     hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), 0, stream, a);
