@@ -49,32 +49,60 @@ int launch_layernorm(const float* x, int ldx, float* y, int ldy, const float* ga
 }
 
 // ---------------------------------------------------------------------------------------------
-// Chunk-causal depthwise conv + BatchNorm(eval) + SiLU.  Thread = (t, c); lanes run along c so
-// every tap is one coalesced row read (the [T,C] tile stays in L1/L2: T'*C*4 = 128 KB at 5 s).
+// Chunk-causal depthwise conv (k = 31) + BatchNorm(eval) + SiLU, in LDS
+// (reference chunk_unity/modules/conformer_layer.py:94-119 + chunk_causal_conv1d.py:39-68).
+// Workgroup = 32 output rows x 64 channels: the (32 + K - 1)-row input slab is read from global once
+// (coalesced 256-B row segments) into LDS, then thread (c, row group) slides over its 8 rows with
+// the 31 taps of its channel in registers -- every input element is fetched from HBM/L2 once per
+// workgroup instead of once per tap.  Visibility: taps at input positions >= the output row's
+// chunk end (or the sequence end) are zero, the closed form of the reference's unfold/pad/re-stitch.
 // ---------------------------------------------------------------------------------------------
+constexpr int DW_TT = 32, DW_TC = 64, DW_KMAX = 31;
+
 __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
     const float* __restrict__ x, int ldx, float* y, int ldy, const float* __restrict__ wt, int K,
     const float* __restrict__ bn_mean, const float* __restrict__ bn_var, const float* __restrict__ bn_gamma,
     const float* __restrict__ bn_beta, float bn_eps, int T, int C, int chunk, const int* __restrict__ segs,
     int t_begin) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int t = blockIdx.y + t_begin;
+  __shared__ float slab[(DW_TT + DW_KMAX - 1) * DW_TC];
   if (segs) {   // ragged batch: {row_start, len} per utterance
     const int st = segs[2 * blockIdx.z];
     T = segs[2 * blockIdx.z + 1];
     x += (size_t)st * ldx; y += (size_t)st * ldy;
   }
-  if (c >= C || t >= T) return;
+  const int t0 = t_begin + blockIdx.y * DW_TT;       // first output row of the tile
+  if (t0 >= T) return;
+  const int c0 = blockIdx.x * DW_TC;
+  const int tid = threadIdx.x, cl = tid & (DW_TC - 1), rg = tid >> 6;
   const int half = K / 2;
-  int lo = t - half, hi = t + half;            // inclusive tap window in input positions
-  if (lo < 0) lo = 0;
-  int lim = T;
-  if (chunk > 0) { const int cl = (t / chunk + 1) * chunk; if (cl < lim) lim = cl; }
-  if (hi > lim - 1) hi = lim - 1;
-  float acc = 0.f;
-  for (int pos = lo; pos <= hi; ++pos) acc = fmaf(wt[(pos - t + half) * C + c], x[(size_t)pos * ldx + c], acc);
-  float v = (acc - bn_mean[c]) / sqrtf(bn_var[c] + bn_eps) * bn_gamma[c] + bn_beta[c];
-  y[(size_t)t * ldy + c] = v / (1.0f + expf(-v));
+  const int rows = DW_TT + K - 1;                    // slab row s <-> input row t0 - half + s
+  for (int idx = tid; idx < rows * DW_TC; idx += 256) {
+    const int sr = idx / DW_TC, cc = idx - sr * DW_TC;
+    const int tin = t0 - half + sr;
+    slab[idx] = (tin >= 0 && tin < T && c0 + cc < C) ? x[(size_t)tin * ldx + c0 + cc] : 0.f;
+  }
+  const int c = c0 + cl;
+  float w[DW_KMAX];
+#pragma unroll
+  for (int j = 0; j < DW_KMAX; ++j) w[j] = (j < K && c < C) ? wt[j * C + c] : 0.f;
+  __syncthreads();
+  if (c >= C) return;
+  const float mean = bn_mean[c], rstd = 1.0f / sqrtf(bn_var[c] + bn_eps), gam = bn_gamma[c], bet = bn_beta[c];
+#pragma unroll 1
+  for (int u = 0; u < DW_TT / 4; ++u) {
+    const int lt = rg * (DW_TT / 4) + u;             // row inside the tile
+    const int t = t0 + lt;
+    if (t >= T) break;
+    int lim = T;                                     // first invisible input row
+    if (chunk > 0) { const int cl_end = (t / chunk + 1) * chunk; if (cl_end < lim) lim = cl_end; }
+    const int jmax = min(K, lim - (t - half));       // taps j < jmax are visible (input row t - half + j < lim)
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < DW_KMAX; ++j)
+      if (j < jmax) acc = fmaf(w[j], slab[(lt + j) * DW_TC + cl], acc);
+    const float v = (acc - mean) * rstd * gam + bet;
+    y[(size_t)t * ldy + c] = v / (1.0f + expf(-v));
+  }
 }
 
 int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const float* wt, int K,
@@ -82,7 +110,8 @@ int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const floa
                           const float* bn_beta, float bn_eps, int T, int C, int chunk, hipStream_t stream,
                           const int* segs, int nseg, int t_begin) {
   if (T - t_begin <= 0) return SS_OK;
-  dim3 grid(cdiv(C, 256), T - t_begin, nseg > 0 ? nseg : 1);
+  if (K > DW_KMAX || (K & 1) == 0) return SS_ERR_ARG;
+  dim3 grid(cdiv(C, DW_TC), cdiv(T - t_begin, DW_TT), nseg > 0 ? nseg : 1);
   hipLaunchKernelGGL(dwconv_bn_silu_kernel, grid, dim3(256), 0, stream, x, ldx, y, ldy, wt, K, bn_mean,
                      bn_var, bn_gamma, bn_beta, bn_eps, T, C, chunk, nseg > 0 ? segs : nullptr, t_begin);
   SS_LAUNCH_CHECK();
