@@ -156,3 +156,33 @@ def test_offline_driver_writes_fairseq_generate_format(hip_model, hip_vocoder, t
             w = hyps[sid]["wav"].cpu().numpy()
             assert sr == 16000 and y.shape == w.shape and np.abs(np.clip(w, -1, 1) - y).max() < 1e-4
 
+
+
+def test_multilingual_models_coexist_with_mixed_length_batches(synth_weights, golden_dir):
+    """BASELINE.json configs[4] shape: fr/es/de checkpoints (same architecture, different weights and
+    CMVN statistics -- configs/{fr,es,de}-en/gcmvn.npz) live side by side on one GPU and serve
+    mixed-length ragged batches; every utterance equals its one-at-a-time result."""
+    import os
+    from streamspeech_amd import synth
+    from streamspeech_amd.config import ModelConfig
+    from streamspeech_amd.engine import HipModel
+    cfg = ModelConfig()
+    models = {}
+    for seed, lang in enumerate(("fr", "es", "de")):
+        g = np.load(os.path.join(golden_dir, f"gcmvn_{lang}-en.npz"))
+        models[lang] = HipModel(synth.make_model_state_dict(seed, cfg), cfg, cmvn_mean=g["mean"], cmvn_std=g["std"])
+    lens = [16000 * 6, 16000 * 1 + 37, 16000 * 3, 16000 * 11]
+    pcm = [torch.from_numpy(synth.synth_pcm(50 + i, n)).to("cuda:0") for i, n in enumerate(lens)]
+    outs = {}
+    for lang, m in models.items():
+        feat, T = m.batch_fbank_cmvn(torch.cat(pcm), lens)
+        enc, Tp = m.batch_encoder_forward(feat, T)
+        asr = m.batch_ctc_greedy(0, enc, Tp)
+        off = 0
+        for b, p in enumerate(pcm):
+            one = m.encoder_forward(m.fbank_cmvn(p))
+            assert (enc[off:off + Tp[b]] - one).abs().max() < 5e-5
+            assert asr[b][0] == m.ctc_greedy(0, one)[0]
+            off += Tp[b]
+        outs[lang] = enc
+    assert (outs["fr"] - outs["es"]).abs().max() > 1e-2 and (outs["es"] - outs["de"]).abs().max() > 1e-2
