@@ -397,6 +397,7 @@ def main():
             "latency_ms_single_stream": round(single_ms, 3), "rtfx_single_stream": round(single_rtfx, 2),
             "batch1_8streams": None if b1_rtfx is None else {"rtfx": round(b1_rtfx, 1), "utterances_per_sec": round(b1_ups, 1),
                                                              "note": "one utterance per call (no ragged packs), 8 concurrent streams, 64 utterances"},
+            "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),   # must be 0 (bounded waits of the stream-K fix-up)
             "roofline": roofline,
             "roofline_isolated": roofline_iso,
             "roofline_second_kernel": roofline_conv,
