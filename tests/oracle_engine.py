@@ -67,6 +67,43 @@ class OracleEngine:
         return toks, torch.tensor(raw, dtype=torch.int32), (logits if want_logits else None)
 
 
+    # ---- ragged-batch method set (one utterance after the other: the B = 1 arithmetic is the definition) ----
+    def batch_fbank_cmvn(self, pcm_packed, n_samples, pcm_scale=32768.0):
+        feats, T, off = [], [], 0
+        for n in n_samples:
+            f = self.fbank_cmvn(pcm_packed[off:off + n], pcm_scale)
+            feats.append(f); T.append(f.shape[0]); off += n
+        return torch.cat(feats), T
+
+    def batch_encoder_forward(self, fbank_packed, T, attn_chunk=999999, conv_chunk=999999):
+        outs, off = [], 0
+        for t in T:
+            outs.append(self.encoder_forward(fbank_packed[off:off + t], attn_chunk, conv_chunk)); off += t
+        return torch.cat(outs), [o.shape[0] for o in outs]
+
+    def batch_ctc_greedy(self, head, enc_packed, Tp):
+        out, off = [], 0
+        for tp in Tp:
+            toks, idx, _, _ = self.ctc_greedy(head, enc_packed[off:off + tp]); off += tp
+            out.append((toks, idx))
+        return out
+
+    def batch_mt_greedy(self, enc_packed, Tp, max_len, min_len=1):
+        toks, feats, n, off = [], [], [], 0
+        for tp, ml in zip(Tp, max_len):
+            t = O.mt_greedy(self.sd, enc_packed[off:off + tp], self.cfg, max_new_tokens=ml); off += tp
+            f = O.mt_decoder_features(self.sd, [self.cfg.eos] + [x for x in t if x != self.cfg.eos], enc_packed[off - tp:off], self.cfg)
+            toks.append(t); feats.append(f); n.append(f.shape[0])
+        rows = max(n)
+        packed = torch.zeros((len(Tp), rows, self.cfg.dec_dim))
+        for b, f in enumerate(feats):
+            packed[b, :f.shape[0]] = f
+        return toks, packed, n
+
+    def batch_t2u_units(self, feats, n_rows, t2u_causal=False, mask_eos=False):
+        return [self.t2u_units(feats[b][:n], t2u_causal, mask_eos)[0] for b, n in enumerate(n_rows)]
+
+
 class OracleVocoder:
     def __init__(self, vsd, vcfg):
         self.vsd, self.vcfg = O.SD(vsd), vcfg
@@ -79,3 +116,11 @@ class OracleVocoder:
         self.call_lengths.append(len(code))
         wav, dur = O.vocoder_forward(self.vsd, code, self.vcfg, dur_prediction)
         return wav, dur.view(1, -1)
+
+    def batch_forward(self, codes, dur_prediction=True, forced_dur=None):
+        wavs, durs = [], []
+        for b, c in enumerate(codes):
+            w, d = O.vocoder_forward(self.vsd, list(c), self.vcfg, dur_prediction,
+                                     forced_dur=None if forced_dur is None else forced_dur[b])
+            wavs.append(w); durs.append(d.view(-1).tolist())
+        return wavs, durs, [len(c) for c in codes]

@@ -60,3 +60,35 @@ def test_ordered_batches_are_length_sorted_and_bounded():
     b = ordered_batches([10, 10, 10, 10], 8, max_tokens=25)
     assert b == [[0, 1], [2, 3]]
     assert detok(["▁he", "llo", "▁wor", "ld", "</s>"]) == "hello world"
+
+
+def test_offline_driver_on_cpu_doubles(tmp_path):
+    """The offline driver's host logic (length-sorted batches, line formats, cut files, wav dumps) over the
+    oracle-backed engine: no GPU needed; hypotheses equal the oracle's one-utterance pipeline."""
+    import torch
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import offline
+    from streamspeech_amd.config import ModelConfig, VocoderConfig
+    from streamspeech_amd.modules import Dictionary
+    from tests.oracle_engine import OracleEngine, OracleVocoder
+    cfg, vcfg = ModelConfig(), VocoderConfig()
+    sd, vsd = synth.make_model_state_dict(0, cfg), synth.make_vocoder_state_dict(0, vcfg)
+    eng, voc = OracleEngine(sd, cfg), OracleVocoder(vsd, vcfg)
+    dicts = {k: Dictionary.placeholder(n) for k, n in (("source_unigram", cfg.src_vocab), ("ctc_target_unigram", cfg.tgt_vocab),
+                                                       ("target_unigram", cfg.tgt_vocab))}
+    items = [(7 + i, torch.from_numpy(synth.synth_pcm(90 + i, int(16000 * s)))) for i, s in enumerate((0.9, 1.6, 0.7))]
+    hyps = offline.generate(eng, voc, items, dicts, str(tmp_path), "dev", batch_size=2, max_len_a=0.0, max_len_b=4,
+                            dur_prediction=True, dump_wav=True)
+    assert sorted(hyps) == [7, 8, 9]
+    log = (tmp_path / "generate-dev.log").read_text().splitlines()
+    assert len(log) == 9 and log[0].startswith("A-8\t")           # the longest utterance is processed first
+    res = (tmp_path / "generate-dev.txt").read_text().splitlines()
+    assert [ln.split("\t")[0][:2] for ln in res] == ["H-", "D-"] * 3
+    assert len((tmp_path / "generate-dev.unit").read_text().splitlines()) == 3
+    for sid, pcm in items:                                          # same hypotheses as the oracle's single-utterance path
+        fb = eng.fbank_cmvn(pcm)
+        enc = O.encoder_forward(O.SD(sd), fb, cfg)
+        toks = O.mt_greedy(O.SD(sd), enc, cfg, max_new_tokens=4)
+        assert hyps[sid]["mt"] == offline.detok([dicts["target_unigram"][t] for t in toks if t != cfg.eos])
+    n_wav = len(list((tmp_path / "pred_wav").glob("*_pred.wav")))
+    assert n_wav == sum(1 for h in hyps.values() if h["units"])
