@@ -471,6 +471,133 @@ __global__ __launch_bounds__(256) void smallm_gemm_kernel(const GemmArgs p) {
   }
 }
 
+
+// =================================================================================================
+// GEMV form for decode steps (M <= 4 rows: one new MT token, B = 1): these stream 1-4 MB of weights
+// for a few kFLOP, so the matrix cores are irrelevant and what counts is bytes in flight.  One wave
+// per output column (KS waves per column when N alone gives too few waves to cover the chip): the
+// lanes split K in float4 steps, so every weight row is read as fully coalesced 1-KB wave loads, all
+// of a column's loads are issued before the first FMA, and the A rows (optionally LayerNorm'ed in
+// registers: each wave holds the whole row) are loaded once per wave.  Wave-shuffle reduction, fused
+// bias / activation / alpha / residual.  K % 256 == 0, K <= 2048.
+// =================================================================================================
+template <int MR, int KS, bool LNORM>
+__global__ __launch_bounds__(256) void gemv_kernel(const GemmArgs p) {
+  constexpr int WPB = 4;                       // waves per block
+  constexpr int CPB = WPB / KS;                // columns per block
+  __shared__ float part[WPB][MR];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int col = blockIdx.x * CPB + wave / KS;
+  const int ks = wave % KS;
+  const int K = p.Cin;
+  const int kper = K / KS;                     // this wave's slice of K (multiple of 256)
+  const int k0 = ks * kper;
+  const int nit = kper / 256;                  // float4 steps per lane (<= 8)
+  const bool col_ok = col < p.N;
+
+  // weight slice of the column: issue everything first
+  f32x4 wv[8];
+  const float* wrow = p.W + (size_t)(col_ok ? col : 0) * K + k0 + 4 * lane;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    wv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (it < nit && col_ok) wv[it] = *reinterpret_cast<const f32x4*>(wrow + it * 256);
+  }
+  float acc[MR];
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    acc[m] = 0.f;
+    if (m >= p.M) continue;
+    const float* xrow = p.A + (size_t)m * p.lda;
+    float mean = 0.f, rstd = 1.f;
+    if (LNORM) {                               // whole row per wave (K <= 2048: 8 float4 per lane), two-pass statistics
+      f32x4 xv[8];
+      float sm = 0.f;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        xv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (it * 256 < K) xv[it] = *reinterpret_cast<const f32x4*>(xrow + it * 256 + 4 * lane);
+        sm += (xv[it][0] + xv[it][1]) + (xv[it][2] + xv[it][3]);
+      }
+      mean = wave_sum(sm) / (float)K;
+      float q = 0.f;
+#pragma unroll
+      for (int it = 0; it < 8; ++it)
+        if (it * 256 < K) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { const float d = xv[it][e] - mean; q += d * d; }
+        }
+      rstd = 1.0f / sqrtf(wave_sum(q) / (float)K + 1e-5f);
+    }
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      if (it < nit) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(xrow + k0 + it * 256 + 4 * lane);
+        if (LNORM) {
+          const f32x4 gm = *reinterpret_cast<const f32x4*>(p.ln_g + k0 + it * 256 + 4 * lane);
+          const f32x4 bt = *reinterpret_cast<const f32x4*>(p.ln_b + k0 + it * 256 + 4 * lane);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[e] = (x[e] - mean) * rstd * gm[e] + bt[e];
+        }
+        a0 = fmaf(x[0], wv[it][0], a0); a1 = fmaf(x[1], wv[it][1], a1);
+        a2 = fmaf(x[2], wv[it][2], a2); a3 = fmaf(x[3], wv[it][3], a3);
+      }
+    acc[m] = wave_sum((a0 + a1) + (a2 + a3));
+  }
+  if (KS > 1) {
+    if (lane == 0) {
+#pragma unroll
+      for (int m = 0; m < MR; ++m) part[wave][m] = acc[m];
+    }
+    __syncthreads();
+    if (ks != 0) return;
+#pragma unroll
+    for (int m = 0; m < MR; ++m)
+#pragma unroll
+      for (int s2 = 1; s2 < KS; ++s2) acc[m] += part[wave + s2][m];
+  }
+  if (lane != 0 || !col_ok) return;
+  const float b = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+  for (int m = 0; m < MR; ++m) {
+    if (m >= p.M) continue;
+    float v = acc[m] + b;
+    switch (p.act) {
+      case ACT_SILU: v = v / (1.0f + expf(-v)); break;
+      case ACT_RELU: v = fmaxf(v, 0.f); break;
+      default: break;
+    }
+    v *= p.alpha;
+    if (p.R) v += p.R[(size_t)m * p.ldr + col];
+    p.C[(size_t)m * p.ldc + col] = v;
+  }
+}
+
+bool gemv_eligible(const GemmArgs& a) {
+  return smallm_eligible(a) && a.M <= 4 && a.Cin % 256 == 0 && a.Cin <= 2048;
+}
+
+template <int KS>
+static int launch_gemv_ks(const GemmArgs& a, hipStream_t stream) {
+  dim3 grid(cdiv(a.N, 4 / KS));
+  ProfRec rec{}; bool prof = false;
+  int rc = prof_begin(a, stream, 12, rec, prof);     // profiled with the small-M class (decode GEMVs)
+  if (rc != SS_OK) return rc;
+  if (a.ln_g) hipLaunchKernelGGL((gemv_kernel<4, KS, true>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((gemv_kernel<4, KS, false>), grid, dim3(256), 0, stream, a);
+  SS_LAUNCH_CHECK();
+  return prof_end(stream, rec, prof);
+}
+
+static int launch_gemv(const GemmArgs& a, hipStream_t stream) {
+  // waves = N * KS: cover ~1024 SIMDs; KS must divide K/256
+  const int kq = a.Cin / 256;
+  if (a.N * 1 >= 2048 || kq % 2 != 0) return launch_gemv_ks<1>(a, stream);
+  if (a.N * 2 >= 2048 || kq % 4 != 0) return launch_gemv_ks<2>(a, stream);
+  return launch_gemv_ks<4>(a, stream);
+}
+
 // ---- optional event profiler -------------------------------------------------------------------
 static const char* kTileNames[kNumTileCfg] = {
     "conv_gemm<128,16,16,4,1>", "conv_gemm<128,32,32,4,1>", "conv_gemm<128,32,16,4,1>", "conv_gemm<16,128,32,1,4>",
@@ -605,6 +732,7 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.glu && (a.N % 32 != 0 || a.C2)) return SS_ERR_ARG;
   const bool k32 = (a.Cin % 32) == 0;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
+  if (!g_force_bm && gemv_eligible(a)) return launch_gemv(a, stream);
   if (smallm_eligible(a)) {
     const long wgs16 = (long)cdiv(M, 16) * cdiv(a.N, 16);
     if (a.Cin >= 1024 || wgs16 <= 1024) return launch_smallm<4, 1>(a, stream, 12);

@@ -278,3 +278,16 @@ def test_slab_conv_matches_torch(lib, M, C, N, taps, dil, lrelu):
     assert (got - old).abs().max() < 1e-5
     plain = run_conv_gemm(lib, A, Wp, None, M, N, C, taps=taps, dil=dil, pad=pad, act=3)   # LRELU epilogue, no bias
     assert (plain - F.leaky_relu(_conv_ref(A, W, None, taps, dil), 0.1)).abs().max() < TOL
+
+
+@pytest.mark.parametrize("M,N,K,act", [(1, 512, 512, 0), (1, 2048, 512, 2), (1, 512, 2048, 0), (1, 6000, 512, 0), (1, 1536, 512, 0),
+                                       (2, 512, 2048, 1), (4, 1005, 512, 0), (3, 512, 256, 0), (1, 512, 768, 0)])
+def test_gemv_decode_shapes(lib, M, N, K, act):
+    """M <= 4 plain linears route to the GEMV kernel (1 / 2 / 4 waves per column); residual + activation fused."""
+    A, W, b, R = rnd(M, K, seed=31), rnd(N, K, seed=32, scale=K ** -0.5), rnd(N, seed=33, scale=0.1), rnd(M, N, seed=34)
+    got = run_conv_gemm(lib, A, W, b, M, N, K, act=act, alpha=0.5, R=R)
+    y = F.linear(A, W, b)
+    y = F.silu(y) if act == 1 else F.relu(y) if act == 2 else y
+    ref = 0.5 * y + R
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() < TOL, f"max err {(got - ref).abs().max()}"
