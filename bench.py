@@ -118,7 +118,7 @@ def cpu_baseline(sd, vsd, cfg, vcfg, utts, budget_s=25.0):
             "sample": f"{n} utterances ({audio:.1f} s of audio) of the same synthetic workload, after 1 warm-up"}
 
 
-PMC_FILE = "r01_pmc_traffic_v13.json"
+PMC_FILE = "r01_pmc_traffic_v16.json"
 
 
 def main():
