@@ -411,6 +411,9 @@ static int launch_sk(const GemmArgs& a, hipStream_t stream, int g_force) {
   if (G < 1) G = 1;
   if (G > SK_MAXG) G = SK_MAXG;
   const long long tiles = (long long)cdiv(a.M, SK_BM) * (a.N / BN);
+  // data-parallel special case: when the tile count itself nearly fills the resident grid, one tile per
+  // workgroup needs no fix-up at all (U/G = nk exactly)
+  if (g_force <= 0 && tiles <= G && 4 * tiles >= 3 * G) G = tiles;
   const int NG = (g_sk_groups && G >= 64 && tiles >= 64) ? 8 : 1;
   if (NG > 1) G -= G % NG;
   SkArgs q;

@@ -10,6 +10,7 @@
 // C/D layout (MI355X guide §3): col = lane&15, row = (lane>>4)*4 + reg.
 #include "gemm.hpp"
 
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include <utility>
@@ -752,7 +753,8 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
     const long long nk = (long long)a.taps * (a.Cin / 32);
     const bool wide = a.N % 128 == 0;
     const long long units = (long long)cdiv(a.M, 128) * (a.N / (wide ? 128 : 64)) * nk;
-    if (wide ? units >= 12 * 512 : a.taps * a.Cin >= 448) return launch_conv_sk(a, stream);
+    static const long long min_units = getenv("SS_SK_MIN_UNITS") ? atoll(getenv("SS_SK_MIN_UNITS")) : 12 * 512;   // tuning knob
+    if (wide ? units >= min_units : a.taps * a.Cin >= 448) return launch_conv_sk(a, stream);
   }
   if (g_force_bm && a.N > 32 && k32) {   // tuning hook (tools/conv_bench.py): ks = KS*10 + PD
     const int f = g_force_bm * 10000 + (g_force_bn % 100) * 100 + g_force_ks;   // 128x128 -> bn code 28... see cases
