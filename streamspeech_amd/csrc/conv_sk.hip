@@ -34,7 +34,6 @@ typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 struct SkArgs {
   float* ws;            // [G][128*BN] partial tiles
   unsigned* sync;       // [0..7] ticket counter of XCD group x, [8] time-out counter, [16 + w] flag of logical workgroup w
-  const float* zeros;   // >= 16 B of zeros
   unsigned base[8];     // ticket value of rank 0 of each group for this launch
   unsigned epoch;       // flag value meaning "partial of this launch is in place"
   int G;                // workgroups (multiple of NG)
@@ -42,9 +41,9 @@ struct SkArgs {
 };
 
 constexpr int SK_BM = 128, SK_BK = 32, SK_FLAG0 = 16, SK_MAXG = 512;
-constexpr unsigned SK_SPIN_LIMIT = 1u << 22;
-constexpr int SK_NUM_RECORDS = 0x7ffffff0;          // buffer range: every real offset is below, SK_OOB is above
-constexpr unsigned SK_OOB = 0x80000000u;
+[[maybe_unused]] constexpr unsigned SK_SPIN_LIMIT = 1u << 22;
+[[maybe_unused]] constexpr int SK_NUM_RECORDS = 0x7ffffff0;          // buffer range: every real offset is below, SK_OOB is above
+[[maybe_unused]] constexpr unsigned SK_OOB = 0x80000000u;
 
 template <int BN, bool LRELU>
 __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const SkArgs q) {
@@ -418,7 +417,6 @@ static int launch_sk(const GemmArgs& a, hipStream_t stream, int g_force) {
   if (NG > 1) G -= G % NG;
   SkArgs q;
   q.ws = st->ws; q.sync = st->sync;
-  q.zeros = reinterpret_cast<const float*>(st->sync + SK_FLAG0 + SK_MAXG);
   q.epoch = ++st->epoch; q.G = (int)G; q.NG = NG;
   for (int x = 0; x < 8; ++x) q.base[x] = st->base[x];
   for (int x = 0; x < NG; ++x) st->base[x] += (unsigned)(G / NG);
