@@ -186,3 +186,28 @@ def test_multilingual_models_coexist_with_mixed_length_batches(synth_weights, go
             off += Tp[b]
         outs[lang] = enc
     assert (outs["fr"] - outs["es"]).abs().max() > 1e-2 and (outs["es"] - outs["de"]).abs().max() > 1e-2
+
+
+def test_offline_driver_is_deterministic_and_shards_cover_the_set(hip_model, hip_vocoder, tmp_path):
+    """configs[3] shape in miniature: a few hundred utterances through length-bucketed ragged batches.
+    Two runs give bit-identical hypotheses (fixed summation orders everywhere, stream-K included);
+    the two shards of a 2-way split (fairseq --num-shards/--shard-id) cover every id exactly once."""
+    from streamspeech_amd import offline, synth
+    from streamspeech_amd.modules import Dictionary
+    cfg = hip_model.cfg
+    dicts = {k: Dictionary.placeholder(n) for k, n in (("source_unigram", cfg.src_vocab), ("ctc_target_unigram", cfg.tgt_vocab),
+                                                       ("target_unigram", cfg.tgt_vocab))}
+    durs = synth.synth_durations(77, 192)
+    items = [(i, torch.from_numpy(synth.synth_pcm(300 + i, int(16000 * min(float(d), 4.0)))).to(hip_model.device))
+             for i, d in enumerate(durs)]
+    kw = dict(batch_size=32, max_len_a=0.0, max_len_b=6, dur_prediction=True, dump_wav=False)
+    a = offline.generate(hip_model, hip_vocoder, items, dicts, str(tmp_path / "a"), "test", **kw)
+    b = offline.generate(hip_model, hip_vocoder, items, dicts, str(tmp_path / "b"), "test", **kw)
+    assert sorted(a) == list(range(192))
+    for i in a:
+        assert a[i]["units"] == b[i]["units"] and a[i]["asr"] == b[i]["asr"] and a[i]["mt"] == b[i]["mt"]
+    assert (tmp_path / "a" / "generate-test.unit").read_text() == (tmp_path / "b" / "generate-test.unit").read_text()
+    s0 = offline.generate(hip_model, hip_vocoder, items[0::2], dicts, str(tmp_path / "s0"), "test.shard0", **kw)
+    s1 = offline.generate(hip_model, hip_vocoder, items[1::2], dicts, str(tmp_path / "s1"), "test.shard1", **kw)
+    assert sorted(list(s0) + list(s1)) == list(range(192))
+    assert hip_model.lib.ss_debug_sk_errors() == 0
