@@ -28,6 +28,8 @@
 namespace ss {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+constexpr int SK_SC1 = 16;            // buffer cache policy: sc1 = agent scope (writes through / reads past the per-XCD L2)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
@@ -231,19 +233,20 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
 #endif
     if (!has_end) {
       // ---- contributor: park the partial tile, raise the flag ----
-      // Partials and flags move with agent-scope (sc1) relaxed atomics: they write through / read
+      // Partials move as sc1 (agent-scope) b128 buffer stores / loads, flags as sc1 relaxed atomics: they write through / read
       // past the per-XCD L2, so no L2 write-back or invalidate (which would evict the weights every
       // other workgroup of the XCD is streaming) is needed.  Order: stores complete (vmcnt 0) ->
       // workgroup barrier -> flag.
-      unsigned* slot = reinterpret_cast<unsigned*>(q.ws + (size_t)w * (BM * BN));
+      const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(q.ws + (size_t)w * (BM * BN)), 0, BM * BN * 4, 0x00020000);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int j = 0; j < TN; ++j) {
+          u32x4 v;
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            __hip_atomic_store(slot + (((wave * TM + i) * TN + j) * 4 + e) * 64 + lane, __float_as_uint(acc[i][j][e]),
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][e]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsP, (((wave * TM + i) * TN + j) * 64 + lane) * 16, 0, SK_SC1);
+        }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (t == 0) __hip_atomic_store(q.sync + SK_FLAG0 + w, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -266,20 +269,19 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
       }
       __syncthreads();
       for (int ww = wf; ww < w; ++ww) {      // fixed order: ((mine + P[wf]) + P[wf+1]) + ...
-        const unsigned* slot = reinterpret_cast<const unsigned*>(q.ws + (size_t)ww * (BM * BN));
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(q.ws + (size_t)ww * (BM * BN)), 0, BM * BN * 4, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+          u32x4 o[TN];
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            unsigned o[4];
+          for (int j = 0; j < TN; ++j)
+            o[j] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (((wave * TM + i) * TN + j) * 64 + lane) * 16, 0, SK_SC1);
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              o[e] = __hip_atomic_load(slot + (((wave * TM + i) * TN + j) * 4 + e) * 64 + lane, __ATOMIC_RELAXED,
-                                       __HIP_MEMORY_SCOPE_AGENT);
+          for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][e] += __uint_as_float(o[e]);
-            __builtin_amdgcn_sched_barrier(0);   // 4 loads in flight per step: keeps the register budget of the main loop
-          }
+            for (int e = 0; e < 4; ++e) acc[i][j][e] += __uint_as_float(o[j][e]);
+          __builtin_amdgcn_sched_barrier(0);   // TN loads in flight per step: keeps the register budget of the main loop
+        }
       }
     }
 
