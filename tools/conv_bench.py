@@ -98,6 +98,25 @@ def sweep_sk():
     print("sk errors:", lib.ss_debug_sk_errors())
 
 
+def sweep_enc():
+    """encoder / decoder linear shapes at batch-32 scale (M = 3900 encoder rows, 14400 unit-decoder rows)."""
+    shapes = [("enc ffn1", 3900, 2048, 256, 1), ("enc ffn2", 3900, 256, 2048, 1), ("enc qkv", 3900, 768, 256, 1),
+              ("enc out", 3900, 256, 256, 1), ("ctc head", 3900, 6000, 256, 1), ("unit qkv", 14400, 1536, 512, 1),
+              ("unit out", 14400, 512, 512, 1), ("unit fc1", 14400, 2048, 512, 1), ("unit fc2", 14400, 512, 2048, 1),
+              ("unit head", 14400, 1005, 512, 1)]
+    cfgs = [("heur", 0, 0, 0), ("32x64", 32, 64, 11), ("64x64", 64, 64, 11), ("128x64", 128, 64, 11), ("sk auto", 1, 0, 0)]
+    print("%-12s" % "shape" + "".join("%10s" % c[0] for c in cfgs) + "   GFLOP   best TF")
+    for name, M, N, Cin, taps in shapes:
+        line, best = "%-12s" % name, 1e9
+        for _, bm, bn, ks in cfgs:
+            lib.ss_debug_force_tile(bm, bn, ks)
+            r = bench(name, M, N, Cin, taps, 1, reps=5)
+            line += "%10.1f" % r["us"]
+            best = min(best, r["us"])
+        print(line + "   %6.2f  %6.1f" % (r["gflop"], r["gflop"] / best * 1e3), flush=True)
+    lib.ss_debug_force_tile(0, 0, 0)
+
+
 def sweep_slab():
     """narrow vocoder stages: slab kernel (default dispatch) vs the LDS-tiled kernels (force code 2)."""
     shapes = [("stage3 k11 b16", 576000, 32, 32, 11), ("stage3 k7 b16", 576000, 32, 32, 7), ("stage3 k3 b16", 576000, 32, 32, 3),
@@ -115,6 +134,8 @@ def sweep_slab():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "enc":
+        return sweep_enc()
     if len(sys.argv) > 1 and sys.argv[1] == "slab":
         return sweep_slab()
     if len(sys.argv) > 1 and sys.argv[1] == "sk":
