@@ -51,6 +51,9 @@ class _TextAgentBase(SpeechToTextAgent):
         self.asr_text = ""
         self.tgt_text = ""
         self.states.reset()
+        enc = getattr(getattr(self, "model", None), "encoder", None)
+        if enc is not None and hasattr(enc, "reset_stream"):
+            enc.reset_stream()                     # incremental encoder cache: one utterance at a time
 
     def _encode(self):
         feature = self.feature_extractor(self.states.source)

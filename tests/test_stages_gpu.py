@@ -213,6 +213,12 @@ def test_streaming_agent_matches_oracle_agent(hip_model, hip_vocoder, synth_weig
     assert w_hip.shape == w_ora.shape
     rms = float(np.sqrt(np.mean((w_hip - w_ora) ** 2)))
     assert rms < WAV_RMS_TOL, f"rms {rms}"
+    # second utterance through the same agents (longer, different audio): reset() drops the encoder cache
+    pcm2 = synth.synth_pcm(18, int(16000 * 3.3))
+    w2_hip, a2_hip = stream(hip_agent, pcm2, segment_ms)
+    w2_ora, a2_ora = stream(ora_agent, pcm2, segment_ms)
+    assert a2_hip == a2_ora and w2_hip.shape == w2_ora.shape
+    assert w2_hip.size == 0 or float(np.sqrt(np.mean((w2_hip - w2_ora) ** 2))) < WAV_RMS_TOL
 
 
 @pytest.mark.parametrize("kind", ["asr", "s2tt"])
@@ -238,8 +244,12 @@ def test_text_agents_match_oracle_agents(hip_model, synth_weights, kind):
     ora = OracleEngine(sd, cfg)
     ora.fbank_cmvn = lambda pcm, scale=32768.0: hip_model.fbank_cmvn(pcm.to(hip_model.device), scale).cpu()
     pcm = synth.synth_pcm(23, int(16000 * 2.9))
-    got, want = _stream_text(mk(hip_model), pcm), _stream_text(mk(ora), pcm)
+    hip_agent, ora_agent = mk(hip_model), mk(ora)
+    got, want = _stream_text(hip_agent, pcm), _stream_text(ora_agent, pcm)
     assert got == want and len(got) >= 1
+    # a second, different and longer utterance on the SAME agents: reset() must drop the incremental encoder cache
+    pcm2 = synth.synth_pcm(29, int(16000 * 3.7))
+    assert _stream_text(hip_agent, pcm2) == _stream_text(ora_agent, pcm2)
 
 
 def test_incremental_vocoder_tail_on_hip(hip_vocoder, synth_weights):
