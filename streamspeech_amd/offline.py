@@ -68,7 +68,16 @@ def generate(model, vocoder, items: Sequence[Tuple[int, torch.Tensor]], dicts: D
     res_f = open(os.path.join(results_path, f"generate-{subset}.txt"), "w", encoding="utf-8")
     hyps: Dict[int, Dict] = {}
     lens = [int(p.numel()) for _, p in items]
-    for group in ordered_batches(lens, batch_size, max_tokens):
+    for sid, pcm in items:                      # shorter than one 25-ms fbank window: nothing to decode
+        if pcm.numel() < 400:
+            for tag in "ASD":
+                print(f"{tag}-{sid}\t", file=log_f)
+            print(f"H-{sid}\t0.0\t", file=res_f)
+            print(f"D-{sid}\t0.0\t", file=res_f)
+            hyps[sid] = {"asr": "", "st": "", "mt": "", "units": [], "wav": None}
+    keep = [i for i in range(len(items)) if lens[i] >= 400]
+    for group_k in ordered_batches([lens[i] for i in keep], batch_size, max_tokens):
+        group = [keep[j] for j in group_k]
         ids = [items[i][0] for i in group]
         pcm = torch.cat([items[i][1].reshape(-1) for i in group])
         feat, T = model.batch_fbank_cmvn(pcm, [lens[i] for i in group])

@@ -77,15 +77,16 @@ def test_offline_driver_on_cpu_doubles(tmp_path):
     dicts = {k: Dictionary.placeholder(n) for k, n in (("source_unigram", cfg.src_vocab), ("ctc_target_unigram", cfg.tgt_vocab),
                                                        ("target_unigram", cfg.tgt_vocab))}
     items = [(7 + i, torch.from_numpy(synth.synth_pcm(90 + i, int(16000 * s)))) for i, s in enumerate((0.9, 1.6, 0.7))]
+    items.append((10, torch.zeros(123)))                            # shorter than one fbank window: empty hypothesis
     hyps = offline.generate(eng, voc, items, dicts, str(tmp_path), "dev", batch_size=2, max_len_a=0.0, max_len_b=4,
                             dur_prediction=True, dump_wav=True)
-    assert sorted(hyps) == [7, 8, 9]
+    assert sorted(hyps) == [7, 8, 9, 10] and hyps[10]["units"] == []
     log = (tmp_path / "generate-dev.log").read_text().splitlines()
-    assert len(log) == 9 and log[0].startswith("A-8\t")           # the longest utterance is processed first
+    assert len(log) == 12 and log[3].startswith("A-8\t")           # after the empty one, the longest utterance comes first
     res = (tmp_path / "generate-dev.txt").read_text().splitlines()
-    assert [ln.split("\t")[0][:2] for ln in res] == ["H-", "D-"] * 3
-    assert len((tmp_path / "generate-dev.unit").read_text().splitlines()) == 3
-    for sid, pcm in items:                                          # same hypotheses as the oracle's single-utterance path
+    assert [ln.split("\t")[0][:2] for ln in res] == ["H-", "D-"] * 4
+    assert len((tmp_path / "generate-dev.unit").read_text().splitlines()) == 4
+    for sid, pcm in items[:3]:                                          # same hypotheses as the oracle's single-utterance path
         fb = eng.fbank_cmvn(pcm)
         enc = O.encoder_forward(O.SD(sd), fb, cfg)
         toks = O.mt_greedy(O.SD(sd), enc, cfg, max_new_tokens=4)
