@@ -4,9 +4,11 @@
   python bench.py --gpus N --steps K --warmup W
   (N > 1: launched by torch.distributed.run, one rank per GPU, utterance-level data parallel)
 
-A "step" is one synthetic utterance, batch 1, through the whole HIP hot path
-(streamspeech_amd/workload.py): PCM already in HBM -> fbank+CMVN -> chunk-Conformer -> CTC x2 ->
-AR MT greedy decode -> T2U + NAR unit decoder -> CTC collapse -> unit HiFi-GAN -> waveform in HBM.
+A "step" is one pass of the whole HIP hot path over one ragged batch of --batch (32) synthetic
+utterances, each with B = 1 arithmetic (streamspeech_amd/workload.py): PCM already in HBM ->
+fbank+CMVN -> chunk-Conformer -> CTC x2 -> AR MT greedy decode -> T2U + NAR unit decoder -> CTC
+collapse -> unit HiFi-GAN -> waveform in HBM.  The default K = 32 steps is BASELINE.json's
+1024-utterance set; with --batch 1 a step is one utterance through the single-utterance entry points.
 value = total audio seconds / wall seconds over all ranks (RTFx; higher is better); the line also
 carries utterances/sec, the roofline of the dominant kernel (HIP events recorded on the launch
 stream inside the timed region) and the CPU oracle timed on this box's host cores (rank 0, N=1).
@@ -124,8 +126,8 @@ PMC_FILE = "r01_pmc_traffic_v16.json"
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256, help="timed utterances per GPU")
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=32, help="timed steps per GPU (one step = one ragged batch of --batch utterances)")
+    ap.add_argument("--warmup", type=int, default=3, help="untimed warm-up steps per GPU before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--streams", type=int, default=4,
@@ -158,14 +160,18 @@ def main():
     voc = HipVocoder(vsd, vcfg, device=dev)
     lib = L.load()
 
-    K, Wn = args.steps, args.warmup
-    all_utts = workload.make_utterances((K + Wn) * world)
-    # weak scaling: K + W utterances per rank.  The timed set is length-sorted before the round-robin
-    # deal, so every rank gets the same number of utterances AND ~the same audio seconds.
+    Ksteps, Wsteps, Bsz = max(1, args.steps), max(0, args.warmup), max(1, args.batch)
+    K = Ksteps * Bsz                         # timed utterances per rank
+    Kpool = min(K, 2048)                     # distinct synthetic utterances per rank (cycled beyond that)
+    Wn = 3                                   # single-utterance warm-ups (first-touch of every code path)
+    all_utts = workload.make_utterances((Kpool + Wn) * world)
+    # weak scaling: the same number of utterances per rank.  The timed pool is length-sorted before the
+    # round-robin deal, so every rank also gets ~the same audio seconds.
     warm_all, timed_all = all_utts[:Wn * world], all_utts[Wn * world:]
     timed_all = sorted(timed_all, key=lambda u: -u.seconds)
     mine = dp.shard(warm_all, rank, world) + dp.shard(timed_all, rank, world)
     pcms = [torch.from_numpy(synth.synth_pcm(1234 + u.idx, u.n_samples)).to(dev) for u in mine]
+    timed_ids = [Wn + (i % Kpool) for i in range(K)]
     torch.cuda.synchronize()
 
     for u, p in zip(mine[:Wn], pcms[:Wn]):
@@ -174,7 +180,7 @@ def main():
 
     # dominant kernel classes: decided from an untimed profiled pass over one utterance
     dom, dom_conv = None, None
-    if not args.no_prof and Wn > 0:
+    if not args.no_prof:   # untimed; uses the first utterances of this rank whatever --warmup is
         ncls = lib.ss_prof_num_classes()
         lib.ss_prof_reset()
         lib.ss_prof_enable((1 << ncls) - 1)
@@ -198,8 +204,8 @@ def main():
     # single-stream latency pass (untimed for `value`; reported as latency_ms_single_stream)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    nlat = 1 if args.no_latency_pass else min(K, 8)
-    lat_idx = list(range(Wn, Wn + K))[::max(1, K // nlat)][:nlat]   # evenly spread over the length-sorted timed set
+    nlat = 1 if args.no_latency_pass else min(Kpool, 8)
+    lat_idx = list(range(Wn, Wn + Kpool))[::max(1, Kpool // nlat)][:nlat]   # evenly spread over the length-sorted pool
     for i in lat_idx:
         run_utterance(model, voc, pcms[i], mine[i])
     torch.cuda.synchronize()
@@ -212,8 +218,7 @@ def main():
     import threading
     ctxs = [(model, voc)] + [(model.new_context(), voc.new_context()) for _ in range(S - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    Bsz = max(1, args.batch)
-    timed = list(zip(mine[Wn:Wn + K], pcms[Wn:Wn + K]))
+    timed = [(mine[i], pcms[i]) for i in timed_ids]
     if Bsz == 1:
         work = timed
     else:
@@ -268,6 +273,12 @@ def main():
             except Exception:  # noqa: BLE001
                 pass
 
+    for wb in work[:Wsteps]:                 # W untimed warm-up steps (on top of the per-context warm-up inside worker())
+        if Bsz == 1:
+            run_utterance(model, voc, wb[1], wb[0])
+        else:
+            run_batch(model, voc, wb[1], wb[0])
+    torch.cuda.synchronize()
     threads = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
     for t in threads:
         t.start()
@@ -288,7 +299,7 @@ def main():
     if errors:
         raise errors[0]
 
-    audio = sum(u.seconds for u in mine[Wn:Wn + K])
+    audio = sum(mine[i].seconds for i in timed_ids)
     wall, audio, nutt = dp.reduce_stats(dist, wall, audio, float(K), device=dev)
 
     def read_class(c):
@@ -346,8 +357,8 @@ def main():
     # 8 utterances in flight on 8 streams (untimed for `value`).
     b1_rtfx = b1_ups = None
     if rank == 0 and not args.no_latency_pass:
-        S1, n1 = 8, min(K, 64)
-        sel = list(range(Wn, Wn + K))[::max(1, K // n1)][:n1]
+        S1, n1 = 8, min(Kpool, 64)
+        sel = list(range(Wn, Wn + Kpool))[::max(1, Kpool // n1)][:n1]
         ctx1 = ctxs + [(model.new_context(), voc.new_context()) for _ in range(max(0, S1 - len(ctxs)))]
         str1 = [torch.cuda.Stream(device=dev) for _ in range(S1)]
         nxt, lk, bar = [0], threading.Lock(), threading.Barrier(S1 + 1)
@@ -385,13 +396,14 @@ def main():
             "metric": "real-time factor (RTFx = audio seconds / wall seconds) + utterances/sec, offline S2ST fr-en",
             "value": round(audio / wall, 2), "unit": "x real-time",
             "utterances_per_sec": round(nutt / wall, 3),
-            "n_gpus": world, "steps": K, "warmup": Wn, "ms_per_step": round(1e3 * wall / K, 3),
+            "n_gpus": world, "steps": Ksteps, "warmup": Wsteps, "ms_per_step": round(1e3 * wall / Ksteps, 3),
+            "utterances_per_step": Bsz, "ms_per_utterance": round(1e3 * wall / K, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "offline S2ST fr-en, B=1 semantics per utterance (ragged no-padding batches), synthetic CVSS-C-shaped utterances "
                                    "(LogNormal(ln 4.5 s, 0.45) clipped to [1,15] s, seed 1234), full "
                                    "fbank+encoder+CTC+AR-MT+T2U+NAR-unit+vocoder HIP path, random-init weights "
                                    "of the streamspeech.offline.fr-en architecture",
-                       "audio_seconds_per_gpu": round(sum(u.seconds for u in mine[Wn:Wn + K]), 2),
+                       "audio_seconds_per_gpu": round(sum(mine[i].seconds for i in timed_ids), 2), "utterances_per_gpu": K,
                        "length_bucketed_batches": (not args.no_length_bucketing) and Bsz > 1, "utterances_per_ragged_batch": Bsz, "concurrent_streams_per_gpu": S,
                        "parallelism": f"utterance-dp{world}"},
             "latency_ms_single_stream": round(single_ms, 3), "rtfx_single_stream": round(single_rtfx, 2),
@@ -403,7 +415,7 @@ def main():
             "roofline_second_kernel": roofline_conv,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, all_utts[Wn:Wn + K + 1])
+            out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, all_utts[Wn:Wn + Kpool + 1])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
