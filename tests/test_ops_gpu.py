@@ -291,3 +291,37 @@ def test_gemv_decode_shapes(lib, M, N, K, act):
     ref = 0.5 * y + R
     assert torch.isfinite(got).all()
     assert (got - ref).abs().max() < TOL, f"max err {(got - ref).abs().max()}"
+
+
+def test_stream_k_fixup_never_reads_stale_partials(lib):
+    """The fix-up workspace slots are reused by every launch (partials travel as sc1 stores/loads past the
+    non-coherent per-XCD L2s).  Alternate two different problems of the same shape 150 times on one stream:
+    every launch must reproduce its own first result bit for bit."""
+    from streamspeech_amd.weights import conv_tap_major
+    M, N, Cin, taps, dil = 4100, 256, 128, 7, 3
+    pad = dil * (taps - 1) // 2
+    W = rnd(N, Cin, taps, seed=41, scale=(Cin * taps) ** -0.5)
+    Wp = conv_tap_major(W).contiguous().cuda()
+    A = [rnd(M, Cin, seed=42 + i).cuda() for i in range(2)]
+    out = [torch.empty(M, N, device="cuda") for _ in range(2)]
+    first = [None, None]
+    lib.ss_debug_force_tile(1, 0, 0)
+    try:
+        for it in range(150):
+            i = it & 1
+            out[i].fill_(float("nan"))
+            L_check = lib.ss_op_conv_gemm(S(), P(A[i]), Cin, P(Wp), None, None, N, None, N, P(out[i]), N, M, N, Cin, taps, dil, 1, pad,
+                                          M, 0, 0, 0.1, 0, 1.0, 0.0, 0)
+            assert L_check == 0
+            if first[i] is None:
+                torch.cuda.synchronize()
+                first[i] = out[i].clone()
+            elif it % 10 < 2 or it > 140:
+                torch.cuda.synchronize()
+                assert torch.equal(out[i], first[i]), f"launch {it} differs"
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)
+    torch.cuda.synchronize()
+    assert lib.ss_debug_sk_errors() == 0
+    ref = _conv_ref(A[0].cpu(), W, None, taps, dil)
+    assert (first[0].cpu() - ref).abs().max() < TOL
