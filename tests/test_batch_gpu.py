@@ -211,3 +211,45 @@ def test_offline_driver_is_deterministic_and_shards_cover_the_set(hip_model, hip
     s1 = offline.generate(hip_model, hip_vocoder, items[1::2], dicts, str(tmp_path / "s1"), "test.shard1", **kw)
     assert sorted(list(s0) + list(s1)) == list(range(192))
     assert hip_model.lib.ss_debug_sk_errors() == 0
+
+
+def test_concurrent_contexts_on_separate_streams_are_bitwise_reproducible(hip_model, hip_vocoder):
+    """bench.py's serving mode: several contexts (own scratch / stream-K workspace, shared weights) run
+    ragged batches at the same time from worker threads.  Every result equals the one computed alone."""
+    import threading
+    from streamspeech_amd import lib as L, synth
+    lib = L.load()
+    codes = [[[int(c) for c in synth.uniform(9, f"cc/{w}/{i}", (k,), 0, 1000)] for i, k in enumerate((120, 35, 260, 77))] for w in range(3)]
+    durs = [[[1 + ((i + j) % 3 == 0) for j in range(len(c))] for i, c in enumerate(cw)] for cw in codes]
+    lib.ss_debug_force_tile(1, 0, 0)          # every eligible conv through stream-K: the fix-up paths run concurrently
+    try:
+        alone = []
+        for w in range(3):
+            wavs, _, _ = hip_vocoder.batch_forward(codes[w], True, forced_dur=durs[w])
+            alone.append([x.clone() for x in wavs])
+        ctxs = [hip_vocoder.new_context() for _ in range(3)]
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        got, errs = [None] * 3, []
+
+        def work(w):
+            try:
+                torch.cuda.set_device(0)
+                with torch.cuda.stream(streams[w]):
+                    for _ in range(4):
+                        wavs, _, _ = ctxs[w].batch_forward(codes[w], True, forced_dur=durs[w])
+                    streams[w].synchronize()
+                    got[w] = [x.clone() for x in wavs]
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=work, args=(w,)) for w in range(3)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        torch.cuda.synchronize()
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)
+    assert not errs, errs
+    for w in range(3):
+        for a, b in zip(alone[w], got[w]):
+            assert torch.equal(a, b)
+    assert lib.ss_debug_sk_errors() == 0
