@@ -352,6 +352,11 @@ def main():
         if roofline_iso:
             roofline_iso.pop("kernel_time_over_wall", None)
             roofline_iso["note"] = "single stream, 3 of the timed batches, untimed for `value`"
+            if roofline:   # the same kernel without the other streams' kernels sharing the chip (see roofline_isolated)
+                roofline["achieved_isolated"] = roofline_iso["achieved"]
+                roofline["frac_isolated"] = roofline_iso["frac"]
+                roofline["note"] = (f"timed region = {S} concurrent streams: a launch's event-bracketed time includes sharing the chip "
+                                    "with the other streams' kernels; *_isolated = same kernel, same batches, one stream")
 
     # Strict configs[1] form: ONE utterance per call (the single-utterance entry points, no ragged packs),
     # 8 utterances in flight on 8 streams (untimed for `value`).
