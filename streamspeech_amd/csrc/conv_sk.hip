@@ -195,17 +195,11 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                   // step k landed for everyone; everyone finished reading stage cur^1
       }
-#ifdef SS_ABLATE
-      if (!(p.dbg & 1))
-#endif
-      if (k + 1 < kb) issue(k + 1, cur ^ 1);
       const float* S = smem + cur * STAGE;
-#ifdef SS_ABLATE
-      if (!(p.dbg & 2))
+#ifndef SK_VARIANT
+#define SK_VARIANT 2   // 1: s_setprio around the MFMA blocks (neutral), 2: first-half fragments before the next DMA issue (+2 %)
 #endif
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        f32x4 af[TM], bf[TN];
+      auto load_frags = [&](int kk, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           af[i] = *reinterpret_cast<const f32x4*>(S + (kk ? rdA1 : rdA0) + i * 16 * BK);
@@ -216,6 +210,11 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(S + (kk ? rdW1 : rdW0) + j * 16 * BK);
+      };
+      auto mma = [&](f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+#if SK_VARIANT & 1
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -223,7 +222,45 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // D = W.A^T: see epilogue
+#if SK_VARIANT & 1
+        __builtin_amdgcn_s_setprio(0);
+#endif
+      };
+#if SK_VARIANT & 2
+      {   // fragments of the first half first (shortest path from the barrier to the first MFMA), then the next step's DMA
+        f32x4 af[TM], bf[TN];
+        load_frags(0, af, bf);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef SS_ABLATE
+        if (!(p.dbg & 1))
+#endif
+        if (k + 1 < kb) issue(k + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#ifdef SS_ABLATE
+        if (!(p.dbg & 2))
+#endif
+        {
+          mma(af, bf);
+          f32x4 af1[TM], bf1[TN];
+          load_frags(1, af1, bf1);
+          mma(af1, bf1);
+        }
       }
+#else
+#ifdef SS_ABLATE
+      if (!(p.dbg & 1))
+#endif
+      if (k + 1 < kb) issue(k + 1, cur ^ 1);
+#ifdef SS_ABLATE
+      if (!(p.dbg & 2))
+#endif
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        f32x4 af[TM], bf[TN];
+        load_frags(kk, af, bf);
+        mma(af, bf);
+      }
+#endif
     }
 
     bool has_end = kb == nk;

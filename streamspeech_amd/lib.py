@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libstreamspeech_hip.so")
+LIB_PATH = os.environ.get("SS_HIP_LIB") or os.path.join(_HERE, "libstreamspeech_hip.so")   # env override: tuning builds (tools/)
 
 
 class SSConfig(C.Structure):
