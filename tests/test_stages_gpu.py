@@ -317,3 +317,26 @@ def test_resample_kernel_matches_oracle(hip_model, sr_in, n):
     want = resample_poly_ref(x, 16000, sr_in)
     assert got.shape == want.shape
     assert np.abs(got - want).max() < 2e-6
+
+
+@pytest.mark.parametrize("seed,T,n_mt,chunk", [(21, 97, 5, 999999), (22, 250, 9, 999999), (23, 611, 20, 999999), (24, 188, 7, 8),
+                                               (25, 333, 12, 16), (26, 1203, 30, 999999), (27, 61, 3, 8), (28, 470, 17, 24)])
+def test_offline_parity_sweep_vs_oracle(hip_model, hip_vocoder, synth_weights, seed, T, n_mt, chunk):
+    """More of the north-star contract on seeded inputs: identical ASR / ST / unit id sequences and durations,
+    waveform RMS <= 1e-3, across utterance lengths 0.6-12 s, offline and chunked encoders, and with the MT
+    tokens produced by the HIP greedy search itself fed to both sides."""
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import synth
+    from streamspeech_amd.pipeline import offline_s2st
+    cfg, vcfg, sd, vsd = synth_weights
+    fb = synth.synth_fbank(seed, T)
+    conv_chunk = 999999 if chunk > 999 else (16 if chunk >= 16 else 8)
+    mt = [int(t) for t in synth.uniform(seed, "forced_mt", (n_mt,), 4, cfg.tgt_vocab)]
+    out = offline_s2st(hip_model, hip_vocoder, torch.from_numpy(fb).cuda(), attn_chunk=chunk, conv_chunk=conv_chunk, forced_mt_tokens=mt)
+    ref = O.offline_s2st(sd, vsd, fb, cfg, vcfg, attn_chunk=chunk, conv_chunk=conv_chunk, forced_mt_tokens=mt)
+    assert out["asr"] == ref["asr"] and out["st"] == ref["st"]
+    assert out["units"] == ref["units"]
+    if ref["units"]:
+        assert out["dur"].cpu().tolist() == ref["dur"].tolist()
+        rms = float(torch.sqrt(torch.mean((out["wav"].cpu() - ref["wav"]) ** 2)))
+        assert rms < WAV_RMS_TOL, f"rms {rms}"
