@@ -192,7 +192,8 @@ const char* ss_prof_class_name(int cls);
 
 /* Tuning hook for tools/conv_bench.py: force the LDS-tiled GEMM tile (bm = 0: heuristic;
  * bm = 1: route every eligible launch to the persistent stream-K kernel with a grid of ks
- * workgroups, ks = 0 -> 2 per CU). */
+ * workgroups, ks = 0 -> 2 per CU; bm = 3: run the narrow-stage resblock pairs of the vocoder as two launches
+ * instead of the fused kernel). */
 int ss_debug_force_tile(int bm, int bn, int ks);
 /* Number of bounded-spin time-outs the stream-K kernel has recorded (any value but 0 is a bug). */
 int ss_debug_sk_errors(void);

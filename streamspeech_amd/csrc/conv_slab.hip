@@ -244,4 +244,244 @@ int launch_conv_slab(const GemmArgs& a, hipStream_t stream) {
   return SS_ERR_ARG;
 }
 
+// =================================================================================================
+// Fused resblock half: y = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x  (hifigan.py:95-102, one of the
+// three (dilated conv, plain conv, residual add) pairs of a ResBlock) for the narrow stages, where both
+// weight matrices fit in LDS next to the slabs.  Per block of 128 output rows: the activated input slab
+// (128 + halo of both convs) is staged once, conv1 is contracted into an LDS `mid` slab (bias, leaky-ReLU,
+// zero outside the utterance = conv2's padding), conv2 reads it back -- the intermediate tensor never
+// goes to HBM (5 tensor passes per pair -> 2: read x, write y).  Same per-element arithmetic as the two
+// separate launches (same tap/channel order inside each conv), so results are bit-identical to them.
+// =================================================================================================
+struct PairArgs {
+  const float* A = nullptr; int lda = 0;            // x: the un-activated residual stream
+  const float* W1 = nullptr; const float* b1 = nullptr;
+  const float* W2 = nullptr; const float* b2 = nullptr;
+  float* C = nullptr; int ldc = 0;                  // y (must not alias A: neighbouring blocks read A's halo)
+  const float* R2 = nullptr; int ldr2 = 0; float div = 0.f;
+  float* C2 = nullptr; int ldc2 = 0; float c2_slope = 0.1f;
+  int taps = 3, dil = 1, M = 0, in_len = 0;
+  float slope = 0.1f;
+  const int* segs = nullptr; int nseg = 0;
+};
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairArgs p, const int slab_rows) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int BM = SL_BM, MT = BM / 16 + 1;  // 9 mid tiles (144 rows >= 128 + 2*h2), 8 output tiles
+  constexpr int Q = C / 4, TN = C / 16, LDA = C + 4;
+  constexpr int NP = (194 * Q + 255) / 256;    // slab float4 per thread (<= 144 + 50 rows)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int K = p.taps * C, LDW = K + 4;
+  float* sW1 = smem;
+  float* sW2 = sW1 + ((C * LDW + 255) & ~255);
+  float* sA = sW2 + ((C * LDW + 255) & ~255);                    // [slab_rows][LDA]
+  float* sM = sA + ((slab_rows * LDA + 255) & ~255);             // [144][LDA]
+  int* s_blk = reinterpret_cast<int*>(sM + ((MT * 16 * LDA + 255) & ~255));
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  for (int idx = t; idx < C * (K / 4); idx += 256) {
+    const int n = idx / (K / 4), k4 = idx - n * (K / 4);
+    *reinterpret_cast<f32x4*>(sW1 + n * LDW + k4 * 4) = *reinterpret_cast<const f32x4*>(p.W1 + (size_t)n * K + k4 * 4);
+    *reinterpret_cast<f32x4*>(sW2 + n * LDW + k4 * 4) = *reinterpret_cast<const f32x4*>(p.W2 + (size_t)n * K + k4 * 4);
+  }
+  const int nseg = p.nseg > 0 ? p.nseg : 1;
+  if (t == 0) {
+    int acc = 0;
+    for (int s = 0; s < nseg; ++s) {
+      s_blk[s] = acc;
+      acc += ((p.nseg > 0 ? p.segs[4 * s + 1] : p.M) + BM - 1) / BM;
+    }
+    s_blk[nseg] = acc;
+  }
+  __syncthreads();
+  const int nblocks = s_blk[nseg];
+  const int h1 = p.dil * (p.taps - 1) / 2, h2 = (p.taps - 1) / 2;
+  const float slope = p.slope;
+
+  f32x4 pre[NP];
+  int seg = 0, seg_lo = 0, seg_hi = 0, m0 = 0;
+  auto locate = [&](int blk) {
+    while (blk >= s_blk[seg + 1]) ++seg;
+    seg_lo = p.nseg > 0 ? p.segs[4 * seg] : 0;
+    seg_hi = seg_lo + (p.nseg > 0 ? p.segs[4 * seg + 1] : p.in_len);
+    m0 = seg_lo + (blk - s_blk[seg]) * BM;
+  };
+  auto prefetch = [&]() {
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int idx = t + u * 256;
+      const int rho = idx / Q, c4 = idx - rho * Q;
+      const int gin = m0 - h2 - h1 + rho;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (rho < slab_rows && gin >= seg_lo && gin < seg_hi)
+        v = *reinterpret_cast<const f32x4*>(p.A + (size_t)gin * p.lda + c4 * 4);
+      pre[u] = v;
+    }
+  };
+  int blk = blockIdx.x;
+  if (blk < nblocks) { locate(blk); prefetch(); }
+  for (; blk < nblocks; blk += gridDim.x) {
+    const int cm0 = m0, clo = seg_lo, chi = seg_hi;
+    __syncthreads();                                       // previous block's conv2 is done with both slabs
+#pragma unroll
+    for (int u = 0; u < NP; ++u) {
+      const int idx = t + u * 256;
+      const int rho = idx / Q, c4 = idx - rho * Q;
+      if (rho < slab_rows) {
+        f32x4 v = pre[u];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * slope;
+        *reinterpret_cast<f32x4*>(sA + rho * LDA + c4 * 4) = v;
+      }
+    }
+    __syncthreads();
+    if (blk + (int)gridDim.x < nblocks) { locate(blk + gridDim.x); prefetch(); }
+
+    // ---- conv1 (dilated) -> mid slab ----
+    for (int mt = wave; mt < MT; mt += 4) {
+      f32x4 acc[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* pa = sA + (mt * 16 + r) * LDA + 4 * g;
+      const float* pw = sW1 + r * LDW + 4 * g;
+      for (int tap = 0; tap < p.taps; ++tap) {
+#pragma unroll
+        for (int cc = 0; cc < C / 16; ++cc) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(pa + cc * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(pw + j * 16 * LDW + cc * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[e], af[e], acc[j], 0, 0, 0);
+          }
+        }
+        pa += p.dil * LDA;
+        pw += C;
+      }
+      const int gm = cm0 - h2 + mt * 16 + r;               // global row of this lane's mid row
+      const bool in_utt = gm >= clo && gm < chi;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b1 + j * 16 + 4 * g);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float x = acc[j][e] + b[e];
+          v[e] = in_utt ? (x > 0.f ? x : x * slope) : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(sM + (mt * 16 + r) * LDA + j * 16 + 4 * g) = v;
+      }
+    }
+    __syncthreads();
+
+    // ---- conv2 (dilation 1) over the mid slab + residual ----
+    for (int ot = wave; ot < BM / 16; ot += 4) {
+      f32x4 acc[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const float* pa = sM + (ot * 16 + r) * LDA + 4 * g;
+      const float* pw = sW2 + r * LDW + 4 * g;
+      for (int tap = 0; tap < p.taps; ++tap) {
+#pragma unroll
+        for (int cc = 0; cc < C / 16; ++cc) {
+          const f32x4 af = *reinterpret_cast<const f32x4*>(pa + cc * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(pw + j * 16 * LDW + cc * 16);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[e], af[e], acc[j], 0, 0, 0);
+          }
+        }
+        pa += LDA;
+        pw += C;
+      }
+      const int m = cm0 + ot * 16 + r;
+      if (m >= chi) continue;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = j * 16 + 4 * g;
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.b2 + n);
+        const f32x4 xr = *reinterpret_cast<const f32x4*>(p.A + (size_t)m * p.lda + n);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (acc[j][e] + b[e]) + xr[e];
+        if (p.R2) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
+        }
+        if (p.div > 0.f) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / p.div;
+        }
+        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+        if (p.C2) {
+          f32x4 w2;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) w2[e] = v[e] > 0.f ? v[e] : v[e] * p.c2_slope;
+          *reinterpret_cast<f32x4*>(p.C2 + (size_t)m * p.ldc2 + n) = w2;
+        }
+      }
+    }
+  }
+#endif
+}
+
+size_t conv_pair_lds(int C, int taps, int dil) {
+  const int K = taps * C;
+  const int slab_rows = 144 + (taps - 1) * dil;
+  auto r256 = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  return (2 * r256((size_t)C * (K + 4)) + r256((size_t)slab_rows * (C + 4)) + r256((size_t)144 * (C + 4))) * sizeof(float) +
+         (SL_MAXSEG + 2) * sizeof(int);
+}
+
+bool conv_pair_eligible(int C, int taps, int dil, int lda, int ldc, int nseg, long long M) {
+  return (C == 16 || C == 32) && lda == C && (ldc & 3) == 0 && (taps & 1) == 1 && taps * C <= 512 && (taps - 1) * dil <= 50 &&
+         nseg <= SL_MAXSEG && M >= 2048 && conv_pair_lds(C, taps, dil) <= 72 * 1024 &&
+         ((size_t)(M + 256) * lda) * 4 < 0x7ff00000ull;
+}
+
+template <int C>
+static int launch_pair_t(const PairArgs& a, hipStream_t stream) {
+  const size_t lds = conv_pair_lds(C, a.taps, a.dil);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<C>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
+    attr_set = true;
+  }
+  if (!g_slab_cus) {
+    int dev = 0;
+    SS_HIP_CHECK(hipGetDevice(&dev));
+    SS_HIP_CHECK(hipDeviceGetAttribute(&g_slab_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (g_slab_cus <= 0) g_slab_cus = 256;
+  }
+  const int nseg = a.nseg > 0 ? a.nseg : 1;
+  const long long max_blocks = (long long)cdiv(a.M, SL_BM) + nseg;
+  const int occ = (int)std::max<size_t>(2, std::min<size_t>(4, (150 * 1024) / lds));
+  const int grid = (int)std::min<long long>((long long)occ * g_slab_cus, std::max<long long>(1, max_blocks));
+  // profiler class of the slab kernels (C = 32 -> 16, C = 16 -> 17); FLOPs of both convs
+  GemmArgs ga;
+  ga.M = a.M; ga.N = C; ga.Cin = C; ga.taps = a.taps; ga.in_len = a.in_len; ga.algo_flops = 4.0 * (double)a.M * C * C * a.taps;
+  ProfRec rec{}; bool prof = false;
+  int rc = prof_begin(ga, stream, C == 32 ? 16 : 17, rec, prof);
+  if (rc != SS_OK) return rc;
+  hipLaunchKernelGGL((conv_pair_kernel<C>), dim3(grid), dim3(256), lds, stream, a, 144 + (a.taps - 1) * a.dil);
+  SS_LAUNCH_CHECK();
+  return prof_end(stream, rec, prof);
+}
+
+int launch_conv_pair(const float* A, int lda, const float* W1, const float* b1, const float* W2, const float* b2, float* Cc,
+                     int ldc, const float* R2, int ldr2, float div, float* C2, int ldc2, float c2_slope, int C, int taps,
+                     int dil, int M, int in_len, float slope, const int* segs, int nseg, hipStream_t stream) {
+  if (!conv_pair_eligible(C, taps, dil, lda, ldc, nseg, M) || A == Cc) return SS_ERR_ARG;
+  PairArgs a;
+  a.A = A; a.lda = lda; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2; a.C = Cc; a.ldc = ldc; a.R2 = R2; a.ldr2 = ldr2;
+  a.div = div; a.C2 = C2; a.ldc2 = ldc2; a.c2_slope = c2_slope; a.taps = taps; a.dil = dil; a.M = M; a.in_len = in_len;
+  a.slope = slope; a.segs = segs; a.nseg = nseg;
+  return C == 32 ? launch_pair_t<32>(a, stream) : launch_pair_t<16>(a, stream);
+}
 }  // namespace ss

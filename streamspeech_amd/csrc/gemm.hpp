@@ -81,6 +81,13 @@ void conv_sk_set_groups(int on);   // tuning hook: XCD tile grouping on/off
 // Slab conv for the narrow vocoder stages (conv_slab.hip): C, N in {16, 32}, weights + input slab in LDS.
 bool conv_slab_eligible(const GemmArgs& a);
 int launch_conv_slab(const GemmArgs& a, hipStream_t stream);
+
+// Fused resblock half y = conv2(lrelu(conv1(lrelu(x)) + b1)) + b2 + x [+ R2] [/ div] for the narrow stages
+// (both weight matrices and the intermediate slab in LDS; conv_slab.hip).  A must not alias C.
+bool conv_pair_eligible(int C, int taps, int dil, int lda, int ldc, int nseg, long long M);
+int launch_conv_pair(const float* A, int lda, const float* W1, const float* b1, const float* W2, const float* b2, float* C,
+                     int ldc, const float* R2, int ldr2, float div, float* C2, int ldc2, float c2_slope, int Cch, int taps,
+                     int dil, int M, int in_len, float slope, const int* segs, int nseg, hipStream_t stream);
    // number of bounded-spin time-outs seen so far (must stay 0)
 
 // True when launch_conv_gemm would route `a` to the small-M kernel (the only one with the fused

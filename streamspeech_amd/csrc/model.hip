@@ -777,11 +777,12 @@ extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
 // HBM-bound late stages (C < 64) the extra write would cost more than the VALU, so the activation
 // stays on the consumer's A-fragment path there.
 // -------------------------------------------------------------------------------------------------
-struct GenBufs { float *bx, *bt, *br, *bs, *bxa, *bra, *bsa; };
+static int g_no_pair_fusion = getenv("SS_NO_PAIR_FUSION") ? atoi(getenv("SS_NO_PAIR_FUSION")) : 0;   // test hook / env knob (ss_debug_force_tile(3, ...)): run the narrow-stage pairs as two launches
+struct GenBufs { float *bx, *bt, *br, *bs, *bxa, *bra, *bsa, *br2; };
 
-template <class ConvFn, class StageFn>
-static int hifigan_stack(const ss_vocoder* v, ConvFn&& conv, StageFn&& on_stage, const float* frames, int Ft,
-                         const GenBufs& b, int* out_scale, int* out_C) {
+template <class ConvFn, class StageFn, class GeomFn>
+static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, StageFn&& on_stage, GeomFn&& geom,
+                         const float* frames, int Ft, const GenBufs& b, int* out_scale, int* out_C) {
   const ss_vocoder_config& c = v->cfg;
   auto preact = [](int channels) { return channels >= 64; };
   auto mk = [](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
@@ -814,8 +815,22 @@ static int hifigan_stack(const ss_vocoder* v, ConvFn&& conv, StageFn&& on_stage,
     const bool pa_next = (i + 1 < c.n_up) && preact(C);     // the next up-conv reads leaky_relu(x)
     for (int j = 0; j < c.n_res; ++j) {
       const int kr = c.resblock_kernel_sizes[j];
+      // narrow stages: each (dilated conv, plain conv, residual) pair as ONE launch with the intermediate in LDS
+      int gM = 0, gnseg = 0; const int* gsegs = nullptr;
+      geom(scale, gM, gsegs, gnseg);
+      const bool fuse = !pa && !g_no_pair_fusion && conv_pair_eligible(C, kr, c.resblock_dilations[j][2], C, C, gnseg, gM);
+      const float* cur = b.bs;
       for (int dd = 0; dd < 3; ++dd) {
         const int idx = (i * c.n_res + j) * 3 + dd;
+        if (fuse) {
+          float* out = dd == 0 ? b.br : dd == 1 ? b.br2 : b.bx;
+          const float* R2 = (dd == 2 && j > 0) ? b.bx : nullptr;
+          const float div = (dd == 2 && j == c.n_res - 1) ? (float)c.n_res : 0.f;
+          RET(launch_conv_pair(cur, C, v->rb_c1[idx].w, v->rb_c1[idx].b, v->rb_c2[idx].w, v->rb_c2[idx].b, out, C, R2, C, div,
+                               nullptr, C, 0.1f, C, kr, c.resblock_dilations[j][dd], gM, gM, 0.1f, gsegs, gnseg, s));
+          cur = out;
+          continue;
+        }
         const float* rin = dd == 0 ? b.bs : b.br;           // residual stream (un-activated)
         const float* rin_act = dd == 0 ? b.bsa : b.bra;     // its leaky_relu, when pre-activated
         GemmArgs a1 = mk(pa ? rin_act : rin, C, v->rb_c1[idx], C, kr, c.resblock_dilations[j][dd], b.bt, C);
@@ -897,7 +912,7 @@ extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_
     int T = Fr, C = c.upsample_initial_channel;
     for (int i = 0; i < c.n_up; ++i) { T *= c.upsample_rates[i]; C /= 2; stage_max = std::max(stage_max, (size_t)T * C); }
   }
-  RET(v->ws.ensure((7 * stage_max + (size_t)Fr * E) * sizeof(float)));
+  RET(v->ws.ensure((8 * stage_max + (size_t)Fr * E) * sizeof(float)));
   float* frames = v->ws.f();
   GenBufs gb;
   gb.bx = frames + (size_t)Fr * E;       // stage input / MRF accumulator
@@ -907,10 +922,13 @@ extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_
   gb.bxa = gb.bs + stage_max;            // leaky_relu twins of bx / br / bs (MFMA-bound stages only)
   gb.bra = gb.bxa + stage_max;
   gb.bsa = gb.bra + stage_max;
+  gb.br2 = gb.bsa + stage_max;           // second resblock state (fused pairs ping-pong br / br2)
   RET(launch_repeat_rows(emb, cum, K, E, frames, Fr, s));
   int T = 1, C = 0;
-  RET(hifigan_stack(v, [&](GemmArgs& a, int scale) { a.M = Fr * scale; a.in_len = Fr * scale; return launch_conv_gemm(a, s); },
-                    [](int) { return SS_OK; }, frames, Fr, gb, &T, &C));
+  RET(hifigan_stack(v, s, [&](GemmArgs& a, int scale) { a.M = Fr * scale; a.in_len = Fr * scale; return launch_conv_gemm(a, s); },
+                    [](int) { return SS_OK; },
+                    [&](int scale, int& M, const int*& segs, int& nseg) { M = Fr * scale; segs = nullptr; nseg = 0; },
+                    frames, Fr, gb, &T, &C));
   T *= Fr;
   float* bx = gb.bx;
   // leaky_relu (default slope 0.01, hifigan.py:166) -> conv_post -> tanh
@@ -1278,7 +1296,7 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
     int T = Ft, C = c.upsample_initial_channel;
     for (int i = 0; i < c.n_up; ++i) { T *= c.upsample_rates[i]; C /= 2; stage_max = std::max(stage_max, (size_t)T * C); }
   }
-  RET(v->ws.ensure((7 * stage_max + (size_t)Ft * E) * sizeof(float)));
+  RET(v->ws.ensure((8 * stage_max + (size_t)Ft * E) * sizeof(float)));
   float* frames = v->ws.f();
   GenBufs gb;
   gb.bx = frames + (size_t)Ft * E;
@@ -1288,6 +1306,7 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
   gb.bxa = gb.bs + stage_max;
   gb.bra = gb.bxa + stage_max;
   gb.bsa = gb.bra + stage_max;
+  gb.br2 = gb.bsa + stage_max;
   // frame-axis tables, rebuilt per stage (rows scale by the running hop)
   int* dseg = dk + 6 * B;            // conv segs [B][4]
   int* drep = dseg + 4 * B;          // repeat_rows segs [B][4]
@@ -1304,12 +1323,14 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
   }
   RET(launch_repeat_rows(emb, cum, 0, E, frames, of.mx, s, drep, B));
   int scale = 1, C = 0;
-  RET(hifigan_stack(v,
+  RET(hifigan_stack(v, s,
                     [&](GemmArgs& a, int sc) {
                       a.segs = dseg; a.nseg = B; a.max_seg_out = of.mx * sc; a.M = Ft * sc; a.in_len = Ft * sc;
                       return launch_conv_gemm(a, s);
                     },
-                    stage_segs, frames, Ft, gb, &scale, &C));
+                    stage_segs,
+                    [&](int sc, int& M, const int*& segs, int& nseg) { M = Ft * sc; segs = dseg; nseg = B; },
+                    frames, Ft, gb, &scale, &C));
   float* bx = gb.bx;
   {
     std::vector<int> t(2 * B);
@@ -1366,5 +1387,9 @@ extern "C" int ss_prof_read(int cls, double* ms, double* flops, int64_t* launche
 extern "C" int ss_prof_num_classes(void) { return kNumTileCfg; }
 extern "C" const char* ss_prof_class_name(int cls) { return prof_cfg_name(cls); }
 
-extern "C" int ss_debug_force_tile(int bm, int bn, int ks) { debug_force_tile(bm, bn, ks); return SS_OK; }
+extern "C" int ss_debug_force_tile(int bm, int bn, int ks) {
+  if (bm == 3 || bm == 0) g_no_pair_fusion = (bm == 3);            // bm = 3: narrow-stage resblock pairs as two launches (A/B of the fused kernel)
+  debug_force_tile(bm == 3 ? 0 : bm, bn, ks);
+  return SS_OK;
+}
 extern "C" int ss_debug_sk_errors(void) { return conv_sk_error_count(); }

@@ -253,3 +253,26 @@ def test_concurrent_contexts_on_separate_streams_are_bitwise_reproducible(hip_mo
         for a, b in zip(alone[w], got[w]):
             assert torch.equal(a, b)
     assert lib.ss_debug_sk_errors() == 0
+
+
+def test_fused_resblock_pairs_equal_the_two_launch_form_bitwise(hip_vocoder, synth_weights):
+    """conv_pair_kernel (narrow stages: conv1 -> leaky-ReLU -> conv2 -> +x with the intermediate in LDS) performs
+    the same per-element arithmetic as the two separate launches: waveforms are bit-identical, single and ragged."""
+    from streamspeech_amd import lib as L, synth
+    lib = L.load()
+    codes = [[int(c) for c in synth.uniform(13, f"fp/{i}", (k,), 0, 1000)] for i, k in enumerate((90, 33, 150))]
+    durs = [[1 + (j % 4 == 1) for j in range(len(c))] for c in codes]
+    fused, _, _ = hip_vocoder.batch_forward(codes, True, forced_dur=durs)
+    f1, _ = hip_vocoder.forward(torch.tensor(codes[2], dtype=torch.int32, device="cuda:0"), True,
+                                forced_dur=torch.tensor(durs[2], dtype=torch.int32, device="cuda:0"))
+    fused = [w.clone() for w in fused]; f1 = f1.clone()
+    lib.ss_debug_force_tile(3, 0, 0)
+    try:
+        plain, _, _ = hip_vocoder.batch_forward(codes, True, forced_dur=durs)
+        p1, _ = hip_vocoder.forward(torch.tensor(codes[2], dtype=torch.int32, device="cuda:0"), True,
+                                    forced_dur=torch.tensor(durs[2], dtype=torch.int32, device="cuda:0"))
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)
+    for a, b in zip(fused, plain):
+        assert torch.equal(a, b)
+    assert torch.equal(f1, p1)
