@@ -253,6 +253,43 @@ int launch_conv_slab(const GemmArgs& a, hipStream_t stream) {
 // goes to HBM (5 tensor passes per pair -> 2: read x, write y).  Same per-element arithmetic as the two
 // separate launches (same tap/channel order inside each conv), so results are bit-identical to them.
 // =================================================================================================
+// NT (1 or 2) 16-row tiles of one conv contracted together out of LDS slabs: two tiles give two independent
+// accumulator chains per n-tile (a single chain is bound by the MFMA dependent-issue latency) and share the
+// weight fragments.
+template <int C, int NT>
+__device__ __forceinline__ void slab_tiles(const float* __restrict__ slab, int lda, const float* __restrict__ sW, int ldw,
+                                           int taps, int tap_rows, int r, int g, const int (&tile)[2],
+                                           f32x4 (&acc)[2][C / 16]) {
+  constexpr int TN = C / 16;
+#pragma unroll
+  for (int u = 0; u < NT; ++u)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float* pa0 = slab + (tile[0] * 16 + r) * lda + 4 * g;
+  const float* pa1 = slab + (tile[NT - 1] * 16 + r) * lda + 4 * g;
+  const float* pw = sW + r * ldw + 4 * g;
+  for (int tap = 0; tap < taps; ++tap) {
+#pragma unroll
+    for (int cc = 0; cc < C / 16; ++cc) {
+      f32x4 af[2];
+      af[0] = *reinterpret_cast<const f32x4*>(pa0 + cc * 16);
+      if (NT == 2) af[1] = *reinterpret_cast<const f32x4*>(pa1 + cc * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const f32x4 bf = *reinterpret_cast<const f32x4*>(pw + j * 16 * ldw + cc * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int u = 0; u < NT; ++u)
+            acc[u][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[e], af[u][e], acc[u][j], 0, 0, 0);
+      }
+    }
+    pa0 += tap_rows * lda;
+    pa1 += tap_rows * lda;
+    pw += C;
+  }
+}
+
 struct PairArgs {
   const float* A = nullptr; int lda = 0;            // x: the un-activated residual stream
   const float* W1 = nullptr; const float* b1 = nullptr;
@@ -341,26 +378,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairArgs p, con
     if (blk + (int)gridDim.x < nblocks) { locate(blk + gridDim.x); prefetch(); }
 
     // ---- conv1 (dilated) -> mid slab ----
-    for (int mt = wave; mt < MT; mt += 4) {
-      f32x4 acc[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* pa = sA + (mt * 16 + r) * LDA + 4 * g;
-      const float* pw = sW1 + r * LDW + 4 * g;
-      for (int tap = 0; tap < p.taps; ++tap) {
-#pragma unroll
-        for (int cc = 0; cc < C / 16; ++cc) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(pa + cc * 16);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const f32x4 bf = *reinterpret_cast<const f32x4*>(pw + j * 16 * LDW + cc * 16);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[e], af[e], acc[j], 0, 0, 0);
-          }
-        }
-        pa += p.dil * LDA;
-        pw += C;
-      }
+    auto conv1_out = [&](int mt, const f32x4 (&a)[TN]) {   // bias, leaky-ReLU, zero outside the utterance -> mid slab
       const int gm = cm0 - h2 + mt * 16 + r;               // global row of this lane's mid row
       const bool in_utt = gm >= clo && gm < chi;
 #pragma unroll
@@ -369,36 +387,33 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairArgs p, con
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float x = acc[j][e] + b[e];
+          const float x = a[j][e] + b[e];
           v[e] = in_utt ? (x > 0.f ? x : x * slope) : 0.f;
         }
         *reinterpret_cast<f32x4*>(sM + (mt * 16 + r) * LDA + j * 16 + 4 * g) = v;
+      }
+    };
+    {
+      f32x4 acc[2][TN];
+      const int t2[2] = {wave, wave + 4};                  // mid tiles w and w+4 together, the 9th tile on the last wave
+      slab_tiles<C, 2>(sA, LDA, sW1, LDW, p.taps, p.dil, r, g, t2, acc);
+      conv1_out(t2[0], acc[0]);
+      conv1_out(t2[1], acc[1]);
+      if (wave == 3) {
+        const int t1[2] = {MT - 1, MT - 1};
+        slab_tiles<C, 1>(sA, LDA, sW1, LDW, p.taps, p.dil, r, g, t1, acc);
+        conv1_out(t1[0], acc[0]);
       }
     }
     __syncthreads();
 
     // ---- conv2 (dilation 1) over the mid slab + residual ----
-    for (int ot = wave; ot < BM / 16; ot += 4) {
-      f32x4 acc[TN];
+    f32x4 acc2[2][TN];
+    const int o2[2] = {wave, wave + 4};
+    slab_tiles<C, 2>(sM, LDA, sW2, LDW, p.taps, 1, r, g, o2, acc2);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      const float* pa = sM + (ot * 16 + r) * LDA + 4 * g;
-      const float* pw = sW2 + r * LDW + 4 * g;
-      for (int tap = 0; tap < p.taps; ++tap) {
-#pragma unroll
-        for (int cc = 0; cc < C / 16; ++cc) {
-          const f32x4 af = *reinterpret_cast<const f32x4*>(pa + cc * 16);
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const f32x4 bf = *reinterpret_cast<const f32x4*>(pw + j * 16 * LDW + cc * 16);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[e], af[e], acc[j], 0, 0, 0);
-          }
-        }
-        pa += LDA;
-        pw += C;
-      }
-      const int m = cm0 + ot * 16 + r;
+    for (int u = 0; u < 2; ++u) {
+      const int m = cm0 + o2[u] * 16 + r;
       if (m >= chi) continue;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
@@ -407,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_pair_kernel(const PairArgs p, con
         const f32x4 xr = *reinterpret_cast<const f32x4*>(p.A + (size_t)m * p.lda + n);
         f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (acc[j][e] + b[e]) + xr[e];
+        for (int e = 0; e < 4; ++e) v[e] = (acc2[u][j][e] + b[e]) + xr[e];
         if (p.R2) {
           const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + n);
 #pragma unroll

@@ -818,7 +818,10 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
       // narrow stages: each (dilated conv, plain conv, residual) pair as ONE launch with the intermediate in LDS
       int gM = 0, gnseg = 0; const int* gsegs = nullptr;
       geom(scale, gM, gsegs, gnseg);
-      const bool fuse = !pa && !g_no_pair_fusion && conv_pair_eligible(C, kr, c.resblock_dilations[j][2], C, C, gnseg, gM);
+      // measured per kernel size (rocprofv3, batch 32): fused wins 20-25 % at k = 3 (HBM-bound), ties at k = 7, loses
+      // 10-30 % at k = 11 (MFMA-bound: halo rows of conv1 are extra work and the 54-KB footprint halves the occupancy)
+      const bool fuse = !pa && !g_no_pair_fusion && kr == 3 &&
+                        conv_pair_eligible(C, kr, c.resblock_dilations[j][2], C, C, gnseg, gM);
       const float* cur = b.bs;
       for (int dd = 0; dd < 3; ++dd) {
         const int idx = (i * c.n_res + j) * 3 + dd;
