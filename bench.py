@@ -145,12 +145,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # one process per GPU; the modulo only matters for the 2-ranks-on-1-GPU smoke test of this code path
+    # (SS_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2)
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("SS_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     cfg, vcfg = ModelConfig(), VocoderConfig()
     sd = synth.make_model_state_dict(0, cfg)
