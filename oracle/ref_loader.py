@@ -172,19 +172,29 @@ def load():
     _mod("fairseq", utils=utils, checkpoint_utils=_mod("fairseq.checkpoint_utils"))
     inc = _load_file("fairseq.incremental_decoding_utils", "fairseq/fairseq/incremental_decoding_utils.py")
 
-    class FairseqIncrementalDecoder(inc.FairseqIncrementalState, nn.Module):
-        def __init__(self, dictionary=None):
-            super().__init__()
-            self.dictionary = dictionary
-
-    class FairseqEncoder(nn.Module):
-        def __init__(self, dictionary=None):
-            super().__init__()
-            self.dictionary = dictionary
-
-    _mod("fairseq.models", FairseqIncrementalDecoder=FairseqIncrementalDecoder, FairseqEncoder=FairseqEncoder,
-         register_model=_identity_decorator, register_model_architecture=_identity_decorator)
-    _mod("fairseq.models.fairseq_incremental_decoder", FairseqIncrementalDecoder=FairseqIncrementalDecoder)
+    # the reference's own base classes (pure torch): FairseqDecoder.get_normalized_probs is what the
+    # generators call (fairseq/models/fairseq_decoder.py:59-90), FairseqEncoder.forward_torchscript what
+    # EnsembleModel.forward_encoder calls (fairseq/models/fairseq_encoder.py)
+    fm = _mod("fairseq.models", register_model=_identity_decorator, register_model_architecture=_identity_decorator)
+    fdec = _load_file("fairseq.models.fairseq_decoder", "fairseq/fairseq/models/fairseq_decoder.py")
+    fm.FairseqDecoder = fdec.FairseqDecoder
+    fenc = _load_file("fairseq.models.fairseq_encoder", "fairseq/fairseq/models/fairseq_encoder.py")
+    fm.FairseqEncoder = fenc.FairseqEncoder
+    fincd = _load_file("fairseq.models.fairseq_incremental_decoder",
+                       "fairseq/fairseq/models/fairseq_incremental_decoder.py")
+    FairseqIncrementalDecoder = fincd.FairseqIncrementalDecoder
+    fm.FairseqIncrementalDecoder = FairseqIncrementalDecoder
+    if "omegaconf" not in sys.modules:          # fairseq_model.py imports the name only
+        om = types.ModuleType("omegaconf")
+        om.DictConfig = type("DictConfig", (), {})
+        sys.modules["omegaconf"] = om
+    _mod("fairseq.data", Dictionary=type("Dictionary", (), {}))
+    _mod("fairseq.dataclass")
+    _mod("fairseq.dataclass.utils", convert_namespace_to_omegaconf=lambda a: a,
+         gen_parser_from_dataclass=lambda *a, **k: None)
+    fmodel = _load_file("fairseq.models.fairseq_model", "fairseq/fairseq/models/fairseq_model.py")
+    for name in ("BaseFairseqModel", "FairseqEncoderDecoderModel", "FairseqEncoderModel", "FairseqLanguageModel"):
+        setattr(fm, name, getattr(fmodel, name))
     _mod("fairseq.models.transformer", TransformerConfig=_TransformerConfig, Linear=_linear)
     _mod("fairseq.models.speech_to_text")
     _mod("fairseq.models.text_to_speech")
@@ -199,7 +209,6 @@ def load():
         mask = torch.arange(max_lens).to(lens.device).view(1, max_lens)
         return mask.expand(bsz, -1) >= lens.view(bsz, 1).expand(-1, max_lens)
     _mod("fairseq.data.data_utils", lengths_to_padding_mask=lengths_to_padding_mask)
-    _mod("fairseq.models.speech_to_text.s2t_transformer", base_architecture=lambda args: None)
     _mod("fairseq.distributed", fsdp_wrap=lambda m, **k: m)
     _mod("fairseq.modules.fairseq_dropout", FairseqDropout=_FairseqDropout)
     _mod("fairseq.modules.quant_noise", quant_noise=lambda m, p=0, block_size=8: m)
@@ -221,6 +230,15 @@ def load():
             embedding_dim, padding_idx, init_size=num_embeddings + padding_idx + 1)
     fmods.PositionalEmbedding = PositionalEmbedding
 
+    # S2TTransformerEncoder: ChunkS2TConformerEncoder borrows its reorder_encoder_out (s2t_conformer.py:217)
+    fmods.TransformerEncoderLayer = type("TransformerEncoderLayer", (nn.Module,), {})
+    sys.modules["fairseq.models.transformer"].Embedding = nn.Embedding
+    _mod("fairseq.models.speech_to_text.hub_interface")
+    _mod("fairseq.models.speech_to_text.modules")
+    _load_file("fairseq.models.speech_to_text.modules.convolution",
+               "fairseq/fairseq/models/speech_to_text/modules/convolution.py")
+    _load_file("fairseq.models.speech_to_text.s2t_transformer",
+               "fairseq/fairseq/models/speech_to_text/s2t_transformer.py")
     # research packages (user-dir style imports: uni_unity / chunk_unity / ctc_unity)
     for pkg in ("uni_unity", "uni_unity.modules", "chunk_unity", "chunk_unity.modules",
                 "ctc_unity", "ctc_unity.modules"):

@@ -287,11 +287,16 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
                 if j == 0:
                     return ReadAction()
 
+        # agent :576-591: max_tgt_len = len(tokens) (+1 in whole-word mode), row = [eos, tokens-without-eos, <pad>...].
+        # A non-final whole-word hypothesis was cut to [:j] above and lost its eos, so its row has NO pad; a
+        # final one keeps the eos and gets exactly one trailing <pad> position.
+        max_tgt_len = len(hyp["tokens"]) + (1 if self.whole_word else 0)
         tmp = hyp["tokens"].int()
         if len(tmp) > 0 and tmp[-1] == self.generator_mt.eos:
             tmp = tmp[:-1]
-        n_tail_pad = 1 if self.whole_word else 0
-        prev_output_tokens_mt = torch.full((1, len(tmp) + 1 + n_tail_pad), self.model.target_unigram_decoder.padding_idx
+        n_tail_pad = max_tgt_len - (len(tmp) + 1)
+        assert n_tail_pad in (0, 1), "hypothesis without eos outside whole-word mode (the reference fails here too)"
+        prev_output_tokens_mt = torch.full((1, max_tgt_len), self.model.target_unigram_decoder.padding_idx
                                            if hasattr(self.model, "target_unigram_decoder") else 1, dtype=torch.int32)
         prev_output_tokens_mt[0, 0] = self.generator_mt.eos
         prev_output_tokens_mt[0, 1:len(tmp) + 1] = tmp

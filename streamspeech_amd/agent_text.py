@@ -32,7 +32,9 @@ class _TextAgentBase(SpeechToTextAgent):
         self.asr_ctc_generator = CTCDecoder(self.dict["source_unigram"], eng, 0)
         self.st_ctc_generator = CTCDecoder(self.dict["ctc_target_unigram"], eng, 1)
         tgt_dict_mt = self.dict[self.model.mt_task_name]
-        self.generator_mt = SequenceGenerator(eng, tgt_dict_mt, beam_size=1, max_len_a=0, max_len_b=100, max_len=0,
+        # the text agents search with max_len_a=1, max_len_b=200 (s2tt agent :161-180) -- NOT the S2ST agent's 0 / 100:
+        # a final hypothesis may run to (fbank frames + 200) subwords
+        self.generator_mt = SequenceGenerator(eng, tgt_dict_mt, beam_size=1, max_len_a=1, max_len_b=200, max_len=0,
                                               min_len=1, eos=tgt_dict_mt.eos(), use_incremental_states=False)
         self.lagging_k1, self.stride_n = args.lagging_k1, args.stride_n
         self.quiet = args.extra_output_dir is None

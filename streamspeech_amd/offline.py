@@ -57,8 +57,8 @@ def ordered_batches(lengths: Sequence[int], batch_size: int, max_tokens: int = 0
 
 
 def generate(model, vocoder, items: Sequence[Tuple[int, torch.Tensor]], dicts: Dict[str, object], results_path: str,
-             subset: str = "test", batch_size: int = 32, max_tokens: int = 0, max_len_a: float = 1.0,
-             max_len_b: int = 200, dur_prediction: bool = True, dump_wav: bool = True, t2u_causal: bool = False,
+             subset: str = "test", batch_size: int = 32, max_tokens: int = 0, max_len_a: float = 0.0,
+             max_len_b: int = 200, max_len_a_mt: float = 0.0, max_len_b_mt: int = 200, dur_prediction: bool = True, dump_wav: bool = True, t2u_causal: bool = False,
              scores: bool = False, log=None) -> Dict[int, Dict]:
     """items: (sample id, 16 kHz float PCM in [-1, 1] on the device).  Writes generate-<subset>.log/.txt,
     the cut .asr/.tgt/.unit files and pred_wav/<n>_pred.wav; returns the per-id hypotheses."""
@@ -84,8 +84,11 @@ def generate(model, vocoder, items: Sequence[Tuple[int, torch.Tensor]], dicts: D
         enc, Tp = model.batch_encoder_forward(feat, T)
         asr = model.batch_ctc_greedy(0, enc, Tp)
         st = model.batch_ctc_greedy(1, enc, Tp)
-        # generate_decoder: max_len = min(int(max_len_a * src_len + max_len_b), max_decoder_positions - 1)
-        mx = [min(int(max_len_a * tp + max_len_b), cfg.max_target_positions - 1) for tp in Tp]
+        # first-pass text search: max_len = min(int(max_len_a_mt * src_len + max_len_b_mt), max positions - 1) with
+        # the task's defaults 0 / 200 (tasks/speech_to_speech_ctc.py:39-40 -> sequence_generator_multi_decoder_ctc.py
+        # :130-131); src_len is the fbank frame count.  --max-len-a/-b configure the (NAR) unit generator, which has
+        # no length search here.
+        mx = [min(int(max_len_a_mt * t + max_len_b_mt), cfg.max_target_positions - 1) for t in T]
         toks, feats, n = model.batch_mt_greedy(enc, Tp, mx)
         unit_toks = model.batch_t2u_units(feats, n, t2u_causal=t2u_causal, mask_eos=True)
         codes = [units_from_tokens(t, cfg) for t in unit_toks]
@@ -179,8 +182,10 @@ def main(argv: Optional[List[str]] = None):
     ap.add_argument("--synthetic", type=int, default=0, help="N synthetic utterances instead of files")
     ap.add_argument("--batch-size", type=int, default=32)
     ap.add_argument("--max-tokens", type=int, default=0)
-    ap.add_argument("--max-len-a", type=float, default=1.0)
+    ap.add_argument("--max-len-a", type=float, default=0.0, help="unit generator (kept for CLI parity; the NAR decoder has no length search)")
     ap.add_argument("--max-len-b", type=int, default=200)
+    ap.add_argument("--max-len-a-mt", type=float, default=0.0, help="first-pass text search: max_len = a * src_len + b")
+    ap.add_argument("--max-len-b-mt", type=int, default=200)
     ap.add_argument("--dur-prediction", action="store_true")
     ap.add_argument("--no-wav", action="store_true")
     ap.add_argument("--scores", action="store_true")
@@ -226,7 +231,8 @@ def main(argv: Optional[List[str]] = None):
         items.append((e[0], pcm))
     sub = a.gen_subset if a.num_shards == 1 else f"{a.gen_subset}.shard{a.shard_id}"
     hyps = generate(model, voc, items, holder.dict, a.results_path, sub, a.batch_size, a.max_tokens, a.max_len_a,
-                    a.max_len_b, a.dur_prediction, not a.no_wav, getattr(holder.model, "uni_encoder", False), a.scores)
+                    a.max_len_b, a.max_len_a_mt, a.max_len_b_mt, a.dur_prediction, not a.no_wav,
+                    getattr(holder.model, "uni_encoder", False), a.scores)
     print(f"| generated {len(hyps)} utterances into {a.results_path}", file=sys.stderr)
 
 

@@ -129,8 +129,8 @@ def test_offline_driver_writes_fairseq_generate_format(hip_model, hip_vocoder, t
                                                        ("target_unigram", cfg.tgt_vocab))}
     secs = [1.3, 2.9, 0.8, 2.1, 1.7]
     items = [(10 + i, torch.from_numpy(synth.synth_pcm(70 + i, int(16000 * s))).to(hip_model.device)) for i, s in enumerate(secs)]
-    hyps = offline.generate(hip_model, hip_vocoder, items, dicts, str(tmp_path), "test", batch_size=3, max_len_a=0.0,
-                            max_len_b=12, dur_prediction=True, dump_wav=True)
+    hyps = offline.generate(hip_model, hip_vocoder, items, dicts, str(tmp_path), "test", batch_size=3, max_len_a_mt=0.0,
+                            max_len_b_mt=12, dur_prediction=True, dump_wav=True)
     assert sorted(hyps) == [10, 11, 12, 13, 14]
     log = (tmp_path / "generate-test.log").read_text().splitlines()
     assert sorted(ln.split("\t")[0] for ln in log) == sorted(f"{p}-{i}" for p in "ASD" for i in range(10, 15))
@@ -200,7 +200,7 @@ def test_offline_driver_is_deterministic_and_shards_cover_the_set(hip_model, hip
     durs = synth.synth_durations(77, 192)
     items = [(i, torch.from_numpy(synth.synth_pcm(300 + i, int(16000 * min(float(d), 4.0)))).to(hip_model.device))
              for i, d in enumerate(durs)]
-    kw = dict(batch_size=32, max_len_a=0.0, max_len_b=6, dur_prediction=True, dump_wav=False)
+    kw = dict(batch_size=32, max_len_a_mt=0.0, max_len_b_mt=6, dur_prediction=True, dump_wav=False)
     a = offline.generate(hip_model, hip_vocoder, items, dicts, str(tmp_path / "a"), "test", **kw)
     b = offline.generate(hip_model, hip_vocoder, items, dicts, str(tmp_path / "b"), "test", **kw)
     assert sorted(a) == list(range(192))

@@ -78,7 +78,7 @@ def test_offline_driver_on_cpu_doubles(tmp_path):
                                                        ("target_unigram", cfg.tgt_vocab))}
     items = [(7 + i, torch.from_numpy(synth.synth_pcm(90 + i, int(16000 * s)))) for i, s in enumerate((0.9, 1.6, 0.7))]
     items.append((10, torch.zeros(123)))                            # shorter than one fbank window: empty hypothesis
-    hyps = offline.generate(eng, voc, items, dicts, str(tmp_path), "dev", batch_size=2, max_len_a=0.0, max_len_b=4,
+    hyps = offline.generate(eng, voc, items, dicts, str(tmp_path), "dev", batch_size=2, max_len_a_mt=0.0, max_len_b_mt=4,
                             dur_prediction=True, dump_wav=True)
     assert sorted(hyps) == [7, 8, 9, 10] and hyps[10]["units"] == []
     log = (tmp_path / "generate-dev.log").read_text().splitlines()
