@@ -52,19 +52,7 @@ def run_utterance(model, voc, pcm, utt):
     return wav, len(asr), len(st), len(toks)
 
 
-def run_batch(model, voc, pcm_packed, utts):
-    """The same hot path for a ragged batch of utterances (each keeps B = 1 arithmetic; launches,
-    weight streaming and tile occupancy are shared -- streamspeech_amd/csrc/model.hip ss_batch_*)."""
-    cfg = model.cfg
-    feat, T = model.batch_fbank_cmvn(pcm_packed, [u.n_samples for u in utts])
-    enc, Tp = model.batch_encoder_forward(feat, T)
-    asr = model.batch_ctc_greedy(0, enc, Tp)
-    st = model.batch_ctc_greedy(1, enc, Tp)
-    toks, feats, n = model.batch_mt_greedy(enc, Tp, [u.n_mt for u in utts])
-    unit_toks = model.batch_t2u_units(feats, n)
-    codes = [workload.resize_units(units_from_tokens(t, cfg), u.n_units, u.idx) for t, u in zip(unit_toks, utts)]
-    wavs, dur, _ = voc.batch_forward(codes, dur_prediction=True, forced_dur=[u.durations for u in utts])
-    return wavs, asr, st, toks
+run_batch = workload.run_batch      # the timed step; tests/test_bench_config_gpu.py checks this very function against the oracle
 
 
 def cpu_baseline(sd, vsd, cfg, vcfg, utts, budget_s=25.0):
@@ -120,7 +108,14 @@ def cpu_baseline(sd, vsd, cfg, vcfg, utts, budget_s=25.0):
             "sample": f"{n} utterances ({audio:.1f} s of audio) of the same synthetic workload, after 1 warm-up"}
 
 
-PMC_FILE = "r01_pmc_traffic_v16.json"
+def _pmc_file():
+    """Newest committed PMC summary (profiles/rNN_pmc_traffic*.json, written by tools/pmc_traffic.py)."""
+    import glob
+    names = sorted(os.path.basename(p) for p in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic*.json")))
+    return names[-1] if names else None
+
+
+PMC_FILE = _pmc_file()
 
 
 def main():
@@ -171,14 +166,9 @@ def main():
     K = Ksteps * Bsz                         # timed utterances per rank
     Kpool = min(K, 2048)                     # distinct synthetic utterances per rank (cycled beyond that)
     Wn = 3                                   # single-utterance warm-ups (first-touch of every code path)
-    all_utts = workload.make_utterances((Kpool + Wn) * world)
-    # weak scaling: the same number of utterances per rank.  The timed pool is length-sorted before the
-    # round-robin deal, so every rank also gets ~the same audio seconds.
-    warm_all, timed_all = all_utts[:Wn * world], all_utts[Wn * world:]
-    timed_all = sorted(timed_all, key=lambda u: -u.seconds)
-    mine = dp.shard(warm_all, rank, world) + dp.shard(timed_all, rank, world)
+    mine, groups = workload.bench_plan(Ksteps, Bsz, rank, world, bucket=not args.no_length_bucketing, warm=Wn)
     pcms = [torch.from_numpy(synth.synth_pcm(1234 + u.idx, u.n_samples)).to(dev) for u in mine]
-    timed_ids = [Wn + (i % Kpool) for i in range(K)]
+    timed_ids = [i for g in groups for i in g]
     torch.cuda.synchronize()
 
     for u, p in zip(mine[:Wn], pcms[:Wn]):
@@ -225,25 +215,16 @@ def main():
     import threading
     ctxs = [(model, voc)] + [(model.new_context(), voc.new_context()) for _ in range(S - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    timed = [(mine[i], pcms[i]) for i in timed_ids]
+    # one work item per timed step: the utterances of the ragged batch + their packed PCM (built before the timed region)
     if Bsz == 1:
-        work = timed
+        work = [(mine[g[0]], pcms[g[0]]) for g in groups]
     else:
-        # Groups of Bsz utterances; the packed PCM buffer is built before the timed region.  Like the
-        # reference's offline driver (fairseq-generate: dataset.ordered_indices() sorts by source
-        # length before batch_by_size, fairseq/tasks/fairseq_task.py get_batch_iterator), batches are
-        # formed from length-sorted utterances: the lock-step MT greedy search then runs ~mean instead
-        # of ~max-of-32 steps per batch.  Longest batches are dispatched first (LPT over the streams).
-        if not args.no_length_bucketing:
-            timed = sorted(timed, key=lambda t: -t[0].n_samples)
-        work = []
-        for g0 in range(0, len(timed), Bsz):
-            grp = timed[g0:g0 + Bsz]
-            work.append(([u for u, _ in grp], torch.cat([p for _, p in grp])))
+        work = [([mine[i] for i in g], torch.cat([pcms[i] for i in g])) for g in groups]
     longest = max(range(len(mine)), key=lambda i: mine[i].seconds)
     next_idx = [0]
     lock = threading.Lock()
-    start_evt = threading.Barrier(S + 1)
+    ready_evt = threading.Barrier(S + 1)   # every context warmed up (nothing of the warm-up may be profiled or timed)
+    start_evt = threading.Barrier(S + 1)   # released at t0, after the counters were reset and switched on
     samples = [0] * S
     errors = []
 
@@ -257,6 +238,7 @@ def main():
                     big = max(work, key=lambda w: w[1].numel())
                     run_batch(m, v, big[1], big[0])
                 streams[wi].synchronize()
+                ready_evt.wait()
                 start_evt.wait()
                 while True:
                     with lock:
@@ -275,10 +257,11 @@ def main():
                 streams[wi].synchronize()
         except Exception as e:  # noqa: BLE001
             errors.append(e)
-            try:
-                start_evt.abort()
-            except Exception:  # noqa: BLE001
-                pass
+            for ev in (ready_evt, start_evt):
+                try:
+                    ev.abort()
+                except Exception:  # noqa: BLE001
+                    pass
 
     for wb in work[:Wsteps]:                 # W untimed warm-up steps (on top of the per-context warm-up inside worker())
         if Bsz == 1:
@@ -289,11 +272,14 @@ def main():
     threads = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
     for t in threads:
         t.start()
+    ready_evt.wait()                         # all per-context warm-ups are done and synchronised
+    torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
-    if dom is not None:
+    if dom is not None:                      # counters cover exactly the timed region
+        lib.ss_prof_reset()
         lib.ss_prof_enable((1 << dom) | ((1 << dom_conv) if dom_conv is not None else 0))
+    sk_err0 = int(lib.ss_debug_sk_errors())
     start_evt.wait()
     t0 = time.perf_counter()
     for t in threads:
@@ -321,7 +307,7 @@ def main():
         name = lib.ss_prof_class_name(c).decode()
         traffic = None
         try:   # PMC pass is a separate rocprofv3 run (tools/pmc_traffic.py -> profiles/); per-launch MB with the guide's gfx950 correction
-            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+            pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE))) if PMC_FILE else {}
             kv = pm.get("classes", {}).get(name)
             if kv:
                 traffic = {"mbytes_per_launch": kv["hbm_mbytes_per_launch_corrected"], "source": f"profiles/{PMC_FILE}: " + pm.get("note", "")}
@@ -339,31 +325,50 @@ def main():
         return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), **common}
 
-    roofline = roofline_of(dom) if dom is not None else None
-    roofline_conv = roofline_of(dom_conv) if dom_conv is not None and dom_conv != dom else None
+    in_region = roofline_of(dom) if dom is not None else None
+    in_region_conv = roofline_of(dom_conv) if dom_conv is not None and dom_conv != dom else None
+    sk_err_timed = int(lib.ss_debug_sk_errors()) - sk_err0
+    if sk_err_timed:
+        raise RuntimeError(f"{sk_err_timed} stream-K bounded waits timed out inside the timed region")
 
-    # The timed region runs S streams at once, so a launch bracketed above shares the chip with the
-    # other streams' kernels.  Same kernel, same batches, ONE stream (untimed for `value`): the rate a
-    # launch gets when it owns the GPU.
-    roofline_iso = None
-    if dom is not None and Bsz > 1 and work:
+    # Roofline of the dominant kernel.  With S > 1 the timed region keeps S streams in flight, so a launch bracketed by
+    # events there shares the chip with the other streams' kernels (and queues behind them): that bracket measures
+    # scheduling, not the kernel.  The per-launch figure is therefore taken on the SAME batches replayed on ONE stream
+    # (HIP events on the launch stream, every launch of the class; untimed for `value`) -- with --streams 1 the replay is
+    # skipped and the timed region itself is the measurement.  `in_region` keeps what the S-stream region gave:
+    # the event-bracket sums and the class's algorithmic FLOPs over the region's wall time.
+    def region_stats(r):
+        if not r:
+            return None
+        tot = r["algo_gflop_per_launch"] * r["launches"]
+        return {"launches": r["launches"], "avg_event_bracket_us": r["avg_launch_us"],
+                "algo_tflop_total": round(tot / 1e3, 3), "algo_tflops_over_wall": round(tot / 1e3 / wall, 3),
+                "event_bracket_time_over_wall": r["kernel_time_over_wall"], "concurrent_streams": S}
+
+    roofline, roofline_conv = in_region, in_region_conv
+    if dom is not None and S > 1 and work:
         lib.ss_prof_reset()
-        lib.ss_prof_enable(1 << dom)
-        for us, pk in work[:: max(1, len(work) // 3)][:3]:
-            run_batch(model, voc, pk, us)
+        lib.ss_prof_enable((1 << dom) | ((1 << dom_conv) if dom_conv is not None else 0))
+        t_rep = time.perf_counter()
+        for wk in work:
+            if Bsz == 1:
+                run_utterance(model, voc, wk[1], wk[0])
+            else:
+                run_batch(model, voc, wk[1], wk[0])
         torch.cuda.synchronize()
+        rep_wall = time.perf_counter() - t_rep
         lib.ss_prof_enable(0)
-        wall_keep, wall = wall, float("nan")
-        roofline_iso = roofline_of(dom)
+        wall_keep, wall = wall, rep_wall
+        roofline = roofline_of(dom)
+        roofline_conv = roofline_of(dom_conv) if dom_conv is not None and dom_conv != dom else None
         wall = wall_keep
-        if roofline_iso:
-            roofline_iso.pop("kernel_time_over_wall", None)
-            roofline_iso["note"] = "single stream, 3 of the timed batches, untimed for `value`"
-            if roofline:   # the same kernel without the other streams' kernels sharing the chip (see roofline_isolated)
-                roofline["achieved_isolated"] = roofline_iso["achieved"]
-                roofline["frac_isolated"] = roofline_iso["frac"]
-                roofline["note"] = (f"timed region = {S} concurrent streams: a launch's event-bracketed time includes sharing the chip "
-                                    "with the other streams' kernels; *_isolated = same kernel, same batches, one stream")
+        for r, reg in ((roofline, in_region), (roofline_conv, in_region_conv)):
+            if r:
+                r["measured_on"] = (f"the {len(work)} timed batches replayed on one stream right after the timed region "
+                                    f"(replay wall {rep_wall * 1e3:.1f} ms); HIP events on the launch stream around every launch")
+                r["in_region"] = region_stats(reg)
+    elif roofline:
+        roofline["measured_on"] = "the timed region itself (one stream); HIP events on the launch stream around every launch"
 
     # Strict configs[1] form: ONE utterance per call (the single-utterance entry points, no ragged packs),
     # 8 utterances in flight on 8 streams (untimed for `value`).
@@ -416,18 +421,20 @@ def main():
                                    "fbank+encoder+CTC+AR-MT+T2U+NAR-unit+vocoder HIP path, random-init weights "
                                    "of the streamspeech.offline.fr-en architecture",
                        "audio_seconds_per_gpu": round(sum(mine[i].seconds for i in timed_ids), 2), "utterances_per_gpu": K,
+                       "lengths_pinned": "data-dependent lengths are pinned by the workload (SURVEY.md §8d): MT search forced to "
+                                         "N = ceil(3.5 d) subwords + </s> (checked per batch inside the timed step), collapsed unit "
+                                         "sequence cyclically resized to K = ceil(37 d), durations forced to the (1,1,2) cycle",
                        "length_bucketed_batches": (not args.no_length_bucketing) and Bsz > 1, "utterances_per_ragged_batch": Bsz, "concurrent_streams_per_gpu": S,
                        "parallelism": f"utterance-dp{world}"},
             "latency_ms_single_stream": round(single_ms, 3), "rtfx_single_stream": round(single_rtfx, 2),
             "batch1_8streams": None if b1_rtfx is None else {"rtfx": round(b1_rtfx, 1), "utterances_per_sec": round(b1_ups, 1),
                                                              "note": "one utterance per call (no ragged packs), 8 concurrent streams, 64 utterances"},
-            "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),   # must be 0 (bounded waits of the stream-K fix-up)
+            "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),   # must be 0 (bounded waits of the stream-K fix-up); also asserted for the timed region
             "roofline": roofline,
-            "roofline_isolated": roofline_iso,
             "roofline_second_kernel": roofline_conv,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, all_utts[Wn:Wn + Kpool + 1])
+            out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, workload.make_utterances(Wn + Kpool + 1)[Wn:])
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)

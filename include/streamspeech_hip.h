@@ -90,6 +90,11 @@ int ss_encoder_forward(ss_model* m, void* stream, const float* d_fbank, int T, i
  * the handle: one utterance at a time, ss_encoder_stream_reset between utterances (the agent's
  * reset()); a change of chunk sizes or a shorter input resets it implicitly. */
 int ss_encoder_stream_reset(ss_model* m);
+/* Trailing fbank frames whose values may still change when more audio arrives (default 0).  The agent's
+ * front-end resamples the WHOLE sample history at every call (agent :86-89, convert_waveform); a zero-padded
+ * FIR recomputes its last few output samples once the future exists, so with a non-16 kHz source the newest
+ * fbank frame is not settled and rows whose cone reaches it must not be cached as final: set 1. */
+int ss_encoder_stream_set_tail(ss_model* m, int unsettled_fbank_frames);
 int ss_encoder_stream_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
                               int conv_chunk, float* d_enc_out, int32_t* n_final, int32_t* n_computed);
 

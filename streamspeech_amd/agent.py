@@ -200,6 +200,11 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
             layer.conv_module.depthwise_conv.chunk_size = conv_chunk
         if hasattr(model.encoder, "incremental"):
             model.encoder.incremental = not getattr(args, "full_recompute_encoder", False)
+            # a resampled source re-computes its last ~10 output samples when more audio arrives (zero-padded
+            # FIR edge), so the newest fbank frame is not settled: the incremental encoder must not cache rows
+            # that can see it
+            if hasattr(eng, "encoder_stream_set_tail"):
+                eng.encoder_stream_set_tail(1 if int(args.sample_rate) != SAMPLE_RATE else 0)
 
         # dictionaries: target units + the three multitask text dictionaries
         self.dict = {"tgt": Dictionary.units(1000)}

@@ -145,6 +145,7 @@ struct ss_model {
   DevBuf es_glu;        // [layers][es_cap][d]
   DevBuf es_out;        // [es_cap][d]
   int es_cap = 0, es_final = 0, es_achunk = -1, es_cchunk = -1;
+  int es_tail = 0;                                  // trailing fbank frames that may still change (resampler edge)
 };
 
 static int load_dec_layers(ss_model* m, std::vector<DecLayer>& v, const std::string& pfx, int n, int D, int F,
@@ -379,7 +380,7 @@ extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fban
 // chunk and conv taps up to min(i+15, end of its conv chunk); through the subsampler it reaches
 // conv1 rows a(i) = min(2i+2, chunk end) and fbank rows b(a(i)).  The final prefix [0, n) is the
 // largest one that is closed under "reaches" and whose subsampler inputs all exist.
-static int stream_final_rows(int T, int T1, int T2, int k, int achunk, int cchunk, int dwk) {
+static int stream_final_rows(int T, int T1, int T2, int k, int achunk, int cchunk, int dwk, int tail) {
   if (achunk <= 0) return 0;                       // full attention: every frame sees the future
   auto reach = [&](int i, int half, int stride) {  // last input row a stride-`stride` conv output i can read
     int r = i * stride + half;
@@ -390,7 +391,7 @@ static int stream_final_rows(int T, int T1, int T2, int k, int achunk, int cchun
   for (int i = 0; i < T2; ++i) {                   // subsampler level: frames whose whole cone exists
     const int a = reach(i, k / 2, 2);
     if (a > T1 - 1) break;
-    if (reach(a, k / 2, 2) > T - 1) break;
+    if (reach(a, k / 2, 2) > T - 1 - tail) break;   // the last `tail` fbank frames are not settled yet
     n = i + 1;
   }
   while (n > 0) {                                  // closure under one layer's reach (monotone in i)
@@ -406,6 +407,12 @@ static int stream_final_rows(int T, int T1, int T2, int k, int achunk, int cchun
 extern "C" int ss_encoder_stream_reset(ss_model* m) {
   if (!m) return SS_ERR_ARG;
   m->es_final = 0; m->es_achunk = -1; m->es_cchunk = -1;
+  return SS_OK;
+}
+
+extern "C" int ss_encoder_stream_set_tail(ss_model* m, int unsettled_fbank_frames) {
+  if (!m || unsettled_fbank_frames < 0) return SS_ERR_ARG;
+  m->es_tail = unsettled_fbank_frames;
   return SS_OK;
 }
 
@@ -497,7 +504,7 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
       RET(layernorm(s, x, x, e.final_ln, n, d));
     }
   }
-  const int nf = std::max(r0, stream_final_rows(T, T1, T2, k, achunk_cfg, cchunk, c.dw_kernel));
+  const int nf = std::max(r0, stream_final_rows(T, T1, T2, k, achunk_cfg, cchunk, c.dw_kernel, m->es_tail));
   if (nf > r0)
     SS_HIP_CHECK(hipMemcpyAsync(m->es_out.f() + (size_t)r0 * d, d_enc_out + (size_t)r0 * d, (size_t)(nf - r0) * d * sizeof(float),
                                 hipMemcpyDeviceToDevice, s));

@@ -64,8 +64,8 @@ class BatchMixin:
                                                   _ptr(out), hTp), "ss_batch_encoder_forward")
         return out, list(hTp)
 
-    def batch_ctc_greedy(self, head: int, enc_packed: torch.Tensor, Tp: List[int]):
-        """-> per-utterance (tokens, frame index) lists."""
+    def batch_ctc_greedy(self, head: int, enc_packed: torch.Tensor, Tp: List[int], return_raw: bool = False):
+        """-> per-utterance (tokens, frame index) lists (+ the raw per-frame argmax with return_raw)."""
         B, tot = len(Tp), sum(Tp)
         ibuf = torch.empty((3 * tot + B,), dtype=torch.int32, device=self.device)
         raw, toks, idx, cnt = ibuf[:tot], ibuf[tot:2 * tot], ibuf[2 * tot:3 * tot], ibuf[3 * tot:]
@@ -75,7 +75,8 @@ class BatchMixin:
         out, off = [], 0
         for b in range(B):
             n = int(host[3 * tot + b])
-            out.append((host[tot + off: tot + off + n].tolist(), host[2 * tot + off: 2 * tot + off + n].tolist()))
+            rec = (host[tot + off: tot + off + n].tolist(), host[2 * tot + off: 2 * tot + off + n].tolist())
+            out.append(rec + (host[off: off + Tp[b]].tolist(),) if return_raw else rec)
             off += Tp[b]
         return out
 
@@ -92,8 +93,10 @@ class BatchMixin:
         toks = [list(out[b * stride: b * stride + n_out[b]]) for b in range(B)]
         return toks, feats, list(n_out)
 
-    def batch_t2u_units(self, feats: torch.Tensor, n_rows: List[int], t2u_causal=False, mask_eos=False):
-        """feats [B, rows, D] (rows of utterance b used: n_rows[b]) -> list of collapsed unit-vocab token lists."""
+    def batch_t2u_units(self, feats: torch.Tensor, n_rows: List[int], t2u_causal=False, mask_eos=False,
+                        return_raw: bool = False):
+        """feats [B, rows, D] (rows of utterance b used: n_rows[b]) -> list of collapsed unit-vocab token lists
+        (with return_raw: (collapsed lists, raw per-position argmax lists))."""
         B, rows = feats.shape[0], feats.shape[1]
         up = self.cfg.ctc_upsample
         U = sum(n_rows) * up
@@ -102,12 +105,13 @@ class BatchMixin:
         L.check(self.lib.ss_batch_t2u_units(self.h, _stream(), B, _ptr(feats), rows, _i32(n_rows), int(t2u_causal),
                                             int(mask_eos), _ptr(raw), _ptr(toks), _ptr(cnt)), "ss_batch_t2u_units")
         host = ibuf.cpu().numpy()
-        out, off = [], 0
+        out, raws, off = [], [], 0
         for b in range(B):
             k = int(host[2 * U + b])
             out.append(host[U + off: U + off + k].tolist())
+            raws.append(host[off: off + n_rows[b] * up].tolist())
             off += n_rows[b] * up
-        return out
+        return (out, raws) if return_raw else out
 
 
 class HipModel(BatchMixin):
@@ -202,6 +206,10 @@ class HipModel(BatchMixin):
         """Forget the incremental-encoder cache (new utterance)."""
         L.check(self.lib.ss_encoder_stream_reset(self.h), "ss_encoder_stream_reset")
         self.stream_stats = (0, 0)
+
+    def encoder_stream_set_tail(self, unsettled_fbank_frames: int):
+        """Newest fbank frames that may still change on the next call (1 when the front-end resamples, else 0)."""
+        L.check(self.lib.ss_encoder_stream_set_tail(self.h, int(unsettled_fbank_frames)), "ss_encoder_stream_set_tail")
 
     def encoder_stream_forward(self, fbank: torch.Tensor, attn_chunk: int, conv_chunk: int) -> torch.Tensor:
         """Incremental twin of :meth:`encoder_forward` for streaming: same input (fbank

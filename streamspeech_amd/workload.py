@@ -52,3 +52,52 @@ def resize_units(units: List[int], K: int, seed_idx: int = 0) -> List[int]:
 def shard(items, rank: int, world: int):
     """Utterance-level data parallel: round-robin deal."""
     return items[rank::world]
+
+
+def run_batch(model, voc, pcm_packed, utts, detail: bool = False):
+    """The benchmarked hot path for one ragged batch of utterances (bench.py's timed step and the parity
+    test at the benchmarked configuration call THIS function): PCM in HBM -> fbank+CMVN -> chunk-Conformer
+    -> CTC x2 -> lock-step AR MT greedy (n_mt tokens, forced eos) -> T2U + NAR unit decoder + CTC collapse
+    -> unit sequence resized to K -> unit HiFi-GAN with the workload's durations.  Each utterance keeps its
+    B = 1 arithmetic (streamspeech_amd/csrc/model.hip ss_batch_*).  With detail=True every intermediate the
+    parity test compares is returned as well (raw argmax ids, features); the launches are the same."""
+    from .pipeline import units_from_tokens
+    cfg = model.cfg
+    feat, T = model.batch_fbank_cmvn(pcm_packed, [u.n_samples for u in utts])
+    enc, Tp = model.batch_encoder_forward(feat, T)
+    asr = model.batch_ctc_greedy(0, enc, Tp, return_raw=detail)
+    st = model.batch_ctc_greedy(1, enc, Tp, return_raw=detail)
+    toks, feats, n = model.batch_mt_greedy(enc, Tp, [u.n_mt for u in utts])
+    # the workload pins the data-dependent lengths: every search must have run to its forced </s>
+    for b, u in enumerate(utts):
+        if len(toks[b]) != u.n_mt + 1 or toks[b][-1] != cfg.eos:
+            raise RuntimeError(f"utterance {u.idx}: MT search returned {len(toks[b])} tokens, expected {u.n_mt} + </s>")
+    unit_out = model.batch_t2u_units(feats, n, return_raw=detail)
+    unit_toks, unit_raw = unit_out if detail else (unit_out, None)
+    codes = [resize_units(units_from_tokens(t, cfg), u.n_units, u.idx) for t, u in zip(unit_toks, utts)]
+    wavs, dur, _ = voc.batch_forward(codes, dur_prediction=True, forced_dur=[u.durations for u in utts])
+    if not detail:
+        return wavs, asr, st, toks
+    return {"wavs": wavs, "asr": asr, "st": st, "mt": toks, "fbank": feat, "T": T, "Tp": Tp, "unit_toks": unit_toks,
+            "unit_raw": unit_raw, "codes": codes, "dur": dur, "n_feats": n}
+
+
+def bench_plan(steps: int, batch: int, rank: int = 0, world: int = 1, bucket: bool = True, warm: int = 3,
+               pool_cap: int = 2048):
+    """The utterance set and ragged-batch grouping of `bench.py --steps steps --batch batch` on one rank.
+    -> (mine, groups): `mine` = this rank's utterances (the `warm` single-utterance warm-ups first), `groups`
+    = the timed steps as lists of indices into `mine`, in dispatch order.  Weak scaling: every rank gets the same
+    number of utterances; the pool is length-sorted before the round-robin deal so audio seconds
+    balance too.  Like fairseq-generate (dataset.ordered_indices() sorts by source length before batch_by_size)
+    batches are formed from length-sorted utterances, longest first (LPT over the concurrent streams)."""
+    K = steps * batch
+    pool = min(K, pool_cap)
+    all_utts = make_utterances((pool + warm) * world)
+    warm_all, timed_all = all_utts[:warm * world], all_utts[warm * world:]
+    timed_all = sorted(timed_all, key=lambda u: -u.seconds)
+    mine = shard(warm_all, rank, world) + shard(timed_all, rank, world)
+    ids = [warm + (i % pool) for i in range(K)]
+    if batch > 1 and bucket:
+        ids = sorted(ids, key=lambda i: -mine[i].n_samples)
+    groups = [ids[g0:g0 + batch] for g0 in range(0, len(ids), batch)]
+    return mine, groups

@@ -1,0 +1,125 @@
+"""Parity at the configuration that is benchmarked.
+
+bench.py's timed step is streamspeech_amd/workload.py::run_batch on the ragged batches of
+workload.bench_plan (32 CVSS-C-shaped utterances per batch, length-bucketed, natural kernel dispatch -- no
+forced tiles), 8 batches in flight on 8 HIP streams / contexts.  Here exactly that runs, and every utterance
+of the longest (up to 15 s), the shortest (1 s) and a middle batch is checked against the CPU oracle:
+identical ASR / ST ids and frame indices, identical MT ids, identical raw unit argmax at every one of the
+U = 25 (N+1) positions and identical collapsed units, durations as forced, waveform RMS <= 1e-3
+(reference: fairseq/models/text_to_speech/hifigan.py:154-170, ctc_transformer_unit_decoder.py:153-260).
+The oracle is fed the HIP fbank (north star: 'on the same fbank input'); the fbank itself is checked
+against the oracle's Kaldi restatement at 1e-3."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+WAV_RMS_TOL = 1e-3
+
+
+def _oracle_utterance(O, osd, ovsd, cfg, vcfg, fb, u, workload):
+    enc = O.encoder_forward(osd, fb, cfg)
+    asr = O.ctc_head(osd, enc, "source_unigram", cfg)
+    st = O.ctc_head(osd, enc, "ctc_target_unigram", cfg)
+    toks = O.mt_greedy(osd, enc, cfg, max_new_tokens=u.n_mt)
+    body = toks[:-1] if toks and toks[-1] == cfg.eos else toks
+    feats = O.mt_decoder_features(osd, [cfg.eos] + body, enc, cfg)
+    logits = O.unit_decoder_logits(osd, O.t2u_encoder(osd, feats, cfg), cfg)
+    unit_toks, raw = O.unit_ctc_generate(logits, cfg)       # unit ids (0..999) and raw argmax over the unit vocabulary
+    codes = workload.resize_units(unit_toks, u.n_units, u.idx)
+    wav, dur = O.vocoder_forward(ovsd, codes, vcfg, True, forced_dur=u.durations)
+    return {"asr": asr, "st": st, "mt": toks, "raw": raw, "codes": codes, "wav": wav, "dur": dur}
+
+
+def test_timed_step_matches_oracle_on_8_streams(hip_model, hip_vocoder, synth_weights):
+    from oracle import kaldi_fbank as K
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import synth, workload
+    cfg, vcfg, sd, vsd = synth_weights
+    osd, ovsd = O.SD(sd), O.SD(vsd)
+    dev = hip_model.device
+    mine, groups = workload.bench_plan(32, 32)            # the default bench: 32 steps x 32 utterances
+    assert len(groups) == 32 and all(len(g) == 32 for g in groups)
+    secs = [[mine[i].seconds for i in g] for g in groups]
+    assert max(secs[0]) == 15.0 and min(secs[-1]) == 1.0   # the clipped ends of the length distribution are in
+    checked = [0, len(groups) // 2, len(groups) - 1]
+    others = [3, 7, 12, 20, 27]                            # in flight at the same time (not oracle-checked)
+    sel = checked + others
+    S = len(sel)
+    assert S == 8
+    # model.hip's CMVN for this test = identity, as in bench.py (HipModel(sd, cfg) without statistics)
+    from streamspeech_amd.engine import HipModel
+    model0 = HipModel(sd, cfg, device=str(dev))
+    ctxs = [(model0, hip_vocoder)] + [(model0.new_context(), hip_vocoder.new_context()) for _ in range(S - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    packs = [torch.cat([torch.from_numpy(synth.synth_pcm(1234 + mine[i].idx, mine[i].n_samples)) for i in groups[g]]).to(dev)
+             for g in sel]
+    torch.cuda.synchronize()
+    results, errors = [None] * S, []
+    bar = threading.Barrier(S)
+
+    def worker(wi):
+        try:
+            m, v = ctxs[wi]
+            utts = [mine[i] for i in groups[sel[wi]]]
+            with torch.cuda.stream(streams[wi]):
+                bar.wait()
+                results[wi] = workload.run_batch(m, v, packs[wi], utts, detail=True)
+                streams[wi].synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            try:
+                bar.abort()
+            except Exception:  # noqa: BLE001
+                pass
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    torch.cuda.synchronize()
+    if errors:
+        raise errors[0]
+    assert int(hip_model.lib.ss_debug_sk_errors()) == 0, "stream-K bounded wait timed out"
+
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    worst = {"fbank": 0.0, "rms": 0.0}
+    n_units_total = n_pos_total = 0
+    with torch.inference_mode():
+        for wi in range(len(checked)):
+            utts = [mine[i] for i in groups[sel[wi]]]
+            r = results[wi]
+            fb_all = r["fbank"].cpu()
+            off_f = off_s = 0
+            for b, u in enumerate(utts):
+                fb = fb_all[off_f:off_f + r["T"][b]].numpy()
+                off_f += r["T"][b]
+                pcm = synth.synth_pcm(1234 + u.idx, u.n_samples)
+                off_s += u.n_samples
+                ref_fb = K.fbank(pcm * np.float32(32768.0))
+                assert ref_fb.shape == fb.shape
+                worst["fbank"] = max(worst["fbank"], float(np.abs(ref_fb - fb).max()))
+                ref = _oracle_utterance(O, osd, ovsd, cfg, vcfg, fb, u, workload)
+                tag = f"batch {sel[wi]} utt {u.idx} ({u.seconds:.2f} s)"
+                assert r["asr"][b][0] == ref["asr"][0] and r["asr"][b][1] == ref["asr"][1], tag + ": ASR ids / frame index"
+                assert r["asr"][b][2] == ref["asr"][2], tag + ": ASR raw argmax"
+                assert r["st"][b][0] == ref["st"][0] and r["st"][b][1] == ref["st"][1], tag + ": ST ids / frame index"
+                assert r["mt"][b] == ref["mt"], tag + ": MT ids"
+                assert r["unit_raw"][b] == ref["raw"], tag + ": raw unit argmax"
+                assert r["codes"][b] == ref["codes"], tag + ": units fed to the vocoder"
+                n_pos_total += len(ref["raw"])
+                n_units_total += len(ref["codes"])
+                wav = r["wavs"][b].cpu()
+                assert wav.numel() == ref["wav"].numel() == 320 * sum(u.durations), tag
+                rms = float(torch.sqrt(torch.mean((wav - ref["wav"]) ** 2)))
+                worst["rms"] = max(worst["rms"], rms)
+                assert rms < WAV_RMS_TOL, f"{tag}: waveform rms {rms}"
+            durs = r["dur"].cpu().tolist()
+            assert durs == [d for u in utts for d in u.durations]
+    assert worst["fbank"] < 1e-3, worst
+    print(f"bench-config parity: 96 utterances, {n_pos_total} unit positions, {n_units_total} vocoder units, "
+          f"worst fbank err {worst['fbank']:.2e}, worst wav rms {worst['rms']:.2e}")
