@@ -1,0 +1,619 @@
+// Persistent stream-K implicit-GEMM Conv1d, second generation (gfx950, exact-f32 MFMA): the wide
+// (N % 128 == 0) path of launch_conv_gemm -- HiFi-GAN resblock / up-sampling convs of a packed batch at
+// C >= 128, conv_pre, the unit-decoder projections (reference fairseq/models/text_to_speech/hifigan.py:52-172,
+// SURVEY.md §8a rows a12, a15).
+//
+// What changed against conv_sk.hip (which stays for N % 128 == 64), and why (profiles/r01_sk_ablation.txt:
+// of a 281-us launch the MFMA + ds_read stream alone took 211 us, LDS-DMA issue + barrier 38 us, fix-up +
+// epilogue 32 us -- additive, because the two co-resident workgroups of a CU ran in phase):
+//   * ONE workgroup per CU, 4 waves, one per SIMD, on a 256 x 128 tile (wave tile 128 x 64 = 32 accumulator
+//     tiles): 256 MFMAs per wave between barriers instead of 128, 25 % fewer LDS-DMA pieces and ds_reads per
+//     MFMA, and nothing on a SIMD competes with its wave for issue slots.
+//   * 3-stage LDS ring (3 x 48 KB), k-step k+2 is issued while k is contracted: the DMA has two full steps
+//     (~16k cycles) to land, waits are counted (vmcnt(12) leaves the newest step in flight across the barrier),
+//     the barrier is a raw s_barrier.
+//   * the k-loop is software-pipelined inside the wave: fragments of the next half-step are read while the
+//     current half's MFMAs issue, and the one barrier per k-step sits in the MIDDLE of the second half -- the
+//     remaining 64 MFMAs cover the barrier, the DMA wait and the first ds_reads of the next stage.  The
+//     12 DMA pieces of a step are spread over the first half's MFMA groups.
+//   * stream-K hand-off without waiting: every shared tile has exactly two contributors (grid <= tiles).
+//     Whoever finishes its part first parks it (sc1 write-through stores) and raises `ready`; the second one
+//     adds it and runs the epilogue (a + b is commutative, so the result does not depend on who was first).
+//     A workgroup never waits for one that has not arrived yet, so there are no tickets and no dependence on
+//     dispatch order.  Odd workgroups walk their range forwards, even ones backwards: the tile shared by an
+//     even workgroup and its right neighbour is worked on by both FIRST, so half of the fix-ups and epilogues
+//     happen in the middle of the launch instead of all at its end.
+#include "gemm.hpp"
+
+#include <map>
+#include <mutex>
+
+namespace ss {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int K2_BM = 256, K2_BN = 128, K2_BK = 32;
+constexpr int K2_STAGE = (K2_BM + K2_BN) * K2_BK;       // floats per ring stage (48 KB)
+constexpr int K2_SC1 = 16;                              // buffer cache policy bit: agent scope
+constexpr int K2_MAXG = 512;
+constexpr int K2_WORD0 = 16;                            // sync[K2_WORD0 + 2 b] = arrival word of boundary b, + 1 = ready word
+[[maybe_unused]] constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
+[[maybe_unused]] constexpr int K2_NUM_RECORDS = 0x7ffffff0;
+[[maybe_unused]] constexpr unsigned K2_OOB = 0x80000000u;
+
+struct Sk2Args {
+  float* ws;            // [G][256*128] parked partial tiles; slot b = the tile shared by workgroups b and b + 1
+  unsigned* sync;       // [8] time-out counter, [K2_WORD0 + 2 b] arrival word, [K2_WORD0 + 2 b + 1] ready word
+  unsigned epoch;       // value that marks "of this launch" in both words
+  int G;                // workgroups (<= tiles: every shared tile has exactly two contributors)
+};
+
+#define K2_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// Timing-only ablation builds (tools/sk2_bench.py with SS_EXTRA_FLAGS=-DK2_ABL=<mask>; results are wrong by design):
+// 1 no LDS-DMA in the k-loop, 2 no wait + barrier in the k-loop, 4 no ds_reads in the k-loop, 8 no epilogue / hand-off,
+// 16 no MFMAs, 32 no hand-off (every part runs the epilogue), 64 no C / C2 stores, 128 no R / R2 loads, 256 no next-part
+// prefetch before the epilogue.  Never set in the product build.
+#ifndef K2_ABL
+#define K2_ABL 0
+#endif
+
+// SiLU / tanh epilogues are rare on this path (no vocoder conv uses them): out of line, so that their expf / tanhf /
+// division expansions are not inlined once per accumulator element -- 128 copies made a 115-KB kernel whose epilogue
+// thrashed the instruction cache and cost 25+ us per tile part (profiles/r02_sk2_ablation.txt).
+__device__ __attribute__((noinline)) float k2_act_slow(float v, int act) {
+  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  if (act == ACT_TANH) return tanhf(v);
+  return v;
+}
+
+template <bool LRELU>
+__global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, const Sk2Args q) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int BM = K2_BM, BN = K2_BN, BK = K2_BK, STAGE = K2_STAGE;
+  constexpr int TM = 8, TN = 4;                  // 16x16 MFMA tiles per wave (wave tile 128 x 64)
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* s_lo = reinterpret_cast<int*>(smem + 3 * STAGE);
+  int* s_hi = s_lo + BM;
+  int* s_misc = s_hi + BM;
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 15, g = lane >> 4;
+  const int w = blockIdx.x;
+
+  const int kpt = p.Cin / BK;
+  const int nk = p.taps * kpt;
+  const int Ktot = p.taps * p.Cin;
+  const int tiles_n = p.N / BN;
+  const int tiles_m = (p.M + BM - 1) / BM;
+  const long long U = (long long)tiles_m * tiles_n * nk;
+  const long long u0 = (long long)w * U / q.G, u1 = (long long)(w + 1) * U / q.G;
+  if (u1 <= u0) return;
+  const int t_first = (int)(u0 / nk), t_last = (int)((u1 - 1) / nk);
+  const bool fwd = (w & 1) != 0;
+
+  const float slope = p.in_slope;
+  // Buffer resources of the LDS-DMA loads: per-lane byte offsets stay constant over a tile part, the k-step
+  // (tap shift, channel block) goes into the wave-uniform soffset; rows outside their utterance get an offset
+  // beyond num_records and the range check returns zeros (the conv's zero padding).  The A base is moved back by
+  // `pad` rows so that every valid offset is non-negative.
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(reinterpret_cast<uintptr_t>(p.A) - (uintptr_t)p.pad * p.lda * sizeof(float)), 0, K2_NUM_RECORDS, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, K2_NUM_RECORDS, 0x00020000);
+
+  // per-lane LDS read offsets (floats) inside a stage: 16-B chunk c of row rr sits at chunk position c ^ ((rr >> 1) & 7)
+  // (the swizzle is applied to the DMA's SOURCE address; rows of a 16-row MFMA tile differ only in r)
+  const int swz = (r >> 1) & 7;
+  const int rdA0 = (wm * 128 + r) * BK + ((g ^ swz) << 2);
+  const int rdA1 = (wm * 128 + r) * BK + (((4 + g) ^ swz) << 2);
+  const int rdW0 = BM * BK + (wn * 64 + r) * BK + ((g ^ swz) << 2);
+  const int rdW1 = BM * BK + (wn * 64 + r) * BK + (((4 + g) ^ swz) << 2);
+  const int st_row = lane >> 3, st_pos = lane & 7;       // DMA piece = 8 rows x 8 chunks
+
+  // ---- state of the part whose k-steps are being staged (registers; the k-step scalars are wave-uniform) ----
+  struct Part { int ka, kb, n, m0, n0, tm; };
+  const int nparts = t_last - t_first + 1;
+  auto part_of = [&](int ip) {
+    const int tile = fwd ? t_first + ip : t_last - ip;
+    const long long ut0 = (long long)tile * nk;
+    Part P;
+    P.ka = (int)(max(u0, ut0) - ut0);
+    P.kb = (int)(min(u1, ut0 + nk) - ut0);
+    P.n = P.kb - P.ka;
+    P.tm = tile / tiles_n;
+    P.m0 = P.tm * BM;
+    P.n0 = (tile - P.tm * tiles_n) * BN;
+    return P;
+  };
+  int a_rin0[8], a_lo[8], a_hi[8];
+  unsigned a_off[8], w_off[4];
+  int nci = 0, ntap = 0;                 // of the next step to stage
+  int soffA = 0, soffW = 0, shift = 0;
+  int cur_tm = -1;
+  // Row bounds + per-lane offsets of a part.  Called when every wave is past the previous part's k-loop (two barriers
+  // inside when the row tile changes).
+  auto stage_setup = [&](const Part& P) {
+    __syncthreads();                     // row-bound readers of the previous part / s_misc users are done
+    if (P.tm != cur_tm) {
+      cur_tm = P.tm;
+      const int m = P.m0 + t;            // 256 threads, 256 rows
+      int lo = 0, hi = 0;
+      if (m < p.M) {
+        if (p.nseg > 0) {
+          for (int s = 0; s < p.nseg; ++s) {
+            const int sst = p.segs[4 * s], ln = p.segs[4 * s + 1];
+            if (m >= sst && m < sst + ln) { lo = sst; hi = sst + ln; }
+          }
+        } else {
+          hi = p.in_len;
+        }
+      }
+      s_lo[t] = lo; s_hi[t] = hi;
+      __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int row = wave * 64 + j * 8 + st_row;
+      a_rin0[j] = P.m0 + row - p.pad;
+      a_lo[j] = s_lo[row]; a_hi[j] = s_hi[row];
+      a_off[j] = (unsigned)(((P.m0 + row) * p.lda + ((st_pos ^ ((row >> 1) & 7)) << 2)) * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nrow = wave * 32 + j * 8 + st_row;
+      w_off[j] = (unsigned)(((P.n0 + nrow) * Ktot + ((st_pos ^ ((nrow >> 1) & 7)) << 2)) * 4);
+    }
+    // k-step s = (channel block s / taps, tap s % taps): the taps of one 32-channel block run back to back, so the
+    // (256 + halo) x 128-B slab of A rows they share is re-read from L1/L2 while it is still there
+    nci = (P.ka / p.taps) * BK;
+    ntap = P.ka - (P.ka / p.taps) * p.taps;
+  };
+  auto step_begin = [&]() {              // scalars of the step about to be staged.  readfirstlane: they MUST be SGPRs --
+    const int tapv = __builtin_amdgcn_readfirstlane(ntap);   // a soffset the compiler keeps in a VGPR turns every DMA piece
+    const int nciv = __builtin_amdgcn_readfirstlane(nci);    // into a waterfall loop (cdna_hip_programming.md T20)
+    shift = tapv * p.dil;
+    soffA = (shift * p.lda + nciv) * 4;
+    soffW = (tapv * p.Cin + nciv) * 4;
+  };
+  auto step_advance = [&](bool adv = true) {   // branch-free: the k-loop body must stay ONE basic block (the scheduler
+    const int nt = ntap + (adv ? 1 : 0);       // interleaves DMA pieces, ds_reads and MFMAs only inside a block)
+    const bool wrap = nt >= p.taps;
+    ntap = wrap ? 0 : nt;
+    nci += wrap ? BK : 0;
+  };
+  // `live` = false turns a piece into a zero fill (offset beyond the buffer range: no memory traffic): the last two
+  // steps of a part keep issuing into ring slots nobody reads any more, so the k-loop body has no branches and
+  // the wait count is the same every iteration.
+  bool in_loop = false;
+  auto issueA = [&](int stage, int j, bool live) {
+    if ((K2_ABL & 1) && in_loop) return;
+    float* sA = smem + stage * STAGE + (wave * 64) * BK;
+    const int rin = a_rin0[j] + shift;
+    const bool ok = live && rin >= a_lo[j] && rin < a_hi[j];
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + j * 8 * BK), 16, ok ? a_off[j] : K2_OOB,
+                                             __builtin_amdgcn_readfirstlane(soffA), 0, 0);
+  };
+  auto issueW = [&](int stage, int j, bool live) {
+    if ((K2_ABL & 1) && in_loop) return;
+    float* sW = smem + stage * STAGE + BM * BK + (wave * 32) * BK;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sW + j * 8 * BK), 16, live ? w_off[j] : K2_OOB,
+                                             __builtin_amdgcn_readfirstlane(soffW), 0, 0);
+  };
+  auto issue_step = [&](int stage, bool live) {
+    step_begin();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) issueA(stage, j, live);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) issueW(stage, j, live);
+    step_advance(live);
+  };
+  // first two k-steps of a part into ring slots `slot`, `slot + 1` (a one-step part gets a zero fill for the second)
+  auto prefetch2 = [&](const Part& P, int slot) {
+    issue_step(slot, true);
+    issue_step(slot == 2 ? 0 : slot + 1, P.n > 1);
+  };
+
+  int st = 0;                            // ring slot of the step being contracted (runs on across parts)
+  Part cur = part_of(0);
+  stage_setup(cur);
+  prefetch2(cur, st);
+  for (int ip = 0; ip < nparts; ++ip) {
+    const int n = cur.n, m0 = cur.m0, n0 = cur.n0;
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto loadA = [&](const float* S, int half, int i, f32x4 (&af)[TM]) {
+      if ((K2_ABL & 4) && in_loop) return;
+      af[i] = *reinterpret_cast<const f32x4*>(S + (half ? rdA1 : rdA0) + i * 16 * BK);
+      if (LRELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) af[i][e] = fmaxf(af[i][e], af[i][e] * slope);
+      }
+    };
+    auto loadB = [&](const float* S, int half, int j, f32x4 (&bf)[TN]) {
+      if ((K2_ABL & 4) && in_loop) return;
+      bf[j] = *reinterpret_cast<const f32x4*>(S + (half ? rdW1 : rdW0) + j * 16 * BK);
+    };
+    auto load_frags = [&](const float* S, int half, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) loadB(S, half, j, bf);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) loadA(S, half, i, af);
+    };
+    // 8 MFMAs: k4 slice e of row tiles 2q, 2q+1 against all 4 column tiles (8 independent accumulators; the same
+    // accumulator comes back 32 MFMAs later)
+    auto mma8 = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int e, int qd) {
+      if (K2_ABL & 16) return;
+#pragma unroll
+      for (int i = 2 * qd; i < 2 * qd + 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // D = W.A^T: see epilogue
+    };
+
+    // ---- the part's first two steps were staged ahead (before the previous part's epilogue): wait, barrier, first fragments ----
+    K2_WAIT_VMCNT(0);                    // both steps (and the previous epilogue's stores) are out of the counter
+    __builtin_amdgcn_s_barrier();
+    f32x4 ax[TM], bx[TN], ay[TM], by[TN];
+    load_frags(smem + st * STAGE, 0, ax, bx);
+    in_loop = true;
+    for (int i = 0; i < n; ++i) {
+      const float* S = smem + st * STAGE;
+      const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
+      const bool live = i + 2 < n;
+      // The body is ONE basic block (no branches): DMA pieces, ds_reads and MFMAs of a step can be interleaved by the
+      // scheduler.  K2_SCHED 0 leaves the order to hipcc; 1 asks for "8 MFMAs, 1 ds_read, 1 DMA piece" groups with a
+      // sched_group_barrier pipeline (source order = requested order: a ds_read may not cross an LDS-DMA piece);
+      // 2 pins the same order with sched_barrier(0) fences.  Measured (tools/sk2_bench.py, profiles/r02_sk2_*.txt):
+      // 0 is the fastest -- 1 and 2 make the register allocator slide the accumulators (~100 v_accvgpr moves per step).
+#ifndef K2_SCHED
+#define K2_SCHED 0
+#endif
+      const float* S1 = smem + st1 * STAGE;                  // (after the last step: a slot nobody reads from again)
+      step_begin();
+#if K2_SCHED == 2
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) {
+        mma8(ax, bx, sl >> 2, sl & 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (sl < 4) loadB(S, 1, sl, by);
+        else if (sl < 12) loadA(S, 1, sl - 4, ay);
+        if (sl >= 2 && sl < 10) issueA(st2, sl - 2, live);
+        else if (sl >= 10 && sl < 14) issueW(st2, sl - 10, live);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      step_advance(live);
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) mma8(ay, by, sl >> 2, sl & 3);
+      __builtin_amdgcn_sched_barrier(0);
+#if !(K2_ABL & 2)
+      K2_WAIT_VMCNT(12);
+      __builtin_amdgcn_s_barrier();
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) {
+        if (sl < 2) { loadB(S1, 0, 2 * sl, bx); loadB(S1, 0, 2 * sl + 1, bx); }
+        else if (sl < 6) { loadA(S1, 0, 2 * (sl - 2), ax); loadA(S1, 0, 2 * (sl - 2) + 1, ax); }
+        mma8(ay, by, 2 + (sl >> 2), sl & 3);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#else
+      // ---- contract X (128 MFMAs) and k4 slices 0-1 of Y (64); read Y; stage step i+2 ----
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        if (u < 4) loadB(S, 1, u, by); else loadA(S, 1, u - 4, ay);
+        if (u < 8) issueA(st2, u, live); else issueW(st2, u - 8, live);
+      }
+      step_advance(live);
+#pragma unroll
+      for (int sl = 0; sl < 16; ++sl) mma8(ax, bx, sl >> 2, sl & 3);
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) mma8(ay, by, sl >> 2, sl & 3);
+#if K2_SCHED == 1
+#pragma unroll
+      for (int u = 0; u < 12; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (a Y fragment)
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (an LDS-DMA piece)
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 96, 0);
+#endif
+      // ---- step i+1 landed for every wave, every wave is done with slot st-1 and with X ----
+#if !(K2_ABL & 2)
+      K2_WAIT_VMCNT(12);
+      __builtin_amdgcn_s_barrier();
+#endif
+      // ---- k4 slices 2-3 of Y; the first-half fragments of step i+1 are read under them ----
+      load_frags(S1, 0, ax, bx);
+#pragma unroll
+      for (int sl = 0; sl < 8; ++sl) mma8(ay, by, 2 + (sl >> 2), sl & 3);
+#if K2_SCHED == 1
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
+      }
+      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+#endif
+#endif
+      st = st1;
+    }
+    in_loop = false;
+    // st is now the slot after the last contracted step: free (the last two steps staged zero fills there and beyond),
+    // and so is st + 1 (every wave passed the last step's barrier, i.e. is done with the step before it).  Stage the
+    // NEXT part's first two steps now, so that they land while this part is handed off / written out.
+    const bool has_begin = cur.ka == 0, has_end = cur.kb == nk;
+    if (ip + 1 < nparts) {
+      cur = part_of(ip + 1);
+      stage_setup(cur);
+      prefetch2(cur, st);
+    }
+#if K2_ABL & 8
+    if (acc[0][0][0] != 12345.f) continue;
+#endif
+
+    // Everything below derives its per-lane addresses from `le`, which the compiler cannot see through: otherwise it
+    // computes the hand-off / epilogue addresses BEFORE the k-loop and carries ~100 VGPRs through it.
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int r_e = le & 15, g_e = le >> 4;
+    if (!(K2_ABL & 32) && !(has_begin && has_end)) {
+      // ---- shared tile: first to finish parks its part, second adds it and owns the epilogue ----
+      const int b = has_begin ? w : w - 1;                 // boundary index: the tile is shared with w + 1 resp. w - 1
+      unsigned* word = q.sync + K2_WORD0 + 2 * b;
+      __syncthreads();                                     // s_misc reuse
+      if (t == 0) s_misc[0] = (int)(__hip_atomic_exchange(word, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q.epoch);
+      __syncthreads();
+      const bool first = __builtin_amdgcn_readfirstlane(s_misc[0]) != 0;
+      const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(q.ws + (size_t)b * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+      if (first) {
+        // Partials move as sc1 (agent-scope) b128 buffer stores / loads and the words as sc1 relaxed atomics: they write
+        // through / read past the per-XCD L2, so no L2 write-back or invalidate (which would evict the weights every
+        // other workgroup of the XCD is streaming) is needed.  Order: stores complete (vmcnt 0) -> workgroup barrier -> word.
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            u32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][e]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rsP, (((wave * TM + i) * TN + j) * 64 + le) * 16, 0, K2_SC1);
+          }
+        K2_WAIT_VMCNT(0);
+        __syncthreads();
+        if (t == 0) __hip_atomic_store(word + 1, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
+      if (t == 0) {                                        // the other contributor has arrived: it is running and will publish
+        unsigned spins = 0;
+        while (__hip_atomic_load(word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q.epoch) {
+          __builtin_amdgcn_s_sleep(8);
+          if (++spins > K2_SPIN_LIMIT) { atomicAdd(q.sync + 8, 1u); break; }
+        }
+      }
+      __syncthreads();
+      // the parked part comes in quarters of 8 tiles, all 8 loads of a quarter in flight before the first add
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 o[2][TN];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            o[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (((wave * TM + qq * 2 + i) * TN + j) * 64 + le) * 16, 0, K2_SC1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[qq * 2 + i][j][e] += __uint_as_float(o[i][j][e]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- epilogue (same operation order as conv_gemm_kernel / conv_sk_kernel) ----
+    // The MFMAs were issued with the operands swapped (D = W_tile . A_tile^T), so in the C/D layout
+    // (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds 4 CONSECUTIVE output channels of ONE row:
+    // bias / residual loads and the stores are float4.  Needs ldc/ldr/ldr2/ldc2 % 4 == 0 (checked on the host).
+    // In quarters of 8 accumulator tiles: ALL residual loads of a quarter (R and R2: up to 16 KB per wave) are issued
+    // before its first use -- with one workgroup per CU nothing else hides the memory latency, and one dependent
+    // load -> add -> store round per tile cost 30+ us per tile part.  sched_barrier(0) on both sides keeps the
+    // compiler from merging quarters (which spills).
+    if (m0 + wm * 128 >= p.M) continue;
+    f32x4 bb[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bb[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + j * 16 + g_e * 4);
+    }
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      __builtin_amdgcn_sched_barrier(0);
+      f32x4 rr[2][TN], rr2[2][TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = min(m0 + wm * 128 + (qq * 2 + i) * 16 + r_e, p.M - 1);    // clamped: rows >= M are never stored
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nn = n0 + wn * 64 + j * 16 + g_e * 4;
+          if (p.R && !(K2_ABL & 128)) rr[i][j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nn);
+          if (p.R2 && !(K2_ABL & 128)) rr2[i][j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + nn);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // every option is ONE wave-uniform branch around a loop over the quarter's 32 elements (not a branch per element)
+      f32x4 v[2][TN];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          v[i][j] = acc[qq * 2 + i][j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][j][e] += bb[j][e];
+        }
+      if (p.act == ACT_LRELU) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][j][e] = v[i][j][e] > 0.f ? v[i][j][e] : v[i][j][e] * p.act_slope;
+      } else if (p.act == ACT_RELU) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][j][e] = fmaxf(v[i][j][e], 0.f);
+      } else if (p.act != ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][j][e] = k2_act_slow(v[i][j][e], p.act);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[i][j][e] *= p.alpha;
+      if (p.R && !(K2_ABL & 128)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][j][e] += rr[i][j][e];
+      }
+      if (p.R2 && !(K2_ABL & 128)) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][j][e] = rr2[i][j][e] + v[i][j][e];
+      }
+      if (p.div > 0.f) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][j][e] = v[i][j][e] / p.div;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm * 128 + (qq * 2 + i) * 16 + r_e;
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int nn = n0 + wn * 64 + j * 16 + g_e * 4;
+          if (!(K2_ABL & 64) || v[i][j][0] == 12345.f) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + nn) = v[i][j];
+          if (p.C2 && !(K2_ABL & 64)) {
+            f32x4 w2;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) w2[e] = v[i][j][e] > 0.f ? v[i][j][e] : v[i][j][e] * p.c2_slope;
+            *reinterpret_cast<f32x4*>(p.C2 + (size_t)m * p.ldc2 + nn) = w2;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#endif
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+// Workspace / words / function attribute / CU count live per (device, stream): two devices in one process may both
+// use the null stream, and a workspace belongs to the device it was allocated on.
+struct Sk2State {
+  float* ws = nullptr;
+  unsigned* sync = nullptr;
+  unsigned epoch = 0;
+};
+struct Sk2Dev { int cus = 0; bool attr[2] = {false, false}; };
+static std::map<std::pair<int, hipStream_t>, Sk2State> g_k2;
+static std::map<int, Sk2Dev> g_k2_dev;
+static std::mutex g_k2_mu;
+constexpr size_t K2_SYNC_BYTES = (K2_WORD0 + 2 * K2_MAXG) * sizeof(unsigned) + 256;
+constexpr size_t K2_LDS = 3 * (size_t)K2_STAGE * sizeof(float) + (2 * K2_BM + 4) * sizeof(int);
+
+bool conv_sk2_eligible(const GemmArgs& a) {
+  return a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && a.Cin % K2_BK == 0 && (a.lda & 3) == 0 &&
+         a.N % K2_BN == 0 && a.M > 0 && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && (!a.R2 || (a.ldr2 & 3) == 0) &&
+         (!a.C2 || (a.ldc2 & 3) == 0) && ((size_t)(a.M + a.pad + 256) * a.lda + a.Cin) * 4 < 0x7ff00000ull &&
+         (size_t)a.N * a.taps * a.Cin * 4 < 0x7ff00000ull &&
+         (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f));
+}
+
+int conv_sk2_error_count() {
+  std::lock_guard<std::mutex> lk(g_k2_mu);
+  int total = 0;
+  for (auto& kv : g_k2) {
+    unsigned v = 0;
+    if (kv.second.sync && hipMemcpy(&v, kv.second.sync + 8, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) total += (int)v;
+  }
+  return total;
+}
+
+template <bool LRELU>
+static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
+  int dev = 0;
+  SS_HIP_CHECK(hipGetDevice(&dev));
+  Sk2State* st = nullptr;
+  int cus = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_k2_mu);
+    Sk2Dev& d = g_k2_dev[dev];
+    if (!d.cus) {
+      SS_HIP_CHECK(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
+      if (d.cus <= 0) d.cus = 256;
+      if (d.cus > K2_MAXG) d.cus = K2_MAXG;
+    }
+    if (!d.attr[LRELU]) {
+      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk2_kernel<LRELU>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2_LDS));
+      d.attr[LRELU] = true;
+    }
+    cus = d.cus;
+    st = &g_k2[std::make_pair(dev, stream)];
+    if (!st->ws) {
+      SS_HIP_CHECK(hipMalloc(&st->ws, (size_t)K2_MAXG * K2_BM * K2_BN * sizeof(float)));
+      SS_HIP_CHECK(hipMalloc(&st->sync, K2_SYNC_BYTES));
+      SS_HIP_CHECK(hipMemsetAsync(st->sync, 0, K2_SYNC_BYTES, stream));
+    }
+  }
+  const long long tiles = (long long)cdiv(a.M, K2_BM) * (a.N / K2_BN);
+  long long G = g_force > 0 ? g_force : cus;        // one workgroup per CU (147 KB of LDS each)
+  if (G > tiles) G = tiles;                         // a range never lies strictly inside a tile: two contributors at most
+  if (G > K2_MAXG) G = K2_MAXG;
+  if (G < 1) G = 1;
+  Sk2Args q;
+  q.ws = st->ws; q.sync = st->sync; q.G = (int)G;
+  q.epoch = ++st->epoch;
+  if (q.epoch == 0) q.epoch = ++st->epoch;          // 0 is what a fresh word holds
+  ProfRec rec{}; bool prof = false;
+  int rc = prof_begin(a, stream, 15, rec, prof);
+  if (rc != SS_OK) return rc;
+  hipLaunchKernelGGL((conv_sk2_kernel<LRELU>), dim3((unsigned)G), dim3(256), K2_LDS, stream, a, q);
+  SS_LAUNCH_CHECK();
+  return prof_end(stream, rec, prof);
+}
+
+int launch_conv_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
+  if (!conv_sk2_eligible(a)) return SS_ERR_ARG;
+  return a.in_act == ACT_LRELU ? launch_sk2<true>(a, stream, g_force) : launch_sk2<false>(a, stream, g_force);
+}
+
+}  // namespace ss

@@ -605,7 +605,7 @@ static const char* kTileNames[kNumTileCfg] = {
     "conv_gemm<16,128,16,1,4>", "conv_gemm<128,128,16,2,2>", "conv_gemm<128,64,32,2,2>", "conv_gemm<64,64,32,2,2>",
     "conv_gemm<64,64,16,2,2>", "conv_gemm<32,64,32,2,2>", "conv_gemm<32,64,16,2,2>", "conv_gemm<32,32,32,2,2>",
     "smallm_gemm<4,1>", "smallm_gemm<2,2>", "smallm_gemm<1,4>", "conv_sk<128,BN,32>",
-    "conv_slab<32>", "conv_slab<16>"};
+    "conv_slab<32>", "conv_slab<16>", "conv_sk2<256,128,32>"};
 static int g_prof_mask = 0;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
@@ -745,6 +745,7 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   a.dbg = g_dbg;
 #endif
   if (g_force_bm == 1 && conv_sk_eligible(a)) return launch_conv_sk(a, stream, g_force_ks);   // tuning hook: stream-K, grid = ks (0 = auto)
+  if (g_force_bm == 4 && conv_sk2_eligible(a)) return launch_conv_sk2(a, stream, g_force_ks);  // tuning hook: 2nd-generation stream-K
   // Big "same" convs / linears (packed vocoder batches, unit-decoder FFN): persistent stream-K
   // 128-wide tiles, 95-110 TFLOP/s against 75-90 for the 32x64 kernel (profiles/r01_sk_sweep.txt).
   // They need enough k-steps per workgroup to amortise the fix-up + epilogue: >= 12 at BN = 128;
@@ -754,6 +755,8 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
     const bool wide = a.N % 128 == 0;
     const long long units = (long long)cdiv(a.M, 128) * (a.N / (wide ? 128 : 64)) * nk;
     static const long long min_units = getenv("SS_SK_MIN_UNITS") ? atoll(getenv("SS_SK_MIN_UNITS")) : 12 * 512;   // tuning knob
+    static const bool no_sk2 = getenv("SS_NO_SK2") && atoi(getenv("SS_NO_SK2"));   // A/B knob: first-generation kernel for the wide convs too
+    if (wide && units >= min_units && !no_sk2 && conv_sk2_eligible(a)) return launch_conv_sk2(a, stream);
     if (wide ? units >= min_units : a.taps * a.Cin >= 448) return launch_conv_sk(a, stream);
   }
   if (g_force_bm && a.N > 32 && k32) {   // tuning hook (tools/conv_bench.py): ks = KS*10 + PD

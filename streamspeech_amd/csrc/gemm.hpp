@@ -59,7 +59,7 @@ struct GemmArgs {
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 18;
+constexpr int kNumTileCfg = 19;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
@@ -77,6 +77,12 @@ bool conv_sk_eligible(const GemmArgs& a);
 int launch_conv_sk(const GemmArgs& a, hipStream_t stream, int g_force = 0);
 int conv_sk_error_count();
 void conv_sk_set_groups(int on);   // tuning hook: XCD tile grouping on/off
+
+// Second-generation stream-K kernel for N % 128 == 0 (conv_sk2.hip): 256 x 128 tiles, one workgroup per CU, 3-stage
+// LDS-DMA ring, software-pipelined k-loop, wait-free two-contributor hand-off.  g_force > 0 fixes the grid size.
+bool conv_sk2_eligible(const GemmArgs& a);
+int launch_conv_sk2(const GemmArgs& a, hipStream_t stream, int g_force = 0);
+int conv_sk2_error_count();
 
 // Slab conv for the narrow vocoder stages (conv_slab.hip): C, N in {16, 32}, weights + input slab in LDS.
 bool conv_slab_eligible(const GemmArgs& a);

@@ -1402,4 +1402,4 @@ extern "C" int ss_debug_force_tile(int bm, int bn, int ks) {
   debug_force_tile(bm == 3 ? 0 : bm, bn, ks);
   return SS_OK;
 }
-extern "C" int ss_debug_sk_errors(void) { return conv_sk_error_count(); }
+extern "C" int ss_debug_sk_errors(void) { return conv_sk_error_count() + conv_sk2_error_count(); }

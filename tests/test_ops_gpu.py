@@ -252,6 +252,77 @@ def test_stream_k_conv_matches_torch(lib, M, N, Cin, taps, dil, G):
 
 
 
+# ---- second-generation stream-K kernel (conv_sk2.hip): 256 x 128 tiles, wait-free two-contributor hand-off ----
+@pytest.mark.parametrize("M,N,Cin,taps,dil,G", [
+    (1000, 256, 256, 11, 5, 0), (1000, 256, 256, 11, 5, 7), (1000, 256, 256, 3, 1, 8), (777, 128, 128, 7, 3, 3),
+    (9000, 256, 128, 7, 3, 0), (9000, 256, 128, 7, 3, 71), (300, 1280, 512, 3, 1, 0), (257, 128, 64, 1, 1, 2),
+    (40, 128, 32, 1, 1, 1), (20011, 128, 128, 3, 1, 0), (5000, 512, 256, 3, 1, 33)])
+def test_stream_k2_conv_matches_torch(lib, M, N, Cin, taps, dil, G):
+    """Every hand-off shape of the 2nd-generation kernel: tiles shared by two workgroups in both walking directions,
+    grid capped at the tile count, G = 1 (no split), ragged last M tile, 1..88 k-steps per part (pipeline prologue
+    with one step only); leaky-ReLU input, bias, both residuals and the MRF division in the epilogue."""
+    from streamspeech_amd.weights import conv_tap_major
+    A = rnd(M, Cin, seed=11)
+    W = rnd(N, Cin, taps, seed=12, scale=(Cin * taps) ** -0.5)
+    b, R, R2 = rnd(N, seed=13, scale=0.1), rnd(M, N, seed=14), rnd(M, N, seed=15)
+    Wp = conv_tap_major(W) if taps > 1 else W.view(N, Cin)
+    lib.ss_debug_force_tile(4, 0, G)
+    try:
+        got = run_conv_gemm(lib, A, Wp, b, M, N, Cin, taps=taps, dil=dil, pad=dil * (taps - 1) // 2, in_act=3, slope=0.1,
+                            div=3.0, R=R, R2=R2)
+        got2 = run_conv_gemm(lib, A, Wp, b, M, N, Cin, taps=taps, dil=dil, pad=dil * (taps - 1) // 2, in_act=3, slope=0.1,
+                             div=3.0, R=R, R2=R2)
+        plain = run_conv_gemm(lib, A, Wp, None, M, N, Cin, taps=taps, dil=dil, pad=dil * (taps - 1) // 2)
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)
+    assert lib.ss_debug_sk_errors() == 0
+    ref = (R2 + (_conv_ref(A, W.reshape(N, -1) if taps == 1 else W, b, taps, dil, 0.1) + R)) / 3.0
+    assert torch.isfinite(got).all()
+    assert (got - ref).abs().max() < TOL, f"max err {(got - ref).abs().max()}"
+    assert torch.equal(got, got2), "the result must not depend on which contributor arrives first"
+    assert (plain - _conv_ref(A, W.reshape(N, -1) if taps == 1 else W, None, taps, dil)).abs().max() < TOL
+
+
+def test_stream_k2_handoff_is_reproducible_under_load(lib):
+    """Workspace slots and hand-off words are reused by every launch (partials travel as sc1 stores/loads past the
+    non-coherent per-XCD L2s; the words carry a launch epoch).  Alternate two different problems of the same shape
+    150 times on one stream while a second stream keeps the chip busy with another stream-K conv: every launch must
+    reproduce its own first result bit for bit, whoever arrives first at each shared tile."""
+    from streamspeech_amd.weights import conv_tap_major
+    M, N, Cin, taps, dil = 8200, 256, 128, 7, 3
+    pad = dil * (taps - 1) // 2
+    W = rnd(N, Cin, taps, seed=41, scale=(Cin * taps) ** -0.5)
+    Wp = conv_tap_major(W).contiguous().cuda()
+    A = [rnd(M, Cin, seed=42 + i).cuda() for i in range(2)]
+    out = [torch.empty(M, N, device="cuda") for _ in range(2)]
+    side = torch.cuda.Stream()
+    sA, sO = rnd(3000, Cin, seed=50).cuda(), torch.empty(3000, N, device="cuda")
+    first = [None, None]
+    torch.cuda.synchronize()
+    lib.ss_debug_force_tile(4, 0, 0)
+    try:
+        for it in range(150):
+            i = it & 1
+            out[i].fill_(float("nan"))
+            with torch.cuda.stream(side):        # uneven background load on another stream (own workspace)
+                assert lib.ss_op_conv_gemm(S(), P(sA), Cin, P(Wp), None, None, N, None, N, P(sO), N, 3000, N, Cin, taps, dil, 1, pad,
+                                           3000, 0, 0, 0.1, 0, 1.0, 0.0, 0) == 0
+            assert lib.ss_op_conv_gemm(S(), P(A[i]), Cin, P(Wp), None, None, N, None, N, P(out[i]), N, M, N, Cin, taps, dil, 1, pad,
+                                       M, 0, 0, 0.1, 0, 1.0, 0.0, 0) == 0
+            if first[i] is None:
+                torch.cuda.synchronize()
+                first[i] = out[i].clone()
+            elif it % 10 < 2 or it > 140:
+                torch.cuda.synchronize()
+                assert torch.equal(out[i], first[i]), f"launch {it} differs"
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)
+    torch.cuda.synchronize()
+    assert lib.ss_debug_sk_errors() == 0
+    ref = _conv_ref(A[0].cpu(), W, None, taps, dil)
+    assert (first[0].cpu() - ref).abs().max() < TOL
+
+
 # ---- slab conv for the narrow vocoder stages (conv_slab.hip) -------------------------------------
 @pytest.mark.parametrize("M,C,N,taps,dil,lrelu", [
     (5000, 32, 32, 11, 5, True), (5000, 32, 32, 3, 1, False), (4099, 16, 16, 11, 5, True), (2048, 16, 16, 7, 3, True),
