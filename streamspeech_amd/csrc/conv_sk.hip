@@ -47,6 +47,12 @@ constexpr int SK_BM = 128, SK_BK = 32, SK_FLAG0 = 16, SK_MAXG = 512;
 [[maybe_unused]] constexpr int SK_NUM_RECORDS = 0x7ffffff0;          // buffer range: every real offset is below, SK_OOB is above
 [[maybe_unused]] constexpr unsigned SK_OOB = 0x80000000u;
 
+__device__ __attribute__((noinline)) float sk_act_slow(float v, int act) {
+  if (act == ACT_SILU) return v / (1.0f + expf(-v));
+  if (act == ACT_TANH) return tanhf(v);
+  return v;
+}
+
 template <int BN, bool LRELU>
 __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const SkArgs q) {
 #if __HIP_DEVICE_COMPILE__   // the buffer-resource builtins have no host-pass meaning (the stub would not be emitted)
@@ -130,10 +136,15 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
         int lo = 0, hi = 0;
         if (m < p.M) {
           if (p.nseg > 0) {
-            for (int s = 0; s < p.nseg; ++s) {
-              const int st = p.segs[4 * s], ln = p.segs[4 * s + 1];
-              if (m >= st && m < st + ln) { lo = st; hi = st + ln; }
+            // segments are contiguous and ascending (same_rows): binary search for the one that holds row m
+            int a = 0, bsz = p.nseg;
+            while (bsz > 1) {
+              const int half = bsz >> 1;
+              if (p.segs[4 * (a + half)] <= m) a += half;
+              bsz -= half;
             }
+            const int st = p.segs[4 * a], ln = p.segs[4 * a + 1];
+            if (m >= st && m < st + ln) { lo = st; hi = st + ln; }
           } else {
             hi = p.in_len;
           }
@@ -335,49 +346,73 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
     // (col = lane&15, row = 4*(lane>>4) + reg) a lane holds 4 CONSECUTIVE output channels of ONE row:
     // bias / residual loads and the stores are float4 (4x fewer memory instructions than the scalar
     // column-per-lane form, same 64-B segments).  Needs ldc/ldr/ldr2/ldc2 % 4 == 0 (checked on the host).
+    // Every option is ONE wave-uniform branch around a loop over a row tile's TN x 4 elements, and SiLU / tanh are out
+    // of line: a per-element switch with expf / tanhf / division inlined made this a 57-KB kernel whose epilogue
+    // thrashed the instruction cache (profiles/r02_sk2_ablation_epilogue.txt).
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       const int m = m0 + wm * 64 + i * 16 + r;
       if (m >= p.M) continue;
+      f32x4 v[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        v[j] = acc[i][j];
+        if (p.bias) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * (BN / 2) + j * 16 + g * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] += b[e];
+        }
+      }
+      if (p.act == ACT_LRELU) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] > 0.f ? v[j][e] : v[j][e] * p.act_slope;
+      } else if (p.act == ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = fmaxf(v[j][e], 0.f);
+      } else if (p.act != ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = sk_act_slow(v[j][e], p.act);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[j][e] *= p.alpha;
+      if (p.R) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + n0 + wn * (BN / 2) + j * 16 + g * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] += rr[e];
+        }
+      }
+      if (p.R2) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + n0 + wn * (BN / 2) + j * 16 + g * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = rr[e] + v[j][e];
+        }
+      }
+      if (p.div > 0.f) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[j][e] = v[j][e] / p.div;
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 16 + g * 4;
-        f32x4 v = acc[i][j];
-        if (p.bias) {
-          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += b[e];
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          switch (p.act) {
-            case ACT_SILU: v[e] = v[e] / (1.0f + expf(-v[e])); break;
-            case ACT_RELU: v[e] = fmaxf(v[e], 0.f); break;
-            case ACT_TANH: v[e] = tanhf(v[e]); break;
-            case ACT_LRELU: v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope; break;
-            default: break;
-          }
-          v[e] *= p.alpha;
-        }
-        if (p.R) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += rr[e];
-        }
-        if (p.R2) {
-          const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + n);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = rr[e] + v[e];
-        }
-        if (p.div > 0.f) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] / p.div;
-        }
-        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+        *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v[j];
         if (p.C2) {
           f32x4 w2;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) w2[e] = v[e] > 0.f ? v[e] : v[e] * p.c2_slope;
+          for (int e = 0; e < 4; ++e) w2[e] = v[j][e] > 0.f ? v[j][e] : v[j][e] * p.c2_slope;
           *reinterpret_cast<f32x4*>(p.C2 + (size_t)m * p.ldc2 + n) = w2;
         }
       }

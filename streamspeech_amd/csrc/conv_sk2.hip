@@ -143,10 +143,16 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       int lo = 0, hi = 0;
       if (m < p.M) {
         if (p.nseg > 0) {
-          for (int s = 0; s < p.nseg; ++s) {
-            const int sst = p.segs[4 * s], ln = p.segs[4 * s + 1];
-            if (m >= sst && m < sst + ln) { lo = sst; hi = sst + ln; }
+          // segments are contiguous and ascending (same_rows): binary search for the one that holds row m
+          // (a linear scan is nseg dependent scalar loads -- ~3 us per row tile at 32 utterances)
+          int a = 0, bsz = p.nseg;
+          while (bsz > 1) {
+            const int half = bsz >> 1;
+            if (p.segs[4 * (a + half)] <= m) a += half;
+            bsz -= half;
           }
+          const int sst = p.segs[4 * a], ln = p.segs[4 * a + 1];
+          if (m >= sst && m < sst + ln) { lo = sst; hi = sst + ln; }
         } else {
           hi = p.in_len;
         }
@@ -604,7 +610,7 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   q.epoch = ++st->epoch;
   if (q.epoch == 0) q.epoch = ++st->epoch;          // 0 is what a fresh word holds
   ProfRec rec{}; bool prof = false;
-  int rc = prof_begin(a, stream, 15, rec, prof);
+  int rc = prof_begin(a, stream, 18, rec, prof);
   if (rc != SS_OK) return rc;
   hipLaunchKernelGGL((conv_sk2_kernel<LRELU>), dim3((unsigned)G), dim3(256), K2_LDS, stream, a, q);
   SS_LAUNCH_CHECK();

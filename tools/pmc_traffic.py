@@ -15,7 +15,7 @@ import json
 import sys
 from collections import defaultdict
 
-CLASSES = [("void ss::conv_sk_kernel", "conv_sk<128,BN,32>"), ("void ss::conv_slab_kernel<32", "conv_slab<32>"),
+CLASSES = [("void ss::conv_sk2_kernel", "conv_sk2<256,128,32>"), ("void ss::conv_sk_kernel", "conv_sk<128,BN,32>"), ("void ss::conv_slab_kernel<32", "conv_slab<32>"),
            ("void ss::conv_slab_kernel<16", "conv_slab<16>"),
            ("void ss::conv_gemm_kernel<32, 64, 32", "conv_gemm<32,64,32,2,2>"), ("void ss::conv_gemm_kernel<32, 32, 32", "conv_gemm<32,32,32,2,2>"),
            ("void ss::conv_gemm_kernel<128, 32, 32", "conv_gemm<128,32,32,4,1>"), ("void ss::conv_gemm_kernel<128, 16, 16", "conv_gemm<128,16,16,4,1>"),

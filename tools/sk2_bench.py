@@ -10,7 +10,9 @@ SHAPES = [("stage0 k11", 38900, 256, 256, 11, 5), ("stage0 k7", 38900, 256, 256,
           ("stage1 k11", 155600, 128, 128, 11, 5), ("stage1 k7", 155600, 128, 128, 7, 1), ("stage1 k3", 155600, 128, 128, 3, 3),
           ("up1", 38900, 512, 256, 3, 1), ("up2", 155600, 256, 128, 3, 1), ("up0", 7780, 1280, 512, 3, 1),
           ("conv_pre", 7780, 512, 128, 7, 1), ("unit fc1", 14400, 2048, 512, 1, 1), ("unit fc2", 14400, 512, 2048, 1, 1),
-          ("unit qkv", 14400, 1536, 512, 1, 1), ("enc ffn1", 3900, 2048, 256, 1, 1), ("enc ffn2", 3900, 256, 2048, 1, 1)]
+          ("unit qkv", 14400, 1536, 512, 1, 1), ("enc ffn1", 3900, 2048, 256, 1, 1), ("enc ffn2", 3900, 256, 2048, 1, 1),
+          ("stage2 k11", 622400, 64, 64, 11, 5), ("stage2 k7", 622400, 64, 64, 7, 3), ("stage2 k3", 622400, 64, 64, 3, 1),
+          ("up3", 622400, 64, 64, 3, 1)]
 
 
 def run_one():
@@ -20,7 +22,7 @@ def run_one():
     lib = L.load()
     P = lambda t: None if t is None else C.c_void_p(t.data_ptr())
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    print("library:", os.environ.get("SS_HIP_LIB", "default"))
+    print("library:", os.environ.get("SS_HIP_LIB", "default"), "| in-loop leaky-ReLU" if os.environ.get("SK2_LRELU") else "")
     print("%-12s %9s %9s %9s | %8s %8s %8s | %9s %5s" % ("shape", "32x64 us", "sk us", "sk2 us", "32x64 TF", "sk TF", "sk2 TF", "max|d|", "det"))
     tot = {"sk": 0.0, "sk2": 0.0}
     only = [x.strip() for x in os.environ.get("SK2_SHAPES", "").split(",") if x.strip()]
@@ -37,7 +39,11 @@ def run_one():
         for key, code in (("t", (32, 64, 11)), ("sk", (1, 0, 0)), ("sk2", (4, 0, 0))):
             lib.ss_debug_force_tile(*code)
             Cc = torch.empty(M, N, device="cuda")
-            args = (s, P(A), Cin, P(W), P(b), P(R), N, None, N, P(Cc), N, M, N, Cin, taps, dil, 1, pad, M, 0, 0, 0.1, 0, 1.0, 0.0, 0)
+            in_act = 3 if os.environ.get("SK2_LRELU") else 0      # leaky-ReLU on the conv input inside the k-loop
+            args = (s, P(A), Cin, P(W), P(b), P(R), N, None, N, P(Cc), N, M, N, Cin, taps, dil, 1, pad, M, 0, in_act, 0.1, 0, 1.0, 0.0, 0)
+            if key == "sk2" and N % 128:
+                times[key], outs[key] = float("nan"), (outs["sk"][0], True)
+                continue
             for _ in range(2):
                 assert lib.ss_op_conv_gemm(*args) == 0
             torch.cuda.synchronize()
