@@ -16,13 +16,15 @@
 //     current half's MFMAs issue, and the one barrier per k-step sits in the MIDDLE of the second half -- the
 //     remaining 64 MFMAs cover the barrier, the DMA wait and the first ds_reads of the next stage.  The
 //     12 DMA pieces of a step are spread over the first half's MFMA groups.
-//   * stream-K hand-off without waiting: every shared tile has exactly two contributors (grid <= tiles).
-//     Whoever finishes its part first parks it (sc1 write-through stores) and raises `ready`; the second one
-//     adds it and runs the epilogue (a + b is commutative, so the result does not depend on who was first).
-//     A workgroup never waits for one that has not arrived yet, so there are no tickets and no dependence on
-//     dispatch order.  Odd workgroups walk their range forwards, even ones backwards: the tile shared by an
-//     even workgroup and its right neighbour is worked on by both FIRST, so half of the fix-ups and epilogues
-//     happen in the middle of the launch instead of all at its end.
+//   * stream-K hand-off as in conv_sk.hip: ranges are walked last-tile-first, so the part a workgroup has to park (the
+//     head k-steps of the last tile of its range) is done FIRST and the tile it has to finish comes LAST -- by then the
+//     lower-numbered workgroups that share it have long parked theirs.  Logical workgroup ids come from an atomic
+//     ticket, so a finisher only ever waits for workgroups that are already running (several stream-K launches on
+//     different streams may share the chip).  Partials are summed in workgroup order: deterministic.
+//   * the staging pipeline runs two k-steps ahead of the contraction straight across part boundaries: the next
+//     part's first steps are in flight while a part is finished, the pipeline never drains.
+//   * epilogue: residual loads of 8 accumulator tiles in flight at a time, every option one wave-uniform branch
+//     (a per-element switch with expf / tanhf inlined made a 115-KB kernel that thrashed the instruction cache).
 #include "gemm.hpp"
 
 #include <map>
@@ -38,16 +40,17 @@ constexpr int K2_BM = 256, K2_BN = 128, K2_BK = 32;
 constexpr int K2_STAGE = (K2_BM + K2_BN) * K2_BK;       // floats per ring stage (48 KB)
 constexpr int K2_SC1 = 16;                              // buffer cache policy bit: agent scope
 constexpr int K2_MAXG = 512;
-constexpr int K2_WORD0 = 16;                            // sync[K2_WORD0 + 2 b] = arrival word of boundary b, + 1 = ready word
+constexpr int K2_WORD0 = 16;                            // sync[K2_WORD0 + w] = flag of logical workgroup w
 [[maybe_unused]] constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
 [[maybe_unused]] constexpr int K2_NUM_RECORDS = 0x7ffffff0;
 [[maybe_unused]] constexpr unsigned K2_OOB = 0x80000000u;
 
 struct Sk2Args {
-  float* ws;            // [G][256*128] parked partial tiles; slot b = the tile shared by workgroups b and b + 1
-  unsigned* sync;       // [8] time-out counter, [K2_WORD0 + 2 b] arrival word, [K2_WORD0 + 2 b + 1] ready word
-  unsigned epoch;       // value that marks "of this launch" in both words
-  int G;                // workgroups (<= tiles: every shared tile has exactly two contributors)
+  float* ws;            // [G][256*128] parked partial tiles, slot = logical workgroup id
+  unsigned* sync;       // [0] ticket counter, [8] time-out counter, [K2_WORD0 + w] flag of logical workgroup w
+  unsigned base;        // ticket value of logical workgroup 0 of this launch
+  unsigned epoch;       // flag value meaning "the partial of this launch is in place"
+  int G;                // workgroups (<= CUs: one per CU, all resident)
 };
 
 #define K2_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -82,7 +85,9 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 15, g = lane >> 4;
-  const int w = blockIdx.x;
+  if (t == 0) s_misc[0] = (int)(atomicAdd(q.sync, 1u) - q.base);
+  __syncthreads();
+  const int w = __builtin_amdgcn_readfirstlane(s_misc[0]);   // logical id in order of arrival: range, workspace slot, flag
 
   const int kpt = p.Cin / BK;
   const int nk = p.taps * kpt;
@@ -93,7 +98,6 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   const long long u0 = (long long)w * U / q.G, u1 = (long long)(w + 1) * U / q.G;
   if (u1 <= u0) return;
   const int t_first = (int)(u0 / nk), t_last = (int)((u1 - 1) / nk);
-  const bool fwd = (w & 1) != 0;
 
   const float slope = p.in_slope;
   // Buffer resources of the LDS-DMA loads: per-lane byte offsets stay constant over a tile part, the k-step
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   struct Part { int ka, kb, n, m0, n0, tm; };
   const int nparts = t_last - t_first + 1;
   auto part_of = [&](int ip) {
-    const int tile = fwd ? t_first + ip : t_last - ip;
+    const int tile = t_last - ip;              // last tile first: see the header
     const long long ut0 = (long long)tile * nk;
     Part P;
     P.ka = (int)(max(u0, ut0) - ut0);
@@ -216,17 +220,32 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     for (int j = 0; j < 4; ++j) issueW(stage, j, live);
     step_advance(live);
   };
-  // first two k-steps of a part into ring slots `slot`, `slot + 1` (a one-step part gets a zero fill for the second)
-  auto prefetch2 = [&](const Part& P, int slot) {
-    issue_step(slot, true);
-    issue_step(slot == 2 ? 0 : slot + 1, P.n > 1);
+  // ---- the stager: runs two k-steps ahead of the contraction, straight across part boundaries ----
+  // All k-steps of all parts of this workgroup form one sequence; step c is contracted out of ring slot c % 3 while
+  // step c + 2 is staged.  When the stager finishes a part it moves on to the next one (row bounds + offsets), so at a
+  // part boundary the next part's first two steps are already in flight / landed and its first fragments are read by
+  // the last iteration of the previous part: the pipeline never drains, the epilogue is the only gap.
+  int stage_ip = 0, stage_left = 0;      // part being staged, steps of it still to stage
+  auto stager_next_part = [&]() {
+    const Part P = part_of(stage_ip);
+    stage_setup(P);
+    stage_left = P.n;
+  };
+  auto stager_advance = [&]() {          // wave-uniform, taken once per part
+    if (stage_left == 0 && stage_ip + 1 < nparts) { ++stage_ip; stager_next_part(); }
   };
 
   int st = 0;                            // ring slot of the step being contracted (runs on across parts)
-  Part cur = part_of(0);
-  stage_setup(cur);
-  prefetch2(cur, st);
+  stager_next_part();
+  issue_step(0, true);
+  --stage_left;
+  stager_advance();
+  issue_step(1, stage_left > 0);
+  stage_left -= stage_left > 0 ? 1 : 0;
+  K2_WAIT_VMCNT(12);
+  __builtin_amdgcn_s_barrier();
   for (int ip = 0; ip < nparts; ++ip) {
+    const Part cur = part_of(ip);
     const int n = cur.n, m0 = cur.m0, n0 = cur.n0;
     f32x4 acc[TM][TN];
 #pragma unroll
@@ -263,16 +282,17 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // D = W.A^T: see epilogue
     };
 
-    // ---- the part's first two steps were staged ahead (before the previous part's epilogue): wait, barrier, first fragments ----
-    K2_WAIT_VMCNT(0);                    // both steps (and the previous epilogue's stores) are out of the counter
-    __builtin_amdgcn_s_barrier();
+    // The part's first step landed and was made visible by the previous part's last barrier (the initial one for part 0);
+    // its first fragments are (re)read here rather than kept in registers across the epilogue (48 VGPRs the epilogue needs).
     f32x4 ax[TM], bx[TN], ay[TM], by[TN];
     load_frags(smem + st * STAGE, 0, ax, bx);
     in_loop = true;
     for (int i = 0; i < n; ++i) {
+      stager_advance();
       const float* S = smem + st * STAGE;
       const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
-      const bool live = i + 2 < n;
+      const bool live = stage_left > 0;          // nothing left to stage: zero fills (the count stays 12 per step)
+      stage_left -= live ? 1 : 0;
       // The body is ONE basic block (no branches): DMA pieces, ds_reads and MFMAs of a step can be interleaved by the
       // scheduler.  K2_SCHED 0 leaves the order to hipcc; 1 asks for "8 MFMAs, 1 ds_read, 1 DMA piece" groups with a
       // sched_group_barrier pipeline (source order = requested order: a ds_read may not cross an LDS-DMA piece);
@@ -352,15 +372,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       st = st1;
     }
     in_loop = false;
-    // st is now the slot after the last contracted step: free (the last two steps staged zero fills there and beyond),
-    // and so is st + 1 (every wave passed the last step's barrier, i.e. is done with the step before it).  Stage the
-    // NEXT part's first two steps now, so that they land while this part is handed off / written out.
     const bool has_begin = cur.ka == 0, has_end = cur.kb == nk;
-    if (ip + 1 < nparts) {
-      cur = part_of(ip + 1);
-      stage_setup(cur);
-      prefetch2(cur, st);
-    }
 #if K2_ABL & 8
     if (acc[0][0][0] != 12345.f) continue;
 #endif
@@ -370,60 +382,62 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     int le = lane;
     asm volatile("" : "+v"(le));
     const int r_e = le & 15, g_e = le >> 4;
-    if (!(K2_ABL & 32) && !(has_begin && has_end)) {
-      // ---- shared tile: first to finish parks its part, second adds it and owns the epilogue ----
-      const int b = has_begin ? w : w - 1;                 // boundary index: the tile is shared with w + 1 resp. w - 1
-      unsigned* word = q.sync + K2_WORD0 + 2 * b;
-      __syncthreads();                                     // s_misc reuse
-      if (t == 0) s_misc[0] = (int)(__hip_atomic_exchange(word, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q.epoch);
+    if (!(K2_ABL & 32) && !has_end) {
+      // ---- contributor: park the partial tile, raise the flag ----
+      // Partials move as sc1 (agent-scope) b128 buffer stores / loads and the flags as sc1 relaxed atomics: they write
+      // through / read past the per-XCD L2, so no L2 write-back or invalidate (which would evict the weights every
+      // other workgroup of the XCD is streaming) is needed.  Order: stores complete (vmcnt 0) -> workgroup barrier -> flag.
+      const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(q.ws + (size_t)w * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          u32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][e]);
+          __builtin_amdgcn_raw_buffer_store_b128(v, rsP, (((wave * TM + i) * TN + j) * 64 + le) * 16, 0, K2_SC1);
+        }
+      K2_WAIT_VMCNT(0);
       __syncthreads();
-      const bool first = __builtin_amdgcn_readfirstlane(s_misc[0]) != 0;
-      const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(q.ws + (size_t)b * (BM * BN)), 0, BM * BN * 4, 0x00020000);
-      if (first) {
-        // Partials move as sc1 (agent-scope) b128 buffer stores / loads and the words as sc1 relaxed atomics: they write
-        // through / read past the per-XCD L2, so no L2 write-back or invalidate (which would evict the weights every
-        // other workgroup of the XCD is streaming) is needed.  Order: stores complete (vmcnt 0) -> workgroup barrier -> word.
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            u32x4 v;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(acc[i][j][e]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rsP, (((wave * TM + i) * TN + j) * 64 + le) * 16, 0, K2_SC1);
+      if (t == 0) __hip_atomic_store(q.sync + K2_WORD0 + w, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      continue;
+    }
+    if (!(K2_ABL & 32) && !has_begin) {
+      // ---- finisher: add the partials of the workgroups that own k-steps [0, ka) of this tile, in workgroup order ----
+      const long long ut0 = (long long)(t_last - ip) * nk;
+      const int wf = (int)(((ut0 + 1) * q.G - 1) / U);       // workgroup that owns the tile's first unit
+      if (t == 0) {
+        for (int ww = wf; ww < w; ++ww) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(q.sync + K2_WORD0 + ww, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q.epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > K2_SPIN_LIMIT) { atomicAdd(q.sync + 8, 1u); break; }
           }
-        K2_WAIT_VMCNT(0);
-        __syncthreads();
-        if (t == 0) __hip_atomic_store(word + 1, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        continue;
-      }
-      if (t == 0) {                                        // the other contributor has arrived: it is running and will publish
-        unsigned spins = 0;
-        while (__hip_atomic_load(word + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != q.epoch) {
-          __builtin_amdgcn_s_sleep(8);
-          if (++spins > K2_SPIN_LIMIT) { atomicAdd(q.sync + 8, 1u); break; }
         }
       }
       __syncthreads();
-      // the parked part comes in quarters of 8 tiles, all 8 loads of a quarter in flight before the first add
+      for (int ww = wf; ww < w; ++ww) {        // fixed order: ((mine + P[wf]) + P[wf+1]) + ...
+        const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(q.ws + (size_t)ww * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+        // a parked part comes in quarters of 8 tiles, all 8 loads of a quarter in flight before the first add
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) {
+        for (int qq = 0; qq < 4; ++qq) {
+          __builtin_amdgcn_sched_barrier(0);
+          u32x4 o[2][TN];
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              o[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (((wave * TM + qq * 2 + i) * TN + j) * 64 + le) * 16, 0, K2_SC1);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[qq * 2 + i][j][e] += __uint_as_float(o[i][j][e]);
+        }
         __builtin_amdgcn_sched_barrier(0);
-        u32x4 o[2][TN];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            o[i][j] = __builtin_amdgcn_raw_buffer_load_b128(rsP, (((wave * TM + qq * 2 + i) * TN + j) * 64 + le) * 16, 0, K2_SC1);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) acc[qq * 2 + i][j][e] += __uint_as_float(o[i][j][e]);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- epilogue (same operation order as conv_gemm_kernel / conv_sk_kernel) ----
@@ -546,13 +560,13 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 struct Sk2State {
   float* ws = nullptr;
   unsigned* sync = nullptr;
-  unsigned epoch = 0;
+  unsigned base = 0, epoch = 0;
 };
 struct Sk2Dev { int cus = 0; bool attr[2] = {false, false}; };
 static std::map<std::pair<int, hipStream_t>, Sk2State> g_k2;
 static std::map<int, Sk2Dev> g_k2_dev;
 static std::mutex g_k2_mu;
-constexpr size_t K2_SYNC_BYTES = (K2_WORD0 + 2 * K2_MAXG) * sizeof(unsigned) + 256;
+constexpr size_t K2_SYNC_BYTES = (K2_WORD0 + K2_MAXG) * sizeof(unsigned) + 256;
 constexpr size_t K2_LDS = 3 * (size_t)K2_STAGE * sizeof(float) + (2 * K2_BM + 4) * sizeof(int);
 
 bool conv_sk2_eligible(const GemmArgs& a) {
@@ -600,15 +614,18 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
       SS_HIP_CHECK(hipMemsetAsync(st->sync, 0, K2_SYNC_BYTES, stream));
     }
   }
-  const long long tiles = (long long)cdiv(a.M, K2_BM) * (a.N / K2_BN);
-  long long G = g_force > 0 ? g_force : cus;        // one workgroup per CU (147 KB of LDS each)
-  if (G > tiles) G = tiles;                         // a range never lies strictly inside a tile: two contributors at most
+  const long long nk = (long long)a.taps * (a.Cin / K2_BK);
+  const long long U = (long long)cdiv(a.M, K2_BM) * (a.N / K2_BN) * nk;
+  long long G = g_force > 0 ? g_force : cus;        // one workgroup per CU (147 KB of LDS each), all resident
+  if (G > cus) G = cus;
+  if (G > U / 4) G = U / 4;                         // at least 4 k-steps per workgroup
   if (G > K2_MAXG) G = K2_MAXG;
   if (G < 1) G = 1;
   Sk2Args q;
   q.ws = st->ws; q.sync = st->sync; q.G = (int)G;
+  q.base = st->base; st->base += (unsigned)G;
   q.epoch = ++st->epoch;
-  if (q.epoch == 0) q.epoch = ++st->epoch;          // 0 is what a fresh word holds
+  if (q.epoch == 0) q.epoch = ++st->epoch;          // 0 is what a fresh flag holds
   ProfRec rec{}; bool prof = false;
   int rc = prof_begin(a, stream, 18, rec, prof);
   if (rc != SS_OK) return rc;
