@@ -108,6 +108,19 @@ def cpu_baseline(sd, vsd, cfg, vcfg, utts, budget_s=25.0):
             "sample": f"{n} utterances ({audio:.1f} s of audio) of the same synthetic workload, after 1 warm-up"}
 
 
+def census(lib):
+    """Launches and algorithmic work per tile class over the WHOLE process (warm-ups, latency passes, timed region,
+    replay): divide a rocprofv3 kernel-stats / PMC profile of this command by these to recompute the roofline."""
+    out = {}
+    for c in range(lib.ss_prof_num_classes()):
+        fl, by, n = C.c_double(), C.c_double(), C.c_int64()
+        lib.ss_prof_totals(c, C.byref(fl), C.byref(by), C.byref(n))
+        if n.value:
+            out[lib.ss_prof_class_name(c).decode()] = {"launches": int(n.value), "algo_tflop": round(fl.value / 1e12, 4),
+                                                       "algo_gbytes": round(by.value / 1e9, 3)}
+    return out
+
+
 def _pmc_file():
     """Newest committed PMC summary (profiles/rNN_pmc_traffic*.json, written by tools/pmc_traffic.py)."""
     import glob
@@ -432,6 +445,7 @@ def main():
             "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),   # must be 0 (bounded waits of the stream-K fix-up); also asserted for the timed region
             "roofline": roofline,
             "roofline_second_kernel": roofline_conv,
+            "process_census": census(lib),
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, workload.make_utterances(Wn + Kpool + 1)[Wn:])

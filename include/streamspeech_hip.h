@@ -192,6 +192,10 @@ int ss_prof_enable(int cls_mask);
 int ss_prof_reset(void);
 int ss_prof_read(int cls, double* h_ms_total, double* h_flops_total, int64_t* h_launches,
                  double* h_bytes_total);
+/* Always-on census since the library was loaded (no events, no synchronisation): launches and algorithmic FLOPs /
+ * bytes of tile class `cls` over the WHOLE process -- the denominator for a rocprofv3 kernel-stats or PMC run of the
+ * same process (bench.py prints them as "process_census"). */
+int ss_prof_totals(int cls, double* h_flops_total, double* h_bytes_total, int64_t* h_launches);
 int ss_prof_num_classes(void);
 const char* ss_prof_class_name(int cls);
 

@@ -633,19 +633,43 @@ int prof_read(int cls, double* ms_total, double* flops_total, long long* launche
   return SS_OK;
 }
 
+// Always-on launch census (no events, no synchronisation): launches, algorithmic FLOPs and bytes per tile class since the
+// library was loaded.  Lets a profile of a WHOLE process (rocprofv3 kernel stats, PMC passes) be divided by the
+// algorithmic work of exactly the launches it saw.
+struct ProfTotals { double flops = 0, bytes = 0; long long launches = 0; };
+static ProfTotals g_prof_totals[kNumTileCfg];
+static std::mutex g_tot_mu;
+int prof_totals(int cls, double* flops, double* bytes, long long* launches) {
+  if (cls < 0 || cls >= kNumTileCfg) return SS_ERR_ARG;
+  std::lock_guard<std::mutex> lk(g_tot_mu);
+  if (flops) *flops = g_prof_totals[cls].flops;
+  if (bytes) *bytes = g_prof_totals[cls].bytes;
+  if (launches) *launches = g_prof_totals[cls].launches;
+  return SS_OK;
+}
+static void algo_work(const GemmArgs& a, double& flops, double& bytes) {
+  flops = a.algo_flops > 0 ? a.algo_flops : 2.0 * (double)a.M * a.N * a.taps * a.Cin;
+  // algorithmic bytes: weights + bias once, every input row once, every output element once,
+  // residual operands once (all f32); a second (pre-activated) output is NOT algorithmic
+  const double ncols = a.glu ? a.N / 2 : a.N;
+  bytes = 4.0 * ((double)a.N * a.taps * a.Cin + (a.bias ? a.N : 0) + (double)a.in_len * a.Cin +
+                 (double)a.M * ncols * (1 + (a.R ? 1 : 0) + (a.R2 ? 1 : 0)));
+}
+
 int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, bool& prof) {
+  {
+    double fl, by;
+    algo_work(a, fl, by);
+    std::lock_guard<std::mutex> lk(g_tot_mu);
+    g_prof_totals[cls].flops += fl; g_prof_totals[cls].bytes += by; g_prof_totals[cls].launches += 1;
+  }
   prof = (g_prof_mask >> cls) & 1;
   if (!prof) return SS_OK;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_pool.empty()) { rec.e0 = g_prof_pool.back().first; rec.e1 = g_prof_pool.back().second; g_prof_pool.pop_back(); }
   else { SS_HIP_CHECK(hipEventCreate(&rec.e0)); SS_HIP_CHECK(hipEventCreate(&rec.e1)); }
   rec.cls = cls;
-  rec.flops = a.algo_flops > 0 ? a.algo_flops : 2.0 * (double)a.M * a.N * a.taps * a.Cin;
-  // algorithmic bytes: weights + bias once, every input row once, every output element once,
-  // residual operands once (all f32)
-  const double ncols = a.glu ? a.N / 2 : a.N;
-  rec.bytes = 4.0 * ((double)a.N * a.taps * a.Cin + (a.bias ? a.N : 0) + (double)a.in_len * a.Cin +
-                     (double)a.M * ncols * (1 + (a.R ? 1 : 0) + (a.R2 ? 1 : 0)));
+  algo_work(a, rec.flops, rec.bytes);
   SS_HIP_CHECK(hipEventRecord(rec.e0, stream));
   return SS_OK;
 }

@@ -64,6 +64,7 @@ void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile confi
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
 const char* prof_cfg_name(int cls);
+int prof_totals(int cls, double* flops, double* bytes, long long* launches);   // always-on census since library load
 
 // Event-profiler scope shared by the kernel launchers (gemm.hip, conv_sk.hip).
 struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int cls; };

@@ -1394,6 +1394,12 @@ extern "C" int ss_prof_read(int cls, double* ms, double* flops, int64_t* launche
   if (launches) *launches = n;
   return rc;
 }
+extern "C" int ss_prof_totals(int cls, double* flops, double* bytes, int64_t* launches) {
+  long long n = 0;
+  int rc = prof_totals(cls, flops, bytes, &n);
+  if (launches) *launches = n;
+  return rc;
+}
 extern "C" int ss_prof_num_classes(void) { return kNumTileCfg; }
 extern "C" const char* ss_prof_class_name(int cls) { return prof_cfg_name(cls); }
 

@@ -2,7 +2,7 @@
 --kernel-trace --output-format csv, as MI355X_MICROARCH.md §HBM prescribes) into per-kernel and
 per-profiler-class HBM bytes per launch -> profiles/*_pmc_traffic.json (read by bench.py).
 
-  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<note>" [<mfma_counter_collection.csv>]
+  python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> "<note>" [<mfma_counter_collection.csv> [<bench.json of a pass>]]
 
 The optional third pass (--pmc MfmaUtil, the derived metric rocprofv3 -L documents:
 100 * sum(SQ_VALU_MFMA_BUSY_CYCLES) / (max(GRBM_GUI_ACTIVE) * SIMD_NUM)) adds the matrix-core busy
@@ -59,6 +59,15 @@ def main():
         for k in kernels:
             if nu.get(k, 0):
                 kernels[k]["mfma_util_pct"] = round(util[k] / nu[k], 1)
+    if len(sys.argv) > 6:      # bench.py's JSON line of one of the passes: its "process_census" counts the same launches
+        census = json.load(open(sys.argv[6])).get("process_census", {})
+        for cls, c in classes.items():
+            z = census.get(cls)
+            if z and z["launches"]:
+                c["census_launches"] = z["launches"]
+                c["algo_mbytes_per_launch"] = round(z["algo_gbytes"] * 1e3 / z["launches"], 2)
+                c["traffic_over_algorithmic"] = round(c["hbm_mbytes_per_launch_corrected"] / c["algo_mbytes_per_launch"], 3)
+                c["algo_gflop_per_launch"] = round(z["algo_tflop"] * 1e3 / z["launches"], 3)
     top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_mbytes_per_launch_corrected"] * kv[1]["launches"])[:16])
     json.dump({"note": sys.argv[4] if len(sys.argv) > 4 else "", "classes": classes, "kernels": top}, open(sys.argv[3], "w"), indent=1)
     print(json.dumps(classes, indent=1))

@@ -12,7 +12,11 @@ SHAPES = [("stage0 k11", 38900, 256, 256, 11, 5), ("stage0 k7", 38900, 256, 256,
           ("conv_pre", 7780, 512, 128, 7, 1), ("unit fc1", 14400, 2048, 512, 1, 1), ("unit fc2", 14400, 512, 2048, 1, 1),
           ("unit qkv", 14400, 1536, 512, 1, 1), ("enc ffn1", 3900, 2048, 256, 1, 1), ("enc ffn2", 3900, 256, 2048, 1, 1),
           ("stage2 k11", 622400, 64, 64, 11, 5), ("stage2 k7", 622400, 64, 64, 7, 3), ("stage2 k3", 622400, 64, 64, 3, 1),
-          ("up3", 622400, 64, 64, 3, 1)]
+          ("up3", 622400, 64, 64, 3, 1),
+          ("enc qkv", 3900, 768, 256, 1, 1), ("enc out", 3900, 256, 256, 1, 1), ("enc pw1", 3900, 512, 256, 1, 1),
+          ("ctc head", 3900, 6016, 256, 1, 1), ("unit out", 14400, 512, 512, 1, 1), ("unit head", 14400, 1024, 512, 1, 1),
+          ("sub conv1", 7800, 512, 512, 5, 1), ("short s0 k11", 12000, 256, 256, 11, 5), ("short s1 k3", 48000, 128, 128, 3, 1),
+          ("short s0 k3", 12000, 256, 256, 3, 1), ("long s0 k7", 70000, 256, 256, 7, 3)]
 
 
 def run_one():
