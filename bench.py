@@ -121,6 +121,60 @@ def census(lib):
     return out
 
 
+def streaming_mode(args, model, voc, lib, cfg):
+    """BASELINE.json configs[2]: the drop-in SimulEval agent (streamspeech_amd/agent.py) fed 320-ms chunks of synthetic
+    CVSS-C-shaped utterances, one at a time -- with the incremental encoder + receptive-field vocoder tail (default)
+    and with the reference's full recompute at every policy() call.  Random weights: the READ/WRITE pattern and the
+    MT / unit lengths are whatever the random model emits (CTC heads fire on most frames, the unit decoder collapses
+    to few units), so per-call costs are indicative, not CVSS-C statistics."""
+    from streamspeech_amd import streaming_eval as SE
+    from streamspeech_amd.agent import StreamSpeechS2STAgent
+    from streamspeech_amd.modules import CodeHiFiGANVocoderWithDur, StreamSpeechModel
+
+    class VocSurface:
+        def __init__(self, hv):
+            self.hip = hv
+        __call__ = CodeHiFiGANVocoderWithDur.__call__
+
+    utts = workload.make_utterances(args.utterances + 1)
+    pcms = [synth.synth_pcm(1234 + u.idx, u.n_samples) for u in utts]
+    out = {"metric": "simultaneous S2ST fr-en, wait-k agent policy() loop, batch 1 (BASELINE.json configs[2])", "mode": "streaming",
+           "n_gpus": 1, "dtype": "f32", "data": "synthetic", "segment_ms": args.segment_ms,
+           "config": {"workload": f"{args.utterances} synthetic CVSS-C-shaped utterances (LogNormal(ln 4.5 s, 0.45) clipped to [1,15] s), "
+                                  f"{args.segment_ms}-ms source segments at 16 kHz, StreamSpeechS2STAgent.policy() per segment, "
+                                  "random-init weights of the streamspeech.simultaneous.fr-en architecture"}}
+
+    def census_launches():
+        tot = 0
+        for c in range(lib.ss_prof_num_classes()):
+            n = C.c_int64()
+            lib.ss_prof_totals(c, None, None, C.byref(n))
+            tot += n.value
+        return tot
+
+    for name, over in (("incremental", {}), ("full_recompute", {"full_recompute_encoder": True, "vocoder_context_units": 0})):
+        p = argparse.ArgumentParser()
+        StreamSpeechS2STAgent.add_args(p)
+        a = p.parse_args(["--model-path", "synthetic:0", "--data-bin", "/nonexistent", "--vocoder", "synthetic:0", "--dur-prediction",
+                          "--sample-rate", "16000"])
+        a.source_segment_size, a.device = args.segment_ms, "gpu"
+        for k, v in over.items():
+            setattr(a, k, v)
+        agent = StreamSpeechS2STAgent(a, model=StreamSpeechModel.from_engine(model), vocoder=VocSurface(voc))
+        SE.run_utterance(agent, pcms[0], args.segment_ms)                      # warm-up utterance
+        n0 = census_launches()
+        runs = [SE.run_utterance(agent, pcm, args.segment_ms) for pcm in pcms[1:]]
+        n1 = census_launches()
+        summ = SE.summarize(runs)
+        summ["gemm_class_launches_per_policy_call"] = round((n1 - n0) / max(1, summ["policy_calls"]), 1)
+        summ["actions_first_utterance"] = runs[0]["actions"]
+        out[name] = summ
+    out["value"] = out["incremental"]["rtfx_compute"]
+    out["unit"] = "x real-time (audio s / policy() compute s, one utterance at a time)"
+    out["higher_is_better"] = True
+    print(json.dumps(out), flush=True)
+
+
 def _pmc_file():
     """Newest committed PMC summary (profiles/rNN_pmc_traffic*.json, written by tools/pmc_traffic.py)."""
     import glob
@@ -143,6 +197,11 @@ def main():
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the single-stream latency measurement")
     ap.add_argument("--batch", type=int, default=32,
                     help="utterances packed per ragged batch (1 = the one-utterance-at-a-time entry points)")
+    ap.add_argument("--mode", choices=("offline", "streaming"), default="offline",
+                    help="offline: the headline metric (default, what the driver runs); streaming: BASELINE.json configs[2] -- the "
+                         "SimulEval agent's policy() loop on 320-ms chunks, one utterance at a time")
+    ap.add_argument("--segment-ms", type=int, default=320, help="--mode streaming: source segment size")
+    ap.add_argument("--utterances", type=int, default=12, help="--mode streaming: utterances per configuration")
     ap.add_argument("--no-length-bucketing", action="store_true",
                     help="form ragged batches in arrival order instead of sorted by source length")
     args = ap.parse_args()
@@ -174,6 +233,8 @@ def main():
     model = HipModel(sd, cfg, device=dev)
     voc = HipVocoder(vsd, vcfg, device=dev)
     lib = L.load()
+    if args.mode == "streaming":
+        return streaming_mode(args, model, voc, lib, cfg)
 
     Ksteps, Wsteps, Bsz = max(1, args.steps), max(0, args.warmup), max(1, args.batch)
     K = Ksteps * Bsz                         # timed utterances per rank

@@ -153,3 +153,36 @@ def test_incremental_vocoder_tail_equals_full_resynthesis(synth_weights):
         # a context shorter than the receptive field is detected and falls back to the full pass
         inc, _ = synthesize_tail(voc, units[:100], 5, False, 10, rf)
         assert voc.call_lengths[-1] == 100
+
+
+def test_streaming_eval_latency_bookkeeping():
+    """bench.py --mode streaming: SimulEval's speech-output timing model (evaluator/instance.py:349-366, 386-415;
+    scorers/latency_scorer.py:540-587) on a scripted agent: delays are the source milliseconds received, playback
+    intervals never overlap, RTF = end of the last interval / source length."""
+    from streamspeech_amd import streaming_eval as SE
+    from streamspeech_amd.simuleval_shim import EmptySegment
+
+    class Scripted:
+        """emits 0.5 s of speech after the 2nd and 4th chunk, 0.25 s after the last"""
+        def __init__(self):
+            self.n = 0
+
+        def pushpop(self, seg):
+            self.n += 1
+            if self.n in (2, 4):
+                return SpeechSegment(content=[0.0] * 8000, sample_rate=16000, finished=False)
+            if seg.finished:
+                return SpeechSegment(content=[0.0] * 4000, sample_rate=16000, finished=True)
+            return EmptySegment()
+
+    r = SE.run_utterance(Scripted(), np.zeros(16000 * 2, np.float32), 320, sync=False)    # 2 s = 7 chunks
+    assert r["actions"] == "RWRWRRW" and r["writes"] == 3 and r["samples_out"] == 20000
+    # delays 640, 1280, 2000 ms; durations 500, 500, 250 -> intervals [640,1140] [1280,1780] [2000,2250]
+    assert abs(r["StartOffset"] - 640.0) < 1e-6 and abs(r["EndOffset"] - 250.0) < 1e-6
+    assert abs(r["RTF"] - 2250.0 / 2000.0) < 1e-9
+    assert r["RTF_CA"] >= r["RTF"] and r["StartOffset_CA"] >= r["StartOffset"]
+    # overlapping playback is serialised: two 0.5-s segments 320 ms apart
+    iv = SE._intervals([320.0, 640.0], [500.0, 500.0])
+    assert iv == [(320.0, 500.0), (820.0, 500.0)]
+    s = SE.summarize([r])
+    assert s["utterances"] == 1 and s["policy_calls"] == 7 and s["RTF"] == round(2250.0 / 2000.0, 4)
