@@ -136,7 +136,10 @@ def streaming_mode(args, model, voc, lib, cfg):
             self.hip = hv
         __call__ = CodeHiFiGANVocoderWithDur.__call__
 
-    utts = workload.make_utterances(args.utterances + 1)
+    # utterances up to 9 s: the random model's CTC heads fire more often than a trained model's (up to ~5 subwords/s), and
+    # the agent's first-pass search is capped at max_len_b = 100 subwords (agent :162-180)
+    cap_s = 9.0 if args.segment_ms < 640 else 5.0     # whole-word mode (>= 640 ms) commits one more subword per call
+    utts = [u for u in workload.make_utterances(6 * args.utterances + 8) if u.seconds <= cap_s][: args.utterances + 1]
     pcms = [synth.synth_pcm(1234 + u.idx, u.n_samples) for u in utts]
     out = {"metric": "simultaneous S2ST fr-en, wait-k agent policy() loop, batch 1 (BASELINE.json configs[2])", "mode": "streaming",
            "n_gpus": 1, "dtype": "f32", "data": "synthetic", "segment_ms": args.segment_ms,

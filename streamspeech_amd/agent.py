@@ -161,6 +161,9 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
         enc = getattr(getattr(self, "model", None), "encoder", None)
         if enc is not None and hasattr(enc, "reset_stream"):
             enc.reset_stream()                     # incremental encoder cache: one utterance at a time
+        fe = getattr(self, "feature_extractor", None)
+        if fe is not None:
+            fe.clear_cache()                       # converted sample history of the previous utterance
         try:
             self.generator_mt.reset_incremental_states()
             self.ctc_generator.reset_incremental_states()

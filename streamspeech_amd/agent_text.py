@@ -56,6 +56,9 @@ class _TextAgentBase(SpeechToTextAgent):
         enc = getattr(getattr(self, "model", None), "encoder", None)
         if enc is not None and hasattr(enc, "reset_stream"):
             enc.reset_stream()                     # incremental encoder cache: one utterance at a time
+        fe = getattr(self, "feature_extractor", None)
+        if fe is not None:
+            fe.clear_cache()                       # converted sample history of the previous utterance
 
     def _encode(self):
         feature = self.feature_extractor(self.states.source)

@@ -71,7 +71,29 @@ class OnlineFeatureExtractor:
         self.engine = engine
 
     def clear_cache(self):
-        pass
+        self._np = np.zeros(0, np.float32)
+        self._dev = None
+        self._n_dev = 0
+
+    def _samples(self, samples, n):
+        """float32 array of samples[:n].  SimulEval hands the WHOLE sample history as a Python list at every policy() call
+        (states.source only grows within an utterance); converting 15 s of floats costs ~10 ms per call, so only the new
+        tail is converted and the rest comes from the cache.  The cache is dropped when the history does not extend it
+        (new utterance / reset): length shrank, or a spot check of cached values fails."""
+        c = getattr(self, "_np", None)
+        if c is None:
+            self.clear_cache()
+            c = self._np
+        k = len(c)
+        ok = k <= n and (k == 0 or (float(samples[0]) == float(c[0]) and np.float32(samples[k - 1]) == c[k - 1]
+                                    and np.float32(samples[k // 2]) == c[k // 2]))
+        if not ok:
+            self.clear_cache()
+            c, k = self._np, 0
+        if n > k:
+            c = np.concatenate([c, np.asarray(samples[k:n], dtype=np.float32)])
+            self._np = c
+        return c[:n]
 
     def __call__(self, new_samples, sr=None):
         sr = sr or self.sample_rate
@@ -82,8 +104,21 @@ class OnlineFeatureExtractor:
             return torch.empty((0, self.feature_dim), device=self.engine.device)
         effective = int(num_frames * self.len_ms_to_samples(self.shift_size)
                         + self.len_ms_to_samples(self.window_size - self.shift_size))
-        x = np.asarray(samples[:effective], dtype=np.float32)
-        pcm = torch.from_numpy(x).to(self.engine.device)
+        x = self._samples(samples, effective)
+        # device copy of the history: only the new samples cross PCIe
+        dev = self.engine.device
+        if getattr(self, "_dev", None) is None or self._dev.numel() < effective or self._n_dev > effective:
+            cap = max(2 * effective, 1 << 16)
+            buf = torch.empty((cap,), dtype=torch.float32, device=dev)
+            if getattr(self, "_dev", None) is not None and 0 < self._n_dev <= effective:
+                buf[: self._n_dev] = self._dev[: self._n_dev]
+            else:
+                self._n_dev = 0
+            self._dev = buf
+        if effective > self._n_dev:
+            self._dev[self._n_dev:effective] = torch.from_numpy(x[self._n_dev:effective]).to(dev)
+            self._n_dev = effective
+        pcm = self._dev[:effective]
         if sr != SAMPLE_RATE:
             pcm = self.engine.resample(pcm, int(sr), SAMPLE_RATE)
         return self.engine.fbank_cmvn(pcm, 32768.0)

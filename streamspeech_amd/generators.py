@@ -93,6 +93,10 @@ class SequenceGenerator:
         else:
             max_len = start + max_new_tokens
         assert self.min_len <= max_len, "min_len cannot be larger than max_len, please adjust these!"
+        if start > max_len:
+            # the reference's step loop `for step in range(start, max_len + 1)` (agent/sequence_generator.py:340) is empty
+            # then, nothing is finalized and the agent's finalized_mt[0][0] raises IndexError: same error here
+            raise IndexError(f"prefix of {start} tokens is longer than max_len = {max_len}: no hypothesis can be finalized")
         eng = self.engine
         if hasattr(eng, "mt_greedy"):
             out, feats = eng.mt_greedy(enc.contiguous(), prefix, max_len, self.min_len)
