@@ -93,3 +93,17 @@ def test_offline_driver_on_cpu_doubles(tmp_path):
         assert hyps[sid]["mt"] == offline.detok([dicts["target_unigram"][t] for t in toks if t != cfg.eos])
     n_wav = len(list((tmp_path / "pred_wav").glob("*_pred.wav")))
     assert n_wav == sum(1 for h in hyps.values() if h["units"])
+    # The reference's own post-processing, verbatim (researches/ctc_unity/test_scripts/pred.offline-s2st.sh:31, 37, 42-44:
+    # the grep / sort / cut / sed lines that feed sacrebleu and generate_waveform_from_code.py), run over the driver's
+    # generate-<subset>.log / .txt: it must cut out exactly the files the driver wrote itself.
+    import subprocess
+    od, sp = str(tmp_path), "dev"
+    lines = {
+        "asr": f"grep '^A-' {od}/generate-{sp}.log | sort -t'-' -k2,2n | cut -f2",
+        "tgt": f"grep '^D-' {od}/generate-{sp}.log | sort -t'-' -k2,2n | cut -f2",
+        "unit": f"grep \"^D\\-\" {od}/generate-{sp}.txt | sed 's/^D-//ig' | sort -nk1 | cut -f3",
+    }
+    for ext, cmd in lines.items():
+        got = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True, check=True).stdout
+        assert got == (tmp_path / f"generate-{sp}.{ext}").read_text(), ext
+    assert (tmp_path / f"generate-{sp}.unit").read_text().splitlines() == [" ".join(str(u) for u in hyps[i]["units"]) for i in sorted(hyps)]
