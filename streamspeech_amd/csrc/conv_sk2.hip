@@ -1,30 +1,32 @@
-// Persistent stream-K implicit-GEMM Conv1d, second generation (gfx950, exact-f32 MFMA): the wide
-// (N % 128 == 0) path of launch_conv_gemm -- HiFi-GAN resblock / up-sampling convs of a packed batch at
-// C >= 128, conv_pre, the unit-decoder projections (reference fairseq/models/text_to_speech/hifigan.py:52-172,
-// SURVEY.md §8a rows a12, a15).
+// Persistent stream-K implicit-GEMM Conv1d, second generation (gfx950, exact-f32 MFMA): the N % 64 == 0 path of
+// launch_conv_gemm -- HiFi-GAN resblock / up-sampling convs of a packed batch at C >= 64, conv_pre, the unit-decoder
+// and encoder projections with enough k-steps (reference fairseq/models/text_to_speech/hifigan.py:52-172,
+// SURVEY.md §8a rows a4, a12, a15).
 //
-// What changed against conv_sk.hip (which stays for N % 128 == 64), and why (profiles/r01_sk_ablation.txt:
-// of a 281-us launch the MFMA + ds_read stream alone took 211 us, LDS-DMA issue + barrier 38 us, fix-up +
-// epilogue 32 us -- additive, because the two co-resident workgroups of a CU ran in phase):
-//   * ONE workgroup per CU, 4 waves, one per SIMD, on a 256 x 128 tile (wave tile 128 x 64 = 32 accumulator
-//     tiles): 256 MFMAs per wave between barriers instead of 128, 25 % fewer LDS-DMA pieces and ds_reads per
-//     MFMA, and nothing on a SIMD competes with its wave for issue slots.
-//   * 3-stage LDS ring (3 x 48 KB), k-step k+2 is issued while k is contracted: the DMA has two full steps
-//     (~16k cycles) to land, waits are counted (vmcnt(12) leaves the newest step in flight across the barrier),
-//     the barrier is a raw s_barrier.
-//   * the k-loop is software-pipelined inside the wave: fragments of the next half-step are read while the
-//     current half's MFMAs issue, and the one barrier per k-step sits in the MIDDLE of the second half -- the
-//     remaining 64 MFMAs cover the barrier, the DMA wait and the first ds_reads of the next stage.  The
-//     12 DMA pieces of a step are spread over the first half's MFMA groups.
+// What changed against conv_sk.hip, and why (profiles/r01_sk_ablation.txt: of a 281-us launch the MFMA + ds_read stream
+// alone took 211 us, LDS-DMA issue + barrier 38 us, fix-up + epilogue 32 us -- additive, because the two co-resident
+// workgroups of a CU ran in phase; profiles/r02_sk2_ablation*.txt for this kernel):
+//   * ONE workgroup per CU, 4 waves, one per SIMD, on a 256 x BN tile (BN = 128: wave tile 128 x 64 = 32 accumulator
+//     tiles, 256 MFMAs per wave between barriers; BN = 64: wave tile 64 x 64, 128 MFMAs): 25 % fewer LDS-DMA pieces and
+//     ds_reads per MFMA than 128 x 128 tiles, and nothing on a SIMD competes with its wave for issue slots.
+//   * 3-stage LDS ring (3 x 48 | 40 KB): k-step c + 2 is staged while c is contracted, so the DMA has two full steps
+//     (~16k cycles) to land; waits are counted (vmcnt(#pieces) leaves the newest step in flight across the barrier), the
+//     barrier is a raw s_barrier (a __syncthreads would drain the DMA queue).
+//   * the k-loop is software-pipelined inside the wave and its body is ONE basic block (no branches: the last steps of a
+//     launch stage zero fills): the fragments of the second half-step are read under the first half's MFMAs, the first
+//     fragments of the NEXT step under the second half's, and hipcc interleaves DMA pieces, ds_reads and MFMAs.
+//     (Forcing "8 MFMAs, 1 ds_read, 1 piece" groups with sched_group_barrier or sched_barrier fences was measured
+//     slower: the register allocator then slides the accumulators, ~100 v_accvgpr moves per step.)
+//   * the stager runs across part boundaries: when a workgroup finishes a tile part, the next part's first two steps
+//     are already in flight, the pipeline never drains.
 //   * stream-K hand-off as in conv_sk.hip: ranges are walked last-tile-first, so the part a workgroup has to park (the
 //     head k-steps of the last tile of its range) is done FIRST and the tile it has to finish comes LAST -- by then the
 //     lower-numbered workgroups that share it have long parked theirs.  Logical workgroup ids come from an atomic
 //     ticket, so a finisher only ever waits for workgroups that are already running (several stream-K launches on
 //     different streams may share the chip).  Partials are summed in workgroup order: deterministic.
-//   * the staging pipeline runs two k-steps ahead of the contraction straight across part boundaries: the next
-//     part's first steps are in flight while a part is finished, the pipeline never drains.
-//   * epilogue: residual loads of 8 accumulator tiles in flight at a time, every option one wave-uniform branch
-//     (a per-element switch with expf / tanhf inlined made a 115-KB kernel that thrashed the instruction cache).
+//   * epilogue: residual loads of 8 accumulator tiles in flight at a time, every option ONE wave-uniform branch around a
+//     loop, SiLU / tanh out of line (a per-element switch with expf / tanhf inlined made a 115-KB kernel whose epilogue
+//     thrashed the instruction cache and cost 25+ us per tile part).
 #include "gemm.hpp"
 
 #include <map>
@@ -36,17 +38,18 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-constexpr int K2_BM = 256, K2_BN = 128, K2_BK = 32;
-constexpr int K2_STAGE = (K2_BM + K2_BN) * K2_BK;       // floats per ring stage (48 KB)
+constexpr int K2_BM = 256, K2_BK = 32;
 constexpr int K2_SC1 = 16;                              // buffer cache policy bit: agent scope
 constexpr int K2_MAXG = 512;
 constexpr int K2_WORD0 = 16;                            // sync[K2_WORD0 + w] = flag of logical workgroup w
 [[maybe_unused]] constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
 [[maybe_unused]] constexpr int K2_NUM_RECORDS = 0x7ffffff0;
 [[maybe_unused]] constexpr unsigned K2_OOB = 0x80000000u;
+constexpr int k2_stage_floats(int BN) { return (K2_BM + BN) * K2_BK; }
+constexpr size_t k2_lds_bytes(int BN) { return 3 * (size_t)k2_stage_floats(BN) * sizeof(float) + (2 * K2_BM + 4) * sizeof(int); }
 
 struct Sk2Args {
-  float* ws;            // [G][256*128] parked partial tiles, slot = logical workgroup id
+  float* ws;            // [G][256*BN] parked partial tiles, slot = logical workgroup id
   unsigned* sync;       // [0] ticket counter, [8] time-out counter, [K2_WORD0 + w] flag of logical workgroup w
   unsigned base;        // ticket value of logical workgroup 0 of this launch
   unsigned epoch;       // flag value meaning "the partial of this launch is in place"
@@ -56,26 +59,29 @@ struct Sk2Args {
 #define K2_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // Timing-only ablation builds (tools/sk2_bench.py with SS_EXTRA_FLAGS=-DK2_ABL=<mask>; results are wrong by design):
 // 1 no LDS-DMA in the k-loop, 2 no wait + barrier in the k-loop, 4 no ds_reads in the k-loop, 8 no epilogue / hand-off,
-// 16 no MFMAs, 32 no hand-off (every part runs the epilogue), 64 no C / C2 stores, 128 no R / R2 loads, 256 no next-part
-// prefetch before the epilogue.  Never set in the product build.
+// 16 no MFMAs, 32 no hand-off (every part runs the epilogue), 64 no C / C2 stores, 128 no R / R2 loads.  Never set in
+// the product build.
 #ifndef K2_ABL
 #define K2_ABL 0
 #endif
 
-// SiLU / tanh epilogues are rare on this path (no vocoder conv uses them): out of line, so that their expf / tanhf /
-// division expansions are not inlined once per accumulator element -- 128 copies made a 115-KB kernel whose epilogue
-// thrashed the instruction cache and cost 25+ us per tile part (profiles/r02_sk2_ablation.txt).
+// SiLU / tanh epilogues are rare on this path (no vocoder conv uses them): out of line, see the header.
 __device__ __attribute__((noinline)) float k2_act_slow(float v, int act) {
   if (act == ACT_SILU) return v / (1.0f + expf(-v));
   if (act == ACT_TANH) return tanhf(v);
   return v;
 }
 
-template <bool LRELU>
+template <int BN, bool LRELU>
 __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, const Sk2Args q) {
 #if __HIP_DEVICE_COMPILE__
-  constexpr int BM = K2_BM, BN = K2_BN, BK = K2_BK, STAGE = K2_STAGE;
-  constexpr int TM = 8, TN = 4;                  // 16x16 MFMA tiles per wave (wave tile 128 x 64)
+  constexpr int BM = K2_BM, BK = K2_BK, STAGE = k2_stage_floats(BN);
+  constexpr int TN = 4, TM = BN == 128 ? 8 : 4;  // 16x16 MFMA tiles per wave: wave tile 128 x 64 (BN = 128) | 64 x 64 (BN = 64)
+  constexpr int NWP = BN / 32;                   // W pieces per wave per step (a piece = 8 rows x 128 B = one LDS-DMA instruction)
+  constexpr int PIECES = 8 + NWP;                // DMA pieces per wave per step: 64 A rows + BN / 4 W rows
+  constexpr int NFR = TM + TN;                   // b128 fragments per half-step
+  constexpr int HG = TM / 2;                     // groups of 8 MFMAs per k4 slice
+  static_assert(BN == 128 || BN == 64, "tile widths");
   extern __shared__ __attribute__((aligned(16))) float smem[];
   int* s_lo = reinterpret_cast<int*>(smem + 3 * STAGE);
   int* s_hi = s_lo + BM;
@@ -83,7 +89,8 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wrow = BN == 128 ? (wave >> 1) * 128 : wave * 64;   // first tile row / column of this wave
+  const int wcol = BN == 128 ? (wave & 1) * 64 : 0;
   const int r = lane & 15, g = lane >> 4;
   if (t == 0) s_misc[0] = (int)(atomicAdd(q.sync, 1u) - q.base);
   __syncthreads();
@@ -111,10 +118,10 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   // per-lane LDS read offsets (floats) inside a stage: 16-B chunk c of row rr sits at chunk position c ^ ((rr >> 1) & 7)
   // (the swizzle is applied to the DMA's SOURCE address; rows of a 16-row MFMA tile differ only in r)
   const int swz = (r >> 1) & 7;
-  const int rdA0 = (wm * 128 + r) * BK + ((g ^ swz) << 2);
-  const int rdA1 = (wm * 128 + r) * BK + (((4 + g) ^ swz) << 2);
-  const int rdW0 = BM * BK + (wn * 64 + r) * BK + ((g ^ swz) << 2);
-  const int rdW1 = BM * BK + (wn * 64 + r) * BK + (((4 + g) ^ swz) << 2);
+  const int rdA0 = (wrow + r) * BK + ((g ^ swz) << 2);
+  const int rdA1 = (wrow + r) * BK + (((4 + g) ^ swz) << 2);
+  const int rdW0 = BM * BK + (wcol + r) * BK + ((g ^ swz) << 2);
+  const int rdW1 = BM * BK + (wcol + r) * BK + (((4 + g) ^ swz) << 2);
   const int st_row = lane >> 3, st_pos = lane & 7;       // DMA piece = 8 rows x 8 chunks
 
   // ---- state of the part whose k-steps are being staged (registers; the k-step scalars are wave-uniform) ----
@@ -133,14 +140,14 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     return P;
   };
   int a_rin0[8], a_lo[8], a_hi[8];
-  unsigned a_off[8], w_off[4];
+  unsigned a_off[8], w_off[NWP];
   int nci = 0, ntap = 0;                 // of the next step to stage
   int soffA = 0, soffW = 0, shift = 0;
   int cur_tm = -1;
-  // Row bounds + per-lane offsets of a part.  Called when every wave is past the previous part's k-loop (two barriers
-  // inside when the row tile changes).
+  // Row bounds + per-lane offsets of a part.  Called when every wave is past the previous part's reads of them (two
+  // barriers inside when the row tile changes).
   auto stage_setup = [&](const Part& P) {
-    __syncthreads();                     // row-bound readers of the previous part / s_misc users are done
+    __syncthreads();
     if (P.tm != cur_tm) {
       cur_tm = P.tm;
       const int m = P.m0 + t;            // 256 threads, 256 rows
@@ -172,8 +179,8 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       a_off[j] = (unsigned)(((P.m0 + row) * p.lda + ((st_pos ^ ((row >> 1) & 7)) << 2)) * 4);
     }
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int nrow = wave * 32 + j * 8 + st_row;
+    for (int j = 0; j < NWP; ++j) {
+      const int nrow = wave * (BN / 4) + j * 8 + st_row;
       w_off[j] = (unsigned)(((P.n0 + nrow) * Ktot + ((st_pos ^ ((nrow >> 1) & 7)) << 2)) * 4);
     }
     // k-step s = (channel block s / taps, tap s % taps): the taps of one 32-channel block run back to back, so the
@@ -188,15 +195,15 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     soffA = (shift * p.lda + nciv) * 4;
     soffW = (tapv * p.Cin + nciv) * 4;
   };
-  auto step_advance = [&](bool adv = true) {   // branch-free: the k-loop body must stay ONE basic block (the scheduler
-    const int nt = ntap + (adv ? 1 : 0);       // interleaves DMA pieces, ds_reads and MFMAs only inside a block)
+  auto step_advance = [&](bool adv = true) {   // branch-free: the k-loop body must stay ONE basic block
+    const int nt = ntap + (adv ? 1 : 0);
     const bool wrap = nt >= p.taps;
     ntap = wrap ? 0 : nt;
     nci += wrap ? BK : 0;
   };
-  // `live` = false turns a piece into a zero fill (offset beyond the buffer range: no memory traffic): the last two
-  // steps of a part keep issuing into ring slots nobody reads any more, so the k-loop body has no branches and
-  // the wait count is the same every iteration.
+  // `live` = false turns a piece into a zero fill (offset beyond the buffer range: no memory traffic): when nothing is
+  // left to stage the k-loop keeps issuing into ring slots nobody reads any more, so its body has no branches and the
+  // wait count is the same every iteration.
   bool in_loop = false;
   auto issueA = [&](int stage, int j, bool live) {
     if ((K2_ABL & 1) && in_loop) return;
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   };
   auto issueW = [&](int stage, int j, bool live) {
     if ((K2_ABL & 1) && in_loop) return;
-    float* sW = smem + stage * STAGE + BM * BK + (wave * 32) * BK;
+    float* sW = smem + stage * STAGE + BM * BK + (wave * (BN / 4)) * BK;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sW + j * 8 * BK), 16, live ? w_off[j] : K2_OOB,
                                              __builtin_amdgcn_readfirstlane(soffW), 0, 0);
   };
@@ -217,14 +224,16 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) issueA(stage, j, live);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) issueW(stage, j, live);
+    for (int j = 0; j < NWP; ++j) issueW(stage, j, live);
     step_advance(live);
+  };
+  auto wait_newest_step_only = [&]() {   // everything but the PIECES newest VMEM operations of this wave has completed
+    if constexpr (BN == 128) K2_WAIT_VMCNT(12); else K2_WAIT_VMCNT(10);
   };
   // ---- the stager: runs two k-steps ahead of the contraction, straight across part boundaries ----
   // All k-steps of all parts of this workgroup form one sequence; step c is contracted out of ring slot c % 3 while
   // step c + 2 is staged.  When the stager finishes a part it moves on to the next one (row bounds + offsets), so at a
-  // part boundary the next part's first two steps are already in flight / landed and its first fragments are read by
-  // the last iteration of the previous part: the pipeline never drains, the epilogue is the only gap.
+  // part boundary the next part's first two steps are already in flight / landed.
   int stage_ip = 0, stage_left = 0;      // part being staged, steps of it still to stage
   auto stager_next_part = [&]() {
     const Part P = part_of(stage_ip);
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   stager_advance();
   issue_step(1, stage_left > 0);
   stage_left -= stage_left > 0 ? 1 : 0;
-  K2_WAIT_VMCNT(12);
+  wait_newest_step_only();
   __builtin_amdgcn_s_barrier();
   for (int ip = 0; ip < nparts; ++ip) {
     const Part cur = part_of(ip);
@@ -253,26 +262,21 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 #pragma unroll
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    auto loadA = [&](const float* S, int half, int i, f32x4 (&af)[TM]) {
+    auto load_frag = [&](const float* S, int half, int u, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {   // fragment u of a half-step: B 0..3, A 4..
       if ((K2_ABL & 4) && in_loop) return;
-      af[i] = *reinterpret_cast<const f32x4*>(S + (half ? rdA1 : rdA0) + i * 16 * BK);
-      if (LRELU) {
+      if (u < TN) {
+        bf[u] = *reinterpret_cast<const f32x4*>(S + (half ? rdW1 : rdW0) + u * 16 * BK);
+      } else {
+        const int i = u - TN;
+        af[i] = *reinterpret_cast<const f32x4*>(S + (half ? rdA1 : rdA0) + i * 16 * BK);
+        if (LRELU) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) af[i][e] = fmaxf(af[i][e], af[i][e] * slope);
+          for (int e = 0; e < 4; ++e) af[i][e] = fmaxf(af[i][e], af[i][e] * slope);
+        }
       }
     };
-    auto loadB = [&](const float* S, int half, int j, f32x4 (&bf)[TN]) {
-      if ((K2_ABL & 4) && in_loop) return;
-      bf[j] = *reinterpret_cast<const f32x4*>(S + (half ? rdW1 : rdW0) + j * 16 * BK);
-    };
-    auto load_frags = [&](const float* S, int half, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
-#pragma unroll
-      for (int j = 0; j < TN; ++j) loadB(S, half, j, bf);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) loadA(S, half, i, af);
-    };
     // 8 MFMAs: k4 slice e of row tiles 2q, 2q+1 against all 4 column tiles (8 independent accumulators; the same
-    // accumulator comes back 32 MFMAs later)
+    // accumulator comes back 4 * TM MFMAs later)
     auto mma8 = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int e, int qd) {
       if (K2_ABL & 16) return;
 #pragma unroll
@@ -283,92 +287,41 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     };
 
     // The part's first step landed and was made visible by the previous part's last barrier (the initial one for part 0);
-    // its first fragments are (re)read here rather than kept in registers across the epilogue (48 VGPRs the epilogue needs).
+    // its first fragments are (re)read here rather than kept in registers across the epilogue (VGPRs the epilogue needs).
     f32x4 ax[TM], bx[TN], ay[TM], by[TN];
-    load_frags(smem + st * STAGE, 0, ax, bx);
+#pragma unroll
+    for (int u = 0; u < NFR; ++u) load_frag(smem + st * STAGE, 0, u, ax, bx);
     in_loop = true;
     for (int i = 0; i < n; ++i) {
       stager_advance();
       const float* S = smem + st * STAGE;
       const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
-      const bool live = stage_left > 0;          // nothing left to stage: zero fills (the count stays 12 per step)
+      const bool live = stage_left > 0;          // nothing left to stage: zero fills (the count stays PIECES per step)
       stage_left -= live ? 1 : 0;
-      // The body is ONE basic block (no branches): DMA pieces, ds_reads and MFMAs of a step can be interleaved by the
-      // scheduler.  K2_SCHED 0 leaves the order to hipcc; 1 asks for "8 MFMAs, 1 ds_read, 1 DMA piece" groups with a
-      // sched_group_barrier pipeline (source order = requested order: a ds_read may not cross an LDS-DMA piece);
-      // 2 pins the same order with sched_barrier(0) fences.  Measured (tools/sk2_bench.py, profiles/r02_sk2_*.txt):
-      // 0 is the fastest -- 1 and 2 make the register allocator slide the accumulators (~100 v_accvgpr moves per step).
-#ifndef K2_SCHED
-#define K2_SCHED 0
-#endif
-      const float* S1 = smem + st1 * STAGE;                  // (after the last step: a slot nobody reads from again)
+      const float* S1 = smem + st1 * STAGE;      // (after the very last step: a slot nobody reads from again)
+      // ---- contract X (first half-step) and k4 slices 0-1 of Y; read Y; stage step c + 2 ----
+      // (source order: a ds_read may not be moved across an LDS-DMA piece -- both touch LDS -- so they alternate)
       step_begin();
-#if K2_SCHED == 2
 #pragma unroll
-      for (int sl = 0; sl < 16; ++sl) {
-        mma8(ax, bx, sl >> 2, sl & 3);
-        __builtin_amdgcn_sched_barrier(0);
-        if (sl < 4) loadB(S, 1, sl, by);
-        else if (sl < 12) loadA(S, 1, sl - 4, ay);
-        if (sl >= 2 && sl < 10) issueA(st2, sl - 2, live);
-        else if (sl >= 10 && sl < 14) issueW(st2, sl - 10, live);
-        __builtin_amdgcn_sched_barrier(0);
+      for (int u = 0; u < (NFR > PIECES ? NFR : PIECES); ++u) {
+        if (u < NFR) load_frag(S, 1, u, ay, by);
+        if (u < 8) issueA(st2, u, live); else if (u < PIECES) issueW(st2, u - 8, live);
       }
       step_advance(live);
 #pragma unroll
-      for (int sl = 0; sl < 8; ++sl) mma8(ay, by, sl >> 2, sl & 3);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int sl = 0; sl < 4 * HG; ++sl) mma8(ax, bx, sl / HG, sl % HG);
+#pragma unroll
+      for (int sl = 0; sl < 2 * HG; ++sl) mma8(ay, by, sl / HG, sl % HG);
+      // ---- step c + 1 landed for every wave, every wave is done with slot st - 1 and with X ----
 #if !(K2_ABL & 2)
-      K2_WAIT_VMCNT(12);
+      wait_newest_step_only();
       __builtin_amdgcn_s_barrier();
 #endif
-      __builtin_amdgcn_sched_barrier(0);
+      // ---- k4 slices 2-3 of Y; the first-half fragments of step c + 1 are read under them ----
 #pragma unroll
-      for (int sl = 0; sl < 8; ++sl) {
-        if (sl < 2) { loadB(S1, 0, 2 * sl, bx); loadB(S1, 0, 2 * sl + 1, bx); }
-        else if (sl < 6) { loadA(S1, 0, 2 * (sl - 2), ax); loadA(S1, 0, 2 * (sl - 2) + 1, ax); }
-        mma8(ay, by, 2 + (sl >> 2), sl & 3);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-#else
-      // ---- contract X (128 MFMAs) and k4 slices 0-1 of Y (64); read Y; stage step i+2 ----
+      for (int u = 0; u < NFR; ++u) load_frag(S1, 0, u, ax, bx);
 #pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        if (u < 4) loadB(S, 1, u, by); else loadA(S, 1, u - 4, ay);
-        if (u < 8) issueA(st2, u, live); else issueW(st2, u - 8, live);
-      }
-      step_advance(live);
-#pragma unroll
-      for (int sl = 0; sl < 16; ++sl) mma8(ax, bx, sl >> 2, sl & 3);
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) mma8(ay, by, sl >> 2, sl & 3);
-#if K2_SCHED == 1
-#pragma unroll
-      for (int u = 0; u < 12; ++u) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);   // MFMA
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read (a Y fragment)
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (an LDS-DMA piece)
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 96, 0);
-#endif
-      // ---- step i+1 landed for every wave, every wave is done with slot st-1 and with X ----
-#if !(K2_ABL & 2)
-      K2_WAIT_VMCNT(12);
-      __builtin_amdgcn_s_barrier();
-#endif
-      // ---- k4 slices 2-3 of Y; the first-half fragments of step i+1 are read under them ----
-      load_frags(S1, 0, ax, bx);
-#pragma unroll
-      for (int sl = 0; sl < 8; ++sl) mma8(ay, by, 2 + (sl >> 2), sl & 3);
-#if K2_SCHED == 1
-#pragma unroll
-      for (int u = 0; u < 6; ++u) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);
-      }
-      __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
-#endif
-#endif
+      for (int sl = 0; sl < 2 * HG; ++sl) mma8(ay, by, 2 + sl / HG, sl % HG);
       st = st1;
     }
     in_loop = false;
@@ -418,9 +371,9 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       __syncthreads();
       for (int ww = wf; ww < w; ++ww) {        // fixed order: ((mine + P[wf]) + P[wf+1]) + ...
         const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(q.ws + (size_t)ww * (BM * BN)), 0, BM * BN * 4, 0x00020000);
-        // a parked part comes in quarters of 8 tiles, all 8 loads of a quarter in flight before the first add
+        // a parked part comes in groups of 8 tiles, all 8 loads of a group in flight before the first add
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
+        for (int qq = 0; qq < HG; ++qq) {
           __builtin_amdgcn_sched_barrier(0);
           u32x4 o[2][TN];
 #pragma unroll
@@ -444,33 +397,32 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     // The MFMAs were issued with the operands swapped (D = W_tile . A_tile^T), so in the C/D layout
     // (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds 4 CONSECUTIVE output channels of ONE row:
     // bias / residual loads and the stores are float4.  Needs ldc/ldr/ldr2/ldc2 % 4 == 0 (checked on the host).
-    // In quarters of 8 accumulator tiles: ALL residual loads of a quarter (R and R2: up to 16 KB per wave) are issued
-    // before its first use -- with one workgroup per CU nothing else hides the memory latency, and one dependent
-    // load -> add -> store round per tile cost 30+ us per tile part.  sched_barrier(0) on both sides keeps the
-    // compiler from merging quarters (which spills).
-    if (m0 + wm * 128 >= p.M) continue;
+    // In groups of 8 accumulator tiles: ALL residual loads of a group (R and R2: up to 16 KB per wave) are issued
+    // before its first use -- with one workgroup per CU nothing else hides the memory latency.  sched_barrier(0) on
+    // both sides keeps the compiler from merging groups (which spills).
+    if (m0 + wrow >= p.M) continue;
     f32x4 bb[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       bb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bb[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wn * 64 + j * 16 + g_e * 4);
+      if (p.bias) bb[j] = *reinterpret_cast<const f32x4*>(p.bias + n0 + wcol + j * 16 + g_e * 4);
     }
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
+    for (int qq = 0; qq < HG; ++qq) {
       __builtin_amdgcn_sched_barrier(0);
       f32x4 rr[2][TN], rr2[2][TN];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int m = min(m0 + wm * 128 + (qq * 2 + i) * 16 + r_e, p.M - 1);    // clamped: rows >= M are never stored
+        const int m = min(m0 + wrow + (qq * 2 + i) * 16 + r_e, p.M - 1);    // clamped: rows >= M are never stored
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int nn = n0 + wn * 64 + j * 16 + g_e * 4;
+          const int nn = n0 + wcol + j * 16 + g_e * 4;
           if (p.R && !(K2_ABL & 128)) rr[i][j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nn);
           if (p.R2 && !(K2_ABL & 128)) rr2[i][j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + nn);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      // every option is ONE wave-uniform branch around a loop over the quarter's 32 elements (not a branch per element)
+      // every option is ONE wave-uniform branch around a loop over the group's 32 elements (not a branch per element)
       f32x4 v[2][TN];
 #pragma unroll
       for (int i = 0; i < 2; ++i)
@@ -534,11 +486,11 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int m = m0 + wm * 128 + (qq * 2 + i) * 16 + r_e;
+        const int m = m0 + wrow + (qq * 2 + i) * 16 + r_e;
         if (m >= p.M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int nn = n0 + wn * 64 + j * 16 + g_e * 4;
+          const int nn = n0 + wcol + j * 16 + g_e * 4;
           if (!(K2_ABL & 64) || v[i][j][0] == 12345.f) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + nn) = v[i][j];
           if (p.C2 && !(K2_ABL & 64)) {
             f32x4 w2;
@@ -555,23 +507,22 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-// Workspace / words / function attribute / CU count live per (device, stream): two devices in one process may both
+// Workspace / flags / function attributes / CU count live per (device, stream): two devices in one process may both
 // use the null stream, and a workspace belongs to the device it was allocated on.
 struct Sk2State {
   float* ws = nullptr;
   unsigned* sync = nullptr;
   unsigned base = 0, epoch = 0;
 };
-struct Sk2Dev { int cus = 0; bool attr[2] = {false, false}; };
+struct Sk2Dev { int cus = 0; bool attr[4] = {false, false, false, false}; };
 static std::map<std::pair<int, hipStream_t>, Sk2State> g_k2;
 static std::map<int, Sk2Dev> g_k2_dev;
 static std::mutex g_k2_mu;
 constexpr size_t K2_SYNC_BYTES = (K2_WORD0 + K2_MAXG) * sizeof(unsigned) + 256;
-constexpr size_t K2_LDS = 3 * (size_t)K2_STAGE * sizeof(float) + (2 * K2_BM + 4) * sizeof(int);
 
 bool conv_sk2_eligible(const GemmArgs& a) {
   return a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && a.Cin % K2_BK == 0 && (a.lda & 3) == 0 &&
-         a.N % K2_BN == 0 && a.M > 0 && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && (!a.R2 || (a.ldr2 & 3) == 0) &&
+         a.N % 64 == 0 && a.M > 0 && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && (!a.R2 || (a.ldr2 & 3) == 0) &&
          (!a.C2 || (a.ldc2 & 3) == 0) && ((size_t)(a.M + a.pad + 256) * a.lda + a.Cin) * 4 < 0x7ff00000ull &&
          (size_t)a.N * a.taps * a.Cin * 4 < 0x7ff00000ull &&
          (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f));
@@ -587,8 +538,10 @@ int conv_sk2_error_count() {
   return total;
 }
 
-template <bool LRELU>
+template <int BN, bool LRELU>
 static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
+  constexpr size_t kLds = k2_lds_bytes(BN);
+  constexpr int kVariant = (BN == 128 ? 0 : 2) + (LRELU ? 1 : 0);
   int dev = 0;
   SS_HIP_CHECK(hipGetDevice(&dev));
   Sk2State* st = nullptr;
@@ -601,22 +554,22 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
       if (d.cus <= 0) d.cus = 256;
       if (d.cus > K2_MAXG) d.cus = K2_MAXG;
     }
-    if (!d.attr[LRELU]) {
-      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk2_kernel<LRELU>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)K2_LDS));
-      d.attr[LRELU] = true;
+    if (!d.attr[kVariant]) {
+      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk2_kernel<BN, LRELU>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
+      d.attr[kVariant] = true;
     }
     cus = d.cus;
     st = &g_k2[std::make_pair(dev, stream)];
     if (!st->ws) {
-      SS_HIP_CHECK(hipMalloc(&st->ws, (size_t)K2_MAXG * K2_BM * K2_BN * sizeof(float)));
+      SS_HIP_CHECK(hipMalloc(&st->ws, (size_t)K2_MAXG * K2_BM * 128 * sizeof(float)));
       SS_HIP_CHECK(hipMalloc(&st->sync, K2_SYNC_BYTES));
       SS_HIP_CHECK(hipMemsetAsync(st->sync, 0, K2_SYNC_BYTES, stream));
     }
   }
   const long long nk = (long long)a.taps * (a.Cin / K2_BK);
-  const long long U = (long long)cdiv(a.M, K2_BM) * (a.N / K2_BN) * nk;
-  long long G = g_force > 0 ? g_force : cus;        // one workgroup per CU (147 KB of LDS each), all resident
+  const long long U = (long long)cdiv(a.M, K2_BM) * (a.N / BN) * nk;
+  long long G = g_force > 0 ? g_force : cus;        // one workgroup per CU (147 | 123 KB of LDS each), all resident
   if (G > cus) G = cus;
   if (G > U / 4) G = U / 4;                         // at least 4 k-steps per workgroup
   if (G > K2_MAXG) G = K2_MAXG;
@@ -629,14 +582,16 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   ProfRec rec{}; bool prof = false;
   int rc = prof_begin(a, stream, 18, rec, prof);
   if (rc != SS_OK) return rc;
-  hipLaunchKernelGGL((conv_sk2_kernel<LRELU>), dim3((unsigned)G), dim3(256), K2_LDS, stream, a, q);
+  hipLaunchKernelGGL((conv_sk2_kernel<BN, LRELU>), dim3((unsigned)G), dim3(256), kLds, stream, a, q);
   SS_LAUNCH_CHECK();
   return prof_end(stream, rec, prof);
 }
 
 int launch_conv_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   if (!conv_sk2_eligible(a)) return SS_ERR_ARG;
-  return a.in_act == ACT_LRELU ? launch_sk2<true>(a, stream, g_force) : launch_sk2<false>(a, stream, g_force);
+  const bool lr = a.in_act == ACT_LRELU;
+  if (a.N % 128 == 0) return lr ? launch_sk2<128, true>(a, stream, g_force) : launch_sk2<128, false>(a, stream, g_force);
+  return lr ? launch_sk2<64, true>(a, stream, g_force) : launch_sk2<64, false>(a, stream, g_force);
 }
 
 }  // namespace ss

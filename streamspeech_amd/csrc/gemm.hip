@@ -779,8 +779,9 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
     const bool wide = a.N % 128 == 0;
     const long long units = (long long)cdiv(a.M, 128) * (a.N / (wide ? 128 : 64)) * nk;
     static const long long min_units = getenv("SS_SK_MIN_UNITS") ? atoll(getenv("SS_SK_MIN_UNITS")) : 12 * 512;   // tuning knob
-    static const bool no_sk2 = getenv("SS_NO_SK2") && atoi(getenv("SS_NO_SK2"));   // A/B knob: first-generation kernel for the wide convs too
-    if (wide && units >= min_units && !no_sk2 && conv_sk2_eligible(a)) return launch_conv_sk2(a, stream);
+    static const bool no_sk2 = getenv("SS_NO_SK2") && atoi(getenv("SS_NO_SK2"));   // A/B knob: first-generation kernel only
+    static const int sk2_min_k64 = getenv("SS_SK2_MINK64") ? atoi(getenv("SS_SK2_MINK64")) : 192;   // N % 128 == 64: smallest taps * Cin for conv_sk2<64>
+    if (!no_sk2 && conv_sk2_eligible(a) && (wide ? units >= min_units : a.taps * a.Cin >= sk2_min_k64)) return launch_conv_sk2(a, stream);
     if (wide ? units >= min_units : a.taps * a.Cin >= 448) return launch_conv_sk(a, stream);
   }
   if (g_force_bm && a.N > 32 && k32) {   // tuning hook (tools/conv_bench.py): ks = KS*10 + PD

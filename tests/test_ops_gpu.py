@@ -257,7 +257,8 @@ def test_stream_k_conv_matches_torch(lib, M, N, Cin, taps, dil, G):
     (1000, 256, 256, 11, 5, 0), (1000, 256, 256, 11, 5, 7), (1000, 256, 256, 11, 5, 100), (1000, 256, 256, 3, 1, 8),
     (777, 128, 128, 7, 3, 3), (777, 128, 128, 7, 3, 41), (9000, 256, 128, 7, 3, 0), (9000, 256, 128, 7, 3, 71),
     (300, 1280, 512, 3, 1, 0), (257, 128, 64, 1, 1, 2), (40, 128, 32, 1, 1, 1), (20011, 128, 128, 3, 1, 0),
-    (5000, 512, 256, 3, 1, 33), (3000, 256, 2048, 1, 1, 0)])
+    (5000, 512, 256, 3, 1, 33), (3000, 256, 2048, 1, 1, 0), (5001, 64, 64, 11, 1, 0), (5001, 64, 64, 3, 5, 97),
+    (9000, 64, 128, 7, 3, 0), (700, 192, 64, 3, 1, 5)])
 def test_stream_k2_conv_matches_torch(lib, M, N, Cin, taps, dil, G):
     """Every hand-off shape of the 2nd-generation kernel: tiles split over 2..many workgroups, ranges inside one tile,
     G = 1 (no split), ragged last M tile, 1..88 k-steps per part (staging pipeline running across part boundaries,
