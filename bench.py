@@ -370,6 +370,7 @@ def main():
         raise errors[0]
 
     audio = sum(mine[i].seconds for i in timed_ids)
+    per_rank = dp.gather_per_rank(dist, wall, audio, float(K), device=dev)
     wall, audio, nutt = dp.reduce_stats(dist, wall, audio, float(K), device=dev)
 
     def read_class(c):
@@ -510,6 +511,7 @@ def main():
             "roofline": roofline,
             "roofline_second_kernel": roofline_conv,
             "process_census": census(lib),
+            "per_rank": per_rank,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, workload.make_utterances(Wn + Kpool + 1)[Wn:])

@@ -33,3 +33,16 @@ def reduce_stats(dist, wall: float, audio_s: float, n_utts: float, device="cpu")
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(mx[0]), float(t[1]), float(t[2])
+
+
+def gather_per_rank(dist, wall: float, audio_s: float, n_utts: float, device="cpu") -> List[dict]:
+    """Per-rank (wall, audio seconds, utterances) on every rank, so that load imbalance is visible in the bench line
+    (one more 3-double all-gather after the timed region; the scaling loss of this path is imbalance, not communication)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return [{"rank": 0, "wall_s": round(wall, 5), "audio_s": round(audio_s, 2), "utterances": int(n_utts)}]
+    world = dist.get_world_size()
+    t = torch.tensor([wall, audio_s, n_utts], dtype=torch.float64, device=device)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [{"rank": r, "wall_s": round(float(o[0]), 5), "audio_s": round(float(o[1]), 2), "utterances": int(o[2])}
+            for r, o in enumerate(out)]

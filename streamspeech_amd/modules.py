@@ -314,3 +314,60 @@ def vocoder_config_from_json(d: Dict) -> VocoderConfig:
         resblock_dilation_sizes=tuple(tuple(x) for x in d["resblock_dilation_sizes"]),
         dur_hidden=dp.get("var_pred_hidden_dim", 128), dur_kernel=dp.get("var_pred_kernel_size", 3),
         code_hop_size=d.get("code_hop_size", 320))
+
+
+def register_with_fairseq() -> bool:
+    """Put the HIP-backed classes into a REAL fairseq's registries (fairseq/models/__init__.py:109,161 register_model /
+    register_model_architecture; fairseq/tasks/__init__.py register_task) when fairseq is importable; the package-local
+    registries above are filled either way.  fairseq insists on its own base classes, so thin subclasses are made here:
+    the model wrapper is a BaseFairseqModel whose build_model returns the StreamSpeechModel facade, the task a
+    LegacyFairseqTask that owns the dictionaries.  Returns False when fairseq is absent or already holds the names."""
+    try:
+        from fairseq.models import BaseFairseqModel, register_model as f_register_model
+        from fairseq.models import register_model_architecture as f_register_arch
+        from fairseq.tasks import LegacyFairseqTask, register_task as f_register_task
+    except Exception:  # noqa: BLE001  (fairseq absent or not importable in this environment)
+        return False
+    try:
+        @f_register_model("streamspeech")
+        class FairseqStreamSpeechModel(BaseFairseqModel):
+            """fairseq-facing shell: ``build_model(args, task)`` hands back the HIP-backed facade, which carries the
+            attribute surface the agent and the generators touch."""
+
+            @staticmethod
+            def add_args(parser):
+                parser.add_argument("--uni-encoder", action="store_true", default=False)
+
+            @classmethod
+            def build_model(cls, args, task):
+                return StreamSpeechModel.build_model(args, task)
+
+        @f_register_arch("streamspeech", "streamspeech")
+        def _arch(args):
+            streamspeech_architecture(args)
+
+        @f_register_task("speech_to_speech_ctc")
+        class FairseqSpeechToSpeechCTCTask(LegacyFairseqTask):
+            def __init__(self, args, dicts=None):
+                super().__init__(args)
+                self.impl = SpeechToSpeechCTCTask(dicts or {"tgt": Dictionary.units(1000)})
+
+            @classmethod
+            def setup_task(cls, args, **kw):
+                return cls(args)
+
+            @property
+            def target_dictionary(self):
+                return self.impl.target_dictionary
+
+            @property
+            def multitask_tasks(self):
+                return self.impl.multitask_tasks
+
+        @f_register_model("CodeHiFiGANVocoderWithDur")
+        class FairseqCodeHiFiGANVocoderWithDur(BaseFairseqModel):
+            def __new__(cls, checkpoint_path, model_cfg=None, fp16=False, **kw):
+                return CodeHiFiGANVocoderWithDur(checkpoint_path, model_cfg, fp16, **kw)
+    except ValueError:      # "Cannot register duplicate model/task": the reference's user dir was imported first
+        return False
+    return True

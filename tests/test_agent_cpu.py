@@ -186,3 +186,72 @@ def test_streaming_eval_latency_bookkeeping():
     assert iv == [(320.0, 500.0), (820.0, 500.0)]
     s = SE.summarize([r])
     assert s["utterances"] == 1 and s["policy_calls"] == 7 and s["RTF"] == round(2250.0 / 2000.0, 4)
+
+
+def test_user_dir_registers_into_a_fairseq_registry(monkeypatch):
+    """--user-dir streamspeech_amd/fairseq_user_dir: with a fairseq present, the names the reference's user dir
+    registers (streamspeech_model.py:57,418; tasks/speech_to_speech_ctc.py:11; agent/tts/vocoder.py:30) land in ITS
+    registries.  fairseq is not importable in this image, so a stand-in with fairseq's decorator contracts (same names,
+    base-class check, duplicate refusal: fairseq/models/__init__.py:109-170, fairseq/tasks/__init__.py) is planted."""
+    import importlib
+    import sys
+    import types
+
+    class BaseFairseqModel:
+        pass
+
+    class LegacyFairseqTask:
+        def __init__(self, args):
+            self.args = args
+
+    models, archs, tasks = {}, {}, {}
+
+    def register_model(name):
+        def deco(cls):
+            if name in models:
+                raise ValueError("Cannot register duplicate model ({})".format(name))
+            if not issubclass(cls, BaseFairseqModel):
+                raise ValueError("Model ({}: {}) must extend BaseFairseqModel".format(name, cls.__name__))
+            models[name] = cls
+            return cls
+        return deco
+
+    def register_model_architecture(model_name, arch_name):
+        def deco(fn):
+            if model_name not in models:
+                raise ValueError("Cannot register model architecture for unknown model type ({})".format(model_name))
+            archs[arch_name] = fn
+            return fn
+        return deco
+
+    def register_task(name):
+        def deco(cls):
+            if name in tasks:
+                raise ValueError("Cannot register duplicate task ({})".format(name))
+            if not issubclass(cls, LegacyFairseqTask):
+                raise ValueError("Task ({}: {}) must extend FairseqTask".format(name, cls.__name__))
+            tasks[name] = cls
+            return cls
+        return deco
+
+    fs = types.ModuleType("fairseq")
+    fm = types.ModuleType("fairseq.models")
+    ft = types.ModuleType("fairseq.tasks")
+    fm.BaseFairseqModel, fm.register_model, fm.register_model_architecture = BaseFairseqModel, register_model, register_model_architecture
+    ft.LegacyFairseqTask, ft.register_task = LegacyFairseqTask, register_task
+    fs.models, fs.tasks = fm, ft
+    for k, v in (("fairseq", fs), ("fairseq.models", fm), ("fairseq.tasks", ft)):
+        monkeypatch.setitem(sys.modules, k, v)
+    sys.modules.pop("streamspeech_amd.fairseq_user_dir", None)
+    ud = importlib.import_module("streamspeech_amd.fairseq_user_dir")
+    assert ud.REGISTERED is True
+    assert set(models) == {"streamspeech", "CodeHiFiGANVocoderWithDur"} and "streamspeech" in archs and "speech_to_speech_ctc" in tasks
+    task = tasks["speech_to_speech_ctc"].setup_task(argparse.Namespace())
+    assert len(task.target_dictionary) == 1005 and task.target_dictionary.blank_index == 1004
+    ns = argparse.Namespace()
+    archs["streamspeech"](ns)
+    assert ns.enc_layers == 12 and ns.ctc_upsample == 25
+    # a second import attempt (the reference's user dir already there) is refused, not fatal
+    from streamspeech_amd.modules import register_with_fairseq
+    assert register_with_fairseq() is False
+    sys.modules.pop("streamspeech_amd.fairseq_user_dir", None)

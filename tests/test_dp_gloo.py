@@ -24,7 +24,10 @@ def _worker(rank, world, port, q):
     dist.barrier()
     wall = 1.0 + rank            # rank 1 is the straggler
     audio = sum(u.seconds for u in mine)
+    pr = dp.gather_per_rank(dist, wall, audio, float(len(mine)))
     w, a, n = dp.reduce_stats(dist, wall, audio, float(len(mine)))
+    assert [x["rank"] for x in pr] == [0, 1] and [x["wall_s"] for x in pr] == [1.0, 2.0]
+    assert abs(pr[rank]["audio_s"] - round(audio, 2)) < 1e-9 and pr[rank]["utterances"] == len(mine)
     q.put((rank, [u.idx for u in mine], w, a, n))
     dist.barrier()
     dist.destroy_process_group()
