@@ -64,6 +64,9 @@ struct Sk2Args {
 #ifndef K2_ABL
 #define K2_ABL 0
 #endif
+#ifndef K2_RPREF
+#define K2_RPREF 1      // 1: request the tile's residual operand during the part's last k-step (see the k-loop)
+#endif
 
 // SiLU / tanh epilogues are rare on this path (no vocoder conv uses them): out of line, see the header.
 __device__ __attribute__((noinline)) float k2_act_slow(float v, int act) {
@@ -291,8 +294,29 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     f32x4 ax[TM], bx[TN], ay[TM], by[TN];
 #pragma unroll
     for (int u = 0; u < NFR; ++u) load_frag(smem + st * STAGE, 0, u, ax, bx);
+#if K2_RPREF
+    // The residual operand R of the WHOLE tile (TM x TN float4 per lane) is requested at the top of the part's last
+    // k-step, so that it has landed when the epilogue starts: with one workgroup per CU nothing else hides that latency.
+    // (The loads sit in the VMEM queue between two steps' DMA pieces; the counted wait then simply covers them too.)
+    constexpr int PT = BN == 128 ? 2 : TM;                     // row tiles requested ahead (the 128-wide variant has no registers for more)
+    f32x4 rall[PT][TN];
+    const bool want_r = p.R != nullptr && cur.kb == nk;        // only the finisher of a tile needs R
+#endif
     in_loop = true;
     for (int i = 0; i < n; ++i) {
+#if K2_RPREF
+      if (i == n - 1 && want_r) {
+        int lp = lane;
+        asm volatile("" : "+v"(lp));
+#pragma unroll
+        for (int ii = 0; ii < PT; ++ii) {
+          const int m = min(m0 + wrow + ii * 16 + (lp & 15), p.M - 1);
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            rall[ii][j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + n0 + wcol + j * 16 + (lp >> 4) * 4);
+        }
+      }
+#endif
       stager_advance();
       const float* S = smem + st * STAGE;
       const int st1 = st == 2 ? 0 : st + 1, st2 = st1 == 2 ? 0 : st1 + 1;
@@ -417,7 +441,14 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int nn = n0 + wcol + j * 16 + g_e * 4;
+#if K2_RPREF
+          if (p.R && !(K2_ABL & 128)) {
+            if (qq * 2 + i < PT) rr[i][j] = rall[qq * 2 + i < PT ? qq * 2 + i : 0][j];
+            else rr[i][j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nn);
+          }
+#else
           if (p.R && !(K2_ABL & 128)) rr[i][j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nn);
+#endif
           if (p.R2 && !(K2_ABL & 128)) rr2[i][j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + nn);
         }
       }

@@ -1,0 +1,6 @@
+cd "$GRAFT_REPO_ROOT"
+mkdir -p gpurun_out/r02
+export SK2_SHAPES="stage0 k11,stage0 k3,stage1 k7,stage1 k3,stage2 k11,stage2 k7,stage2 k3,unit fc2"
+for i in 1 2; do
+timeout 900 python tools/sk2_bench.py $1 2>&1 | grep -v amdgpu.ids | grep -v "^shape"
+done | tee gpurun_out/r02/ab.txt
