@@ -359,12 +359,14 @@ def main():
     sk_err0 = int(lib.ss_debug_sk_errors())
     start_evt.wait()
     t0 = time.perf_counter()
+    t0_mono_ns = time.monotonic_ns()
     for t in threads:
         t.join()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     wall = time.perf_counter() - t0
+    t1_mono_ns = time.monotonic_ns()
     lib.ss_prof_enable(0)
     if errors:
         raise errors[0]
@@ -424,7 +426,7 @@ def main():
                 "event_bracket_time_over_wall": r["kernel_time_over_wall"], "concurrent_streams": S}
 
     roofline, roofline_conv = in_region, in_region_conv
-    if dom is not None and S > 1 and work:
+    if dom is not None and S > 1 and work and not os.environ.get("SS_BENCH_NO_REPLAY"):   # (tools/jobs/*trace*: keep the trace to the timed region)
         lib.ss_prof_reset()
         lib.ss_prof_enable((1 << dom) | ((1 << dom_conv) if dom_conv is not None else 0))
         t_rep = time.perf_counter()
@@ -512,6 +514,7 @@ def main():
             "roofline_second_kernel": roofline_conv,
             "process_census": census(lib),
             "per_rank": per_rank,
+            "timed_region_monotonic_ns": [t0_mono_ns, t1_mono_ns],   # tools/trace_gaps.py: window of a rocprofv3 kernel trace
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, workload.make_utterances(Wn + Kpool + 1)[Wn:])

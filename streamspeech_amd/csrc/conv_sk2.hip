@@ -584,6 +584,9 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
       SS_HIP_CHECK(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
       if (d.cus <= 0) d.cus = 256;
       if (d.cus > K2_MAXG) d.cus = K2_MAXG;
+      // SS_SK2_SPARE_CUS = n: leave n CUs to the other streams' small kernels (a stream-K workgroup owns its CU: 480 of
+      // the 512 registers per SIMD, 147 KB of LDS -- nothing can be co-resident with it)
+      if (const char* e = getenv("SS_SK2_SPARE_CUS")) { const int n = atoi(e); if (n > 0 && n < d.cus) d.cus -= n; }
     }
     if (!d.attr[kVariant]) {
       SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk2_kernel<BN, LRELU>),

@@ -10,8 +10,11 @@
 // C/D layout (MI355X guide §3): col = lane&15, row = (lane>>4)*4 + reg.
 #include "gemm.hpp"
 
+#include <cstdio>
 #include <cstdlib>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <type_traits>
 #include <utility>
 #include <vector>
@@ -639,6 +642,23 @@ int prof_read(int cls, double* ms_total, double* flops_total, long long* launche
 struct ProfTotals { double flops = 0, bytes = 0; long long launches = 0; };
 static ProfTotals g_prof_totals[kNumTileCfg];
 static std::mutex g_tot_mu;
+// SS_SHAPE_LOG=<path>: per-(class, N, taps, Cin, operands) launch table written at process exit (tuning aid: which
+// layers land on which kernel)
+struct ShapeTot { long launches = 0; double rows = 0, flops = 0, bytes = 0; };
+using ShapeKey = std::tuple<int, int, int, int, int>;
+static std::map<ShapeKey, ShapeTot>* g_shapes = nullptr;
+static void shape_log_dump() {
+  const char* path = getenv("SS_SHAPE_LOG");
+  FILE* f = path ? fopen(path, "w") : nullptr;
+  if (!f) return;
+  fprintf(f, "class N taps Cin operands launches mean_rows gflop_per_launch mbyte_per_launch\n");
+  for (auto& kv : *g_shapes) {
+    const ShapeTot& z = kv.second;
+    fprintf(f, "%d %d %d %d %d %ld %.0f %.3f %.2f\n", std::get<0>(kv.first), std::get<1>(kv.first), std::get<2>(kv.first),
+            std::get<3>(kv.first), std::get<4>(kv.first), z.launches, z.rows / z.launches, z.flops / z.launches * 1e-9, z.bytes / z.launches * 1e-6);
+  }
+  fclose(f);
+}
 int prof_totals(int cls, double* flops, double* bytes, long long* launches) {
   if (cls < 0 || cls >= kNumTileCfg) return SS_ERR_ARG;
   std::lock_guard<std::mutex> lk(g_tot_mu);
@@ -662,6 +682,13 @@ int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, boo
     algo_work(a, fl, by);
     std::lock_guard<std::mutex> lk(g_tot_mu);
     g_prof_totals[cls].flops += fl; g_prof_totals[cls].bytes += by; g_prof_totals[cls].launches += 1;
+    static const bool shape_log = getenv("SS_SHAPE_LOG") != nullptr;
+    if (shape_log) {
+      if (!g_shapes) { g_shapes = new std::map<ShapeKey, ShapeTot>(); atexit(shape_log_dump); }
+      const int ops = (a.R ? 1 : 0) | (a.R2 ? 2 : 0) | (a.C2 ? 4 : 0) | (a.in_act != ACT_NONE ? 8 : 0) | (a.act != ACT_NONE ? 16 : 0) | (a.glu ? 32 : 0) | (a.nseg > 0 ? 64 : 0);
+      ShapeTot& z = (*g_shapes)[ShapeKey(cls, a.N, a.taps, a.Cin, ops)];
+      z.launches += 1; z.rows += a.M; z.flops += fl; z.bytes += by;
+    }
   }
   prof = (g_prof_mask >> cls) & 1;
   if (!prof) return SS_OK;

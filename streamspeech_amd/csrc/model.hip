@@ -84,6 +84,7 @@ int ln_linear(hipStream_t s, const float* x, int M, const LN& ln, const Lin& l, 
   GemmArgs a;
   a.A = x; a.lda = K; a.W = l.w; a.bias = l.b; a.C = C; a.ldc = ldc;
   a.M = M; a.N = N; a.Cin = K; a.in_len = M; a.act = act; a.alpha = alpha; a.glu = glu;
+  a.same_rows = 1;
   if (smallm_eligible(a) && K <= 512) {
     a.ln_g = ln.g; a.ln_b = ln.b;
     return launch_conv_gemm(a, s);
