@@ -199,9 +199,6 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
     issue(ka, 0);
     for (int k = ka; k < kb; ++k) {
       const int cur = (k - ka) & 1;
-#ifdef SS_ABLATE
-      if (!(p.dbg & 8))
-#endif
       {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                   // step k landed for everyone; everyone finished reading stage cur^1
@@ -242,14 +239,8 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
         f32x4 af[TM], bf[TN];
         load_frags(0, af, bf);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef SS_ABLATE
-        if (!(p.dbg & 1))
-#endif
         if (k + 1 < kb) issue(k + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef SS_ABLATE
-        if (!(p.dbg & 2))
-#endif
         {
 #if SK_VARIANT & 4
           f32x4 af1[TM], bf1[TN];
@@ -266,13 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
         }
       }
 #else
-#ifdef SS_ABLATE
-      if (!(p.dbg & 1))
-#endif
       if (k + 1 < kb) issue(k + 1, cur ^ 1);
-#ifdef SS_ABLATE
-      if (!(p.dbg & 2))
-#endif
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         f32x4 af[TM], bf[TN];
@@ -283,10 +268,6 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
     }
 
     bool has_end = kb == nk;
-#ifdef SS_ABLATE
-    if (p.dbg & 16) { if (!has_end) continue; }
-    if (p.dbg & 32) continue;
-#endif
     if (!has_end) {
       // ---- contributor: park the partial tile, raise the flag ----
       // Partials move as sc1 (agent-scope) b128 buffer stores / loads, flags as sc1 relaxed atomics: they write through / read
@@ -308,9 +289,6 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
       if (t == 0) __hip_atomic_store(q.sync + SK_FLAG0 + w, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       continue;
     }
-#ifdef SS_ABLATE
-    if (!(p.dbg & 16))
-#endif
     if (ka > 0) {
       // ---- finisher: collect the partials of the workgroups that own k-steps [0, ka) of this tile ----
       const int wf = grp * Gg + (int)(((ut0 - ubase + 1) * Gg - 1) / U);   // workgroup (of this group) that owns the tile's first unit

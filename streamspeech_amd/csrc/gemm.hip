@@ -99,9 +99,6 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
     for (int i = 0; i < NA; ++i) {
       const int rin = a_rin0[i] + tap * p.dil;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#ifdef SS_ABLATE
-      if (!(p.dbg & 1))
-#endif
       if (valid && a_ok[i] && rin >= 0 && rin < in_len && rin < a_lim[i])
         v = *reinterpret_cast<const f32x4*>(p.A + (size_t)(in_start + rin) * p.lda + ci0 + a_c4[i]);
       ra[sl][i] = v;
@@ -109,9 +106,6 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
 #pragma unroll
     for (int i = 0; i < NW; ++i) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-#ifdef SS_ABLATE
-      if (!(p.dbg & 1))
-#endif
       if (valid && w_ok[i]) v = *reinterpret_cast<const f32x4*>(p.W + w_off[i] + (size_t)tap * p.Cin + ci0);
       rw[sl][i] = v;
     }
@@ -176,9 +170,6 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
         advance();
         const float* As = smem + cur * STAGE + (wm * WTM + r) * LDK + g * 4;
         const float* Ws = smem + cur * STAGE + BM * LDK + (wn * WTN + r) * LDK + g * 4;
-#ifdef SS_ABLATE
-        if (!(p.dbg & 2))
-#endif
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
           f32x4 af[TM], bf[TN];
@@ -194,13 +185,7 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
               for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // D = W.A^T (see epilogue)
         }
-#ifdef SS_ABLATE
-        if (!(p.dbg & 4))
-#endif
         if (it + 1 < kper) store_lds(std::integral_constant<int, (u + 1) % PD>{}, cur ^ 1);
-#ifdef SS_ABLATE
-        if (!(p.dbg & 8))
-#endif
         __syncthreads();
       }
     });
@@ -767,17 +752,9 @@ bool smallm_eligible(const GemmArgs& a) {
   return plain_linear && M <= 128 && M > 0 && a.Cin % 64 == 0 && (a.lda & 3) == 0;
 }
 
-#ifdef SS_ABLATE
-static int g_dbg = 0;
-void debug_set_ablate(int v) { g_dbg = v; }
-extern "C" int ss_debug_set_ablate(int v) { g_dbg = v; return 0; }
-#endif
 
 int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
-#ifdef SS_ABLATE
-  a.dbg = g_dbg;
-#endif
   const int M = a.nseg > 0 ? a.max_seg_out : a.M;
   if (M <= 0 || a.N <= 0) return SS_OK;
   if (a.Cin % 16 != 0 || (a.lda & 3) != 0 || a.taps < 1) return SS_ERR_ARG;
@@ -792,9 +769,6 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
     return launch_smallm<1, 4>(a, stream, 14);
   }
   if (a.ln_g) return SS_ERR_ARG;  // LayerNorm fusion exists only on the small-M path
-#ifdef SS_ABLATE
-  a.dbg = g_dbg;
-#endif
   if (g_force_bm == 1 && conv_sk_eligible(a)) return launch_conv_sk(a, stream, g_force_ks);   // tuning hook: stream-K, grid = ks (0 = auto)
   if (g_force_bm == 4 && conv_sk2_eligible(a)) return launch_conv_sk2(a, stream, g_force_ks);  // tuning hook: 2nd-generation stream-K
   // Big "same" convs / linears (packed vocoder batches, unit-decoder FFN): persistent stream-K

@@ -52,9 +52,6 @@ struct GemmArgs {
   // out_start == in_start and out_len == in_len.  Makes the launch eligible for the persistent
   // stream-K kernel (conv_sk.hip).
   int same_rows = 0;
-#ifdef SS_ABLATE
-  int dbg = 0;                // timing-only ablation switches (tools/, never in the product build)
-#endif
 };
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
