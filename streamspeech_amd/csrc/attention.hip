@@ -563,12 +563,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     if ((a.nseg == 0 && a.q0 + a.Tq != a.Tk) || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
     if (a.nseg > 0 && a.p_tmax <= 0) return SS_ERR_ARG;
     if (!g_attn_no_mfma && ((a.ldq | a.ldo) & 3) == 0 && a.k_mask_tail == 0 && !a.causal) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&attention_relpos_mfma_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRelposLds));
-        attr_set = true;
-      }
+      SS_MAX_LDS_ONCE(&attention_relpos_mfma_kernel, kRelposLds);
       hipLaunchKernelGGL(attention_relpos_mfma_kernel, dim3(cdiv(tq, MQ), a.H, gz), dim3(256), kRelposLds, stream, a);
       SS_LAUNCH_CHECK();
       return SS_OK;

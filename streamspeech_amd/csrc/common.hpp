@@ -4,6 +4,8 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <mutex>
+
 #define SS_OK 0
 #define SS_ERR_HIP 1
 #define SS_ERR_ARG 2
@@ -21,6 +23,18 @@
   } while (0)
 
 #define SS_LAUNCH_CHECK() SS_HIP_CHECK(hipGetLastError())
+
+// Raise a kernel's dynamic-LDS limit exactly once per process, from whichever host thread launches it first (bench.py
+// drives the library from 8 threads).  Wrap a template-id in parentheses: SS_MAX_LDS_ONCE((&k<A, B>), bytes).
+#define SS_MAX_LDS_ONCE(kernel, bytes)                                                                          \
+  do {                                                                                                          \
+    static std::once_flag _once;                                                                                \
+    static hipError_t _once_err = hipSuccess;                                                                   \
+    std::call_once(_once, [&] {                                                                                 \
+      _once_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+    });                                                                                                         \
+    SS_HIP_CHECK(_once_err);                                                                                    \
+  } while (0)
 
 namespace ss {
 

@@ -29,7 +29,7 @@ namespace ss {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
-constexpr int SK_SC1 = 16;            // buffer cache policy: sc1 = agent scope (writes through / reads past the per-XCD L2)
+[[maybe_unused]] constexpr int SK_SC1 = 16;            // buffer cache policy: sc1 = agent scope (writes through / reads past the per-XCD L2)
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) const void* gbl_ptr_t;
 
@@ -453,12 +453,7 @@ int conv_sk_error_count() {
 template <int BN, bool LRELU>
 static int launch_sk(const GemmArgs& a, hipStream_t stream, int g_force) {
   constexpr size_t kLds = 2 * (size_t)(SK_BM + BN) * SK_BK * sizeof(float) + (2 * SK_BM + 4) * sizeof(int);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk_kernel<BN, LRELU>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-    attr_set = true;
-  }
+  SS_MAX_LDS_ONCE((&conv_sk_kernel<BN, LRELU>), kLds);
   SkState* st = nullptr;
   int rc = sk_state(stream, &st);
   if (rc != SS_OK) return rc;

@@ -39,7 +39,7 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int K2_BM = 256, K2_BK = 32;
-constexpr int K2_SC1 = 16;                              // buffer cache policy bit: agent scope
+[[maybe_unused]] constexpr int K2_SC1 = 16;                              // buffer cache policy bit: agent scope
 constexpr int K2_MAXG = 512;
 constexpr int K2_WORD0 = 16;                            // sync[K2_WORD0 + w] = flag of logical workgroup w
 [[maybe_unused]] constexpr unsigned K2_SPIN_LIMIT = 1u << 22;

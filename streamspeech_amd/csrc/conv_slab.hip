@@ -201,7 +201,20 @@ bool conv_slab_eligible(const GemmArgs& a) {
          (a.in_act == ACT_NONE || a.in_act == ACT_LRELU);
 }
 
-static int g_slab_cus = 0;
+static int slab_cus(int& cus) {           // CU count of the current device, read once (thread-safe)
+  static std::once_flag once;
+  static int n = 0;
+  static hipError_t err = hipSuccess;
+  std::call_once(once, [&] {
+    int dev = 0;
+    err = hipGetDevice(&dev);
+    if (err == hipSuccess) err = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n <= 0) n = 256;
+  });
+  SS_HIP_CHECK(err);
+  cus = n;
+  return SS_OK;
+}
 
 template <int C, int N, bool LRELU>
 static int launch_slab_t(const GemmArgs& a, hipStream_t stream, int cls) {
@@ -210,18 +223,9 @@ static int launch_slab_t(const GemmArgs& a, hipStream_t stream, int cls) {
   const size_t lds = ((size_t)((N * (K + 4) + 255) & ~255) + (size_t)((slab_rows * (C + 4) + 255) & ~255)) * sizeof(float) +
                      (SL_MAXSEG + 2) * sizeof(int);
   if (lds > 80 * 1024) return SS_ERR_ARG;
-  static size_t attr_lds = 0;
-  if (lds > attr_lds) {
-    SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_slab_kernel<C, N, LRELU>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    attr_lds = 80 * 1024;
-  }
-  if (!g_slab_cus) {
-    int dev = 0;
-    SS_HIP_CHECK(hipGetDevice(&dev));
-    SS_HIP_CHECK(hipDeviceGetAttribute(&g_slab_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (g_slab_cus <= 0) g_slab_cus = 256;
-  }
+  SS_MAX_LDS_ONCE((&conv_slab_kernel<C, N, LRELU>), 80 * 1024);
+  int g_slab_cus = 0;
+  { int rc_cus = slab_cus(g_slab_cus); if (rc_cus != SS_OK) return rc_cus; }
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   const long long max_blocks = (long long)cdiv(a.M, SL_BM) + nseg;      // upper bound (per-segment round-up)
   const int occ = (int)std::max<size_t>(2, std::min<size_t>(6, (150 * 1024) / lds));   // resident workgroups per CU (LDS-limited)
@@ -462,18 +466,9 @@ bool conv_pair_eligible(int C, int taps, int dil, int lda, int ldc, int nseg, lo
 template <int C>
 static int launch_pair_t(const PairArgs& a, hipStream_t stream) {
   const size_t lds = conv_pair_lds(C, a.taps, a.dil);
-  static bool attr_set = false;
-  if (!attr_set) {
-    SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pair_kernel<C>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024));
-    attr_set = true;
-  }
-  if (!g_slab_cus) {
-    int dev = 0;
-    SS_HIP_CHECK(hipGetDevice(&dev));
-    SS_HIP_CHECK(hipDeviceGetAttribute(&g_slab_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (g_slab_cus <= 0) g_slab_cus = 256;
-  }
+  SS_MAX_LDS_ONCE((&conv_pair_kernel<C>), 72 * 1024);
+  int g_slab_cus = 0;
+  { int rc_cus = slab_cus(g_slab_cus); if (rc_cus != SS_OK) return rc_cus; }
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   const long long max_blocks = (long long)cdiv(a.M, SL_BM) + nseg;
   const int occ = (int)std::max<size_t>(2, std::min<size_t>(4, (150 * 1024) / lds));

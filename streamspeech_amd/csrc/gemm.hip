@@ -698,13 +698,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream, int cls) {
   constexpr size_t kLds = (size_t)KS * 2 * (BM + BN) * (BK + 8) * sizeof(float);
   static_assert(kLds <= 160 * 1024, "LDS budget");
   static_assert((size_t)(KS - 1) * BM * BN * sizeof(float) <= kLds, "reduction scratch fits the staging buffers");
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (kLds > 64 * 1024)
-      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<BM, BN, BK, WM, WN, KS, PD>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-    attr_set = true;
-  }
+  if constexpr (kLds > 64 * 1024) SS_MAX_LDS_ONCE((&conv_gemm_kernel<BM, BN, BK, WM, WN, KS, PD>), kLds);
   const int mmax = a.nseg > 0 ? a.max_seg_out : a.M;
   dim3 grid(cdiv(mmax, BM), cdiv(a.N, BN), a.nseg > 0 ? a.nseg : 1);
   ProfRec rec{}; bool prof = false;

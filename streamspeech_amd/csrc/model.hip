@@ -900,9 +900,7 @@ extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_
     RET(launch_layernorm(t2, Hd, t2, Hd, v->dur_ln2.g, v->dur_ln2.b, K, Hd, 1e-5f, s));
     RET(conv1d(s, t2, K, Hd, v->dur_proj, 1, 1, 1, logdur, ACT_NONE, 0.f, ACT_NONE, nullptr, nullptr, 0.f));
   } else if (!forced) {
-    std::vector<int> one(K, 1);
-    SS_HIP_CHECK(hipMemcpyAsync(ones, one.data(), K * sizeof(int), hipMemcpyHostToDevice, s));
-    SS_HIP_CHECK(hipStreamSynchronize(s));  // `one` must outlive the copy
+    SS_HIP_CHECK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ones), 1, K, s));   // every unit lasts one frame
     forced = ones;
   }
   RET(launch_dur_predict(logdur, forced, K, d_dur, cum, s));
