@@ -385,17 +385,22 @@ def main():
         if n == 0 or ms <= 0:
             return None
         name = lib.ss_prof_class_name(c).decode()
-        traffic = None
-        try:   # PMC pass is a separate rocprofv3 run (tools/pmc_traffic.py -> profiles/); per-launch MB with the guide's gfx950 correction
+        traffic, traffic_detail = None, None
+        try:   # PMC pass is a separate rocprofv3 run (tools/pmc_traffic.py -> profiles/); per-launch bytes with the guide's gfx950 correction
             pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE))) if PMC_FILE else {}
             kv = pm.get("classes", {}).get(name)
             if kv:
-                traffic = {"mbytes_per_launch": kv["hbm_mbytes_per_launch_corrected"], "source": f"profiles/{PMC_FILE}: " + pm.get("note", "")}
+                traffic = round(kv["hbm_mbytes_per_launch_corrected"] * 1e6)          # HBM-side bytes per launch (counters)
+                traffic_detail = {"mbytes_per_launch": kv["hbm_mbytes_per_launch_corrected"],
+                                  "algorithmic_mbytes_per_launch_of_the_pmc_run": kv.get("algo_mbytes_per_launch"),
+                                  "traffic_over_algorithmic": kv.get("traffic_over_algorithmic"),
+                                  "mfma_util_pct": kv.get("mfma_util_pct"),
+                                  "source": f"profiles/{PMC_FILE}: " + pm.get("note", "")}
         except Exception:  # noqa: BLE001
             pass
         common = {"kernel": name, "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
                   "algo_gflop_per_launch": round(fl / n / 1e9, 4), "algo_mbytes_per_launch": round(by / n / 1e6, 3),
-                  "traffic": traffic, "kernel_time_over_wall": round(ms * 1e-3 / wall, 3)}
+                  "traffic": traffic, "traffic_detail": traffic_detail, "kernel_time_over_wall": round(ms * 1e-3 / wall, 3)}
         if name.startswith("smallm"):
             # M <= 128 projections / M = 1 decode GEMVs stream their weights once: HBM-side roofline
             ach = by / (ms * 1e-3) / 1e9
