@@ -147,6 +147,11 @@ int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_blob, size_t 
                       const char* const* names, const int64_t* offsets, const int64_t* numels,
                       int n_slots, ss_vocoder** out);
 void ss_vocoder_destroy(ss_vocoder* v);
+/* Optional, OFF by default (the default path is exact f32, the reference's arithmetic).  on != 0: the C >= 64 generator
+ * convs of this handle (hifigan.py:52-172) contract with three bf16 MFMAs per k-slice on operands split into
+ * bf16(x) + bf16(x - bf16(x)) (16 significant bits), f32 accumulation -- waveform within 1e-3 RMS of the f32 path
+ * (tests/test_bf16x3_gpu.py), durations untouched (the duration predictor and every argmax stage stay f32). */
+int ss_vocoder_set_bf16x3(ss_vocoder* v, int on);
 /* d_codes [K] int32 unit ids (0..999).  dur_prediction != 0 runs the duration predictor, else every
  * unit lasts one frame; d_forced_dur (may be NULL) overrides both.  d_wav must hold
  * wav_capacity floats; *h_n_samples = 320 * sum(dur).  d_dur [K] int32.  Synchronises once

@@ -36,6 +36,9 @@ namespace ss {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+using s16x4 = __attribute__((ext_vector_type(4))) short;
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int K2_BM = 256, K2_BK = 32;
@@ -75,7 +78,26 @@ __device__ __attribute__((noinline)) float k2_act_slow(float v, int act) {
   return v;
 }
 
-template <int BN, bool LRELU>
+// Split-bf16 mode (X3, opt-in per vocoder, never the default): a fragment of 4 f32 values becomes {hi01, hi23, lo01, lo23}
+// with hi = bf16(x) (round to nearest even) and lo = bf16(x - hi), i.e. x to 16 significant bits; the k-slice of 16 is
+// then contracted by THREE v_mfma_f32_16x16x16_bf16 (W_hi.A_hi + W_hi.A_lo + W_lo.A_hi, f32 accumulate; 16 cycles each)
+// instead of FOUR v_mfma_f32_16x16x4_f32 (32 cycles each).  The lane layout of the bf16 instruction (lane (r, g) holds
+// k = 4g .. 4g+3 of row r) is exactly the layout of the f32x4 fragments, so nothing else in the kernel changes.
+__device__ __forceinline__ f32x4 k2_split_bf16(f32x4 x) {
+  const bf16x2_t h01 = __builtin_convertvector((f32x2){x[0], x[1]}, bf16x2_t);
+  const bf16x2_t h23 = __builtin_convertvector((f32x2){x[2], x[3]}, bf16x2_t);
+  const unsigned u01 = __builtin_bit_cast(unsigned, h01), u23 = __builtin_bit_cast(unsigned, h23);
+  const bf16x2_t l01 = __builtin_convertvector((f32x2){x[0] - __uint_as_float(u01 << 16), x[1] - __uint_as_float(u01 & 0xffff0000u)}, bf16x2_t);
+  const bf16x2_t l23 = __builtin_convertvector((f32x2){x[2] - __uint_as_float(u23 << 16), x[3] - __uint_as_float(u23 & 0xffff0000u)}, bf16x2_t);
+  return f32x4{__uint_as_float(u01), __uint_as_float(u23), __uint_as_float(__builtin_bit_cast(unsigned, l01)),
+               __uint_as_float(__builtin_bit_cast(unsigned, l23))};
+}
+__device__ __forceinline__ s16x4 k2_half(f32x4 v, int lo) {      // the hi (lo = 0) or lo (lo = 1) four bf16 of a split fragment
+  const unsigned long long w = (unsigned long long)__float_as_uint(v[2 * lo]) | ((unsigned long long)__float_as_uint(v[2 * lo + 1]) << 32);
+  return __builtin_bit_cast(s16x4, w);
+}
+
+template <int BN, bool LRELU, bool X3>
 __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, const Sk2Args q) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int BM = K2_BM, BK = K2_BK, STAGE = k2_stage_floats(BN);
@@ -269,6 +291,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       if ((K2_ABL & 4) && in_loop) return;
       if (u < TN) {
         bf[u] = *reinterpret_cast<const f32x4*>(S + (half ? rdW1 : rdW0) + u * 16 * BK);
+        if (X3) bf[u] = k2_split_bf16(bf[u]);
       } else {
         const int i = u - TN;
         af[i] = *reinterpret_cast<const f32x4*>(S + (half ? rdA1 : rdA0) + i * 16 * BK);
@@ -276,17 +299,23 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 #pragma unroll
           for (int e = 0; e < 4; ++e) af[i][e] = fmaxf(af[i][e], af[i][e] * slope);
         }
+        if (X3) af[i] = k2_split_bf16(af[i]);
       }
     };
     // 8 MFMAs: k4 slice e of row tiles 2q, 2q+1 against all 4 column tiles (8 independent accumulators; the same
     // accumulator comes back 4 * TM MFMAs later)
     auto mma8 = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int e, int qd) {
       if (K2_ABL & 16) return;
+      if (X3 && e == 3) return;              // split-bf16: three terms per k-slice of 16 (e = 0: hi.hi, 1: hi.lo, 2: lo.hi)
 #pragma unroll
       for (int i = 2 * qd; i < 2 * qd + 2; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // D = W.A^T: see epilogue
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (X3)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(k2_half(bf[j], e == 2), k2_half(af[i], e == 1), acc[i][j], 0, 0, 0);
+          else
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], af[i][e], acc[i][j], 0, 0, 0);   // D = W.A^T: see epilogue
+        }
     };
 
     // The part's first step landed and was made visible by the previous part's last barrier (the initial one for part 0);
@@ -545,7 +574,7 @@ struct Sk2State {
   unsigned* sync = nullptr;
   unsigned base = 0, epoch = 0;
 };
-struct Sk2Dev { int cus = 0; bool attr[4] = {false, false, false, false}; };
+struct Sk2Dev { int cus = 0; bool attr[8] = {false, false, false, false, false, false, false, false}; };
 static std::map<std::pair<int, hipStream_t>, Sk2State> g_k2;
 static std::map<int, Sk2Dev> g_k2_dev;
 static std::mutex g_k2_mu;
@@ -569,10 +598,10 @@ int conv_sk2_error_count() {
   return total;
 }
 
-template <int BN, bool LRELU>
+template <int BN, bool LRELU, bool X3>
 static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   constexpr size_t kLds = k2_lds_bytes(BN);
-  constexpr int kVariant = (BN == 128 ? 0 : 2) + (LRELU ? 1 : 0);
+  constexpr int kVariant = (BN == 128 ? 0 : 2) + (LRELU ? 1 : 0) + (X3 ? 4 : 0);
   int dev = 0;
   SS_HIP_CHECK(hipGetDevice(&dev));
   Sk2State* st = nullptr;
@@ -589,7 +618,7 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
       if (const char* e = getenv("SS_SK2_SPARE_CUS")) { const int n = atoi(e); if (n > 0 && n < d.cus) d.cus -= n; }
     }
     if (!d.attr[kVariant]) {
-      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk2_kernel<BN, LRELU>),
+      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk2_kernel<BN, LRELU, X3>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
       d.attr[kVariant] = true;
     }
@@ -614,9 +643,9 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   q.epoch = ++st->epoch;
   if (q.epoch == 0) q.epoch = ++st->epoch;          // 0 is what a fresh flag holds
   ProfRec rec{}; bool prof = false;
-  int rc = prof_begin(a, stream, 18, rec, prof);
+  int rc = prof_begin(a, stream, X3 ? 19 : 18, rec, prof);
   if (rc != SS_OK) return rc;
-  hipLaunchKernelGGL((conv_sk2_kernel<BN, LRELU>), dim3((unsigned)G), dim3(256), kLds, stream, a, q);
+  hipLaunchKernelGGL((conv_sk2_kernel<BN, LRELU, X3>), dim3((unsigned)G), dim3(256), kLds, stream, a, q);
   SS_LAUNCH_CHECK();
   return prof_end(stream, rec, prof);
 }
@@ -624,8 +653,12 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
 int launch_conv_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   if (!conv_sk2_eligible(a)) return SS_ERR_ARG;
   const bool lr = a.in_act == ACT_LRELU;
-  if (a.N % 128 == 0) return lr ? launch_sk2<128, true>(a, stream, g_force) : launch_sk2<128, false>(a, stream, g_force);
-  return lr ? launch_sk2<64, true>(a, stream, g_force) : launch_sk2<64, false>(a, stream, g_force);
+  if (a.x3) {     // opt-in split-bf16 contraction (ss_vocoder_set_bf16x3): never taken by the default f32 path
+    if (a.N % 128 == 0) return lr ? launch_sk2<128, true, true>(a, stream, g_force) : launch_sk2<128, false, true>(a, stream, g_force);
+    return lr ? launch_sk2<64, true, true>(a, stream, g_force) : launch_sk2<64, false, true>(a, stream, g_force);
+  }
+  if (a.N % 128 == 0) return lr ? launch_sk2<128, true, false>(a, stream, g_force) : launch_sk2<128, false, false>(a, stream, g_force);
+  return lr ? launch_sk2<64, true, false>(a, stream, g_force) : launch_sk2<64, false, false>(a, stream, g_force);
 }
 
 }  // namespace ss

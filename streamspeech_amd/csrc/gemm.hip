@@ -593,7 +593,7 @@ static const char* kTileNames[kNumTileCfg] = {
     "conv_gemm<16,128,16,1,4>", "conv_gemm<128,128,16,2,2>", "conv_gemm<128,64,32,2,2>", "conv_gemm<64,64,32,2,2>",
     "conv_gemm<64,64,16,2,2>", "conv_gemm<32,64,32,2,2>", "conv_gemm<32,64,16,2,2>", "conv_gemm<32,32,32,2,2>",
     "smallm_gemm<4,1>", "smallm_gemm<2,2>", "smallm_gemm<1,4>", "conv_sk<128,BN,32>",
-    "conv_slab<32>", "conv_slab<16>", "conv_sk2<256,128,32>"};
+    "conv_slab<32>", "conv_slab<16>", "conv_sk2<256,128,32>", "conv_sk2_bf16x3<256,128,32>"};
 static int g_prof_mask = 0;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
@@ -765,6 +765,7 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.ln_g) return SS_ERR_ARG;  // LayerNorm fusion exists only on the small-M path
   if (g_force_bm == 1 && conv_sk_eligible(a)) return launch_conv_sk(a, stream, g_force_ks);   // tuning hook: stream-K, grid = ks (0 = auto)
   if (g_force_bm == 4 && conv_sk2_eligible(a)) return launch_conv_sk2(a, stream, g_force_ks);  // tuning hook: 2nd-generation stream-K
+  if (g_force_bm == 5 && conv_sk2_eligible(a)) { GemmArgs b = a; b.x3 = 1; return launch_conv_sk2(b, stream, g_force_ks); }  // ... its split-bf16 variant (tests, tools/sk2_bench.py)
   // Big "same" convs / linears (packed vocoder batches, unit-decoder FFN): persistent stream-K
   // 128-wide tiles, 95-110 TFLOP/s against 75-90 for the 32x64 kernel (profiles/r01_sk_sweep.txt).
   // They need enough k-steps per workgroup to amortise the fix-up + epilogue: >= 12 at BN = 128;

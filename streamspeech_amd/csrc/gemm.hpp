@@ -52,11 +52,12 @@ struct GemmArgs {
   // out_start == in_start and out_len == in_len.  Makes the launch eligible for the persistent
   // stream-K kernel (conv_sk.hip).
   int same_rows = 0;
+  int x3 = 0;                 // 1: split-bf16 (3 x bf16 MFMA) contraction where the kernel has one (conv_sk2 only; opt-in, see ss_vocoder_set_bf16x3)
 };
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 19;
+constexpr int kNumTileCfg = 20;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises

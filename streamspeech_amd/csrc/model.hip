@@ -724,6 +724,7 @@ struct ss_vocoder {
   std::vector<ConvW> ups;
   std::vector<ConvW> rb_c1, rb_c2;  // [(stage*n_res + j)*3 + d]
   DevBuf ws, small, segs;
+  int x3 = 0;          // split-bf16 contraction of the C >= 64 generator convs (ss_vocoder_set_bf16x3); default off = exact f32
 };
 
 extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_blob, size_t blob_floats,
@@ -767,6 +768,12 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
   return SS_OK;
 }
 
+extern "C" int ss_vocoder_set_bf16x3(ss_vocoder* v, int on) {
+  if (!v) return SS_ERR_ARG;
+  v->x3 = on ? 1 : 0;
+  return SS_OK;
+}
+
 extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
   if (!v) return;
   v->ws.release(); v->small.release(); v->segs.release();
@@ -793,10 +800,11 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
                          const float* frames, int Ft, const GenBufs& b, int* out_scale, int* out_C) {
   const ss_vocoder_config& c = v->cfg;
   auto preact = [](int channels) { return channels >= 64; };
-  auto mk = [](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
+  auto mk = [v](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
     GemmArgs a;
     a.A = A; a.lda = Cin; a.W = cw.w; a.bias = cw.b; a.C = Cc; a.ldc = ldc; a.ldr = ldc; a.ldr2 = ldc; a.ldc2 = ldc;
     a.N = Cout; a.Cin = Cin; a.taps = k; a.dil = dil; a.stride = 1; a.pad = dil * (k - 1) / 2; a.same_rows = 1;
+    a.x3 = v->x3;
     return a;
   };
   int scale = 1, C = c.upsample_initial_channel;

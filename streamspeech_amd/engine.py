@@ -325,7 +325,16 @@ class HipVocoder:
         self.max_dur = 64
 
     def new_context(self) -> "HipVocoder":
-        return HipVocoder(None, self.cfg, device=str(self.device), _share=self._packed)
+        v = HipVocoder(None, self.cfg, device=str(self.device), _share=self._packed)
+        if getattr(self, "bf16x3", False):
+            v.set_bf16x3(True)
+        return v
+
+    def set_bf16x3(self, on: bool):
+        """Opt-in split-bf16 (3 bf16 MFMAs per k-slice) contraction for the C >= 64 generator convs of this handle; the
+        default (off) is exact f32, the reference's arithmetic."""
+        L.check(self.lib.ss_vocoder_set_bf16x3(self.h, int(bool(on))), "ss_vocoder_set_bf16x3")
+        self.bf16x3 = bool(on)
 
     def batch_forward(self, codes: List[List[int]], dur_prediction=True, forced_dur: Optional[List[List[int]]] = None):
         """-> (list of wav tensors (views into one packed buffer), list of dur lists)."""

@@ -54,6 +54,7 @@ SIGNATURES = {
     "ss_vocoder_create": (_i, [C.POINTER(SSVocoderConfig), _vp, C.c_size_t, C.POINTER(C.c_char_p),
                                C.POINTER(_i64), C.POINTER(_i64), _i, C.POINTER(_vp)]),
     "ss_vocoder_destroy": (None, [_vp]),
+    "ss_vocoder_set_bf16x3": (_i, [_vp, _i]),
     "ss_vocoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _vp, C.POINTER(_i64)]),
     "ss_batch_fbank_cmvn": (_i, [_vp, _vp, _i, _vp, C.POINTER(_i64), C.POINTER(C.c_int32), _f, _vp, C.POINTER(C.c_int32)]),
     "ss_batch_encoder_forward": (_i, [_vp, _vp, _i, _vp, C.POINTER(C.c_int32), _i, _i, _vp, C.POINTER(C.c_int32)]),

@@ -40,7 +40,8 @@ def run_one():
         R = torch.randn(M, N, device="cuda", generator=g)
         outs, times = {}, {}
         pad = dil * (taps - 1) // 2
-        for key, code in (("t", (32, 64, 11)), ("sk", (1, 0, 0)), ("sk2", (4, 0, 0))):
+        x3 = bool(os.environ.get("SK2_X3"))          # SK2_X3=1: the first column is the split-bf16 variant of conv_sk2 instead of the 32x64 kernel
+        for key, code in (("t", (5, 0, 0) if x3 else (32, 64, 11)), ("sk", (1, 0, 0)), ("sk2", (4, 0, 0))):
             lib.ss_debug_force_tile(*code)
             Cc = torch.empty(M, N, device="cuda")
             in_act = 3 if os.environ.get("SK2_LRELU") else 0      # leaky-ReLU on the conv input inside the k-loop
@@ -61,6 +62,8 @@ def run_one():
         lib.ss_debug_force_tile(0, 0, 0)
         gf = 2.0 * M * N * taps * Cin / 1e9
         d = float((outs["sk2"][0] - outs["t"][0]).abs().max())
+        if x3:                                          # relative RMS difference of the split-bf16 result against the f32 one
+            d = float(((outs["sk2"][0] - outs["t"][0]).double().pow(2).mean() / outs["sk2"][0].double().pow(2).mean()).sqrt())
         tf = {k: gf / (times[k] * 1e-6) / 1e3 for k in times}
         tot["sk"] += times["sk"]; tot["sk2"] += times["sk2"]
         print("%-12s %9.1f %9.1f %9.1f | %8.1f %8.1f %8.1f | %9.2e %5s" % (name, times["t"], times["sk"], times["sk2"], tf["t"], tf["sk"],
