@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     P.n0 = (tile - P.tm * tiles_n) * BN;
     return P;
   };
-  int a_rin0[8], a_lo[8], a_hi[8];
+  int a_base[8], a_len[8];              // row of piece j relative to its utterance (at tap shift 0), rows in that utterance
   unsigned a_off[8], w_off[NWP];
   int nci = 0, ntap = 0;                 // of the next step to stage
   int soffA = 0, soffW = 0, shift = 0;
@@ -199,8 +199,8 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int row = wave * 64 + j * 8 + st_row;
-      a_rin0[j] = P.m0 + row - p.pad;
-      a_lo[j] = s_lo[row]; a_hi[j] = s_hi[row];
+      a_base[j] = P.m0 + row - p.pad - s_lo[row];
+      a_len[j] = s_hi[row] - s_lo[row];             // 0 for rows outside every utterance: the range test below always fails
       a_off[j] = (unsigned)(((P.m0 + row) * p.lda + ((st_pos ^ ((row >> 1) & 7)) << 2)) * 4);
     }
 #pragma unroll
@@ -213,10 +213,12 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     nci = (P.ka / p.taps) * BK;
     ntap = P.ka - (P.ka / p.taps) * p.taps;
   };
-  auto step_begin = [&]() {              // scalars of the step about to be staged.  readfirstlane: they MUST be SGPRs --
+  int shift_l = 0;                       // tap shift for the row-range test; beyond every utterance when nothing is staged
+  auto step_begin = [&](bool live) {     // scalars of the step about to be staged.  readfirstlane: they MUST be SGPRs --
     const int tapv = __builtin_amdgcn_readfirstlane(ntap);   // a soffset the compiler keeps in a VGPR turns every DMA piece
     const int nciv = __builtin_amdgcn_readfirstlane(nci);    // into a waterfall loop (cdna_hip_programming.md T20)
     shift = tapv * p.dil;
+    shift_l = live ? shift : 0x40000000;
     soffA = (shift * p.lda + nciv) * 4;
     soffW = (tapv * p.Cin + nciv) * 4;
   };
@@ -233,8 +235,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   auto issueA = [&](int stage, int j, bool live) {
     if ((K2_ABL & 1) && in_loop) return;
     float* sA = smem + stage * STAGE + (wave * 64) * BK;
-    const int rin = a_rin0[j] + shift;
-    const bool ok = live && rin >= a_lo[j] && rin < a_hi[j];
+    const bool ok = (unsigned)(a_base[j] + shift_l) < (unsigned)a_len[j];   // one unsigned compare: row inside its utterance (and live)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + j * 8 * BK), 16, ok ? a_off[j] : K2_OOB,
                                              __builtin_amdgcn_readfirstlane(soffA), 0, 0);
   };
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
                                              __builtin_amdgcn_readfirstlane(soffW), 0, 0);
   };
   auto issue_step = [&](int stage, bool live) {
-    step_begin();
+    step_begin(live);
 #pragma unroll
     for (int j = 0; j < 8; ++j) issueA(stage, j, live);
 #pragma unroll
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       const float* S1 = smem + st1 * STAGE;      // (after the very last step: a slot nobody reads from again)
       // ---- contract X (first half-step) and k4 slices 0-1 of Y; read Y; stage step c + 2 ----
       // (source order: a ds_read may not be moved across an LDS-DMA piece -- both touch LDS -- so they alternate)
-      step_begin();
+      step_begin(live);
 #pragma unroll
       for (int u = 0; u < (NFR > PIECES ? NFR : PIECES); ++u) {
         if (u < NFR) load_frag(S, 1, u, ay, by);
