@@ -62,8 +62,8 @@ struct Sk2Args {
 #define K2_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // Timing-only ablation builds (tools/sk2_bench.py with SS_EXTRA_FLAGS=-DK2_ABL=<mask>; results are wrong by design):
 // 1 no LDS-DMA in the k-loop, 2 no wait + barrier in the k-loop, 4 no ds_reads in the k-loop, 8 no epilogue / hand-off,
-// 16 no MFMAs, 32 no hand-off (every part runs the epilogue), 64 no C / C2 stores, 128 no R / R2 loads.  Never set in
-// the product build.
+// 16 no MFMAs, 32 no hand-off (every part runs the epilogue), 64 no C / C2 stores, 128 no R / R2 loads, 256 one A piece
+// per k-step instead of eight.  Never set in the product build.
 #ifndef K2_ABL
 #define K2_ABL 0
 #endif
@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   bool in_loop = false;
   auto issueA = [&](int stage, int j, bool live) {
     if ((K2_ABL & 1) && in_loop) return;
+    if ((K2_ABL & 256) && in_loop && j > 0) return;     // timing-only: one A piece per step (what an A slab resident across the taps would issue)
     float* sA = smem + stage * STAGE + (wave * 64) * BK;
     const bool ok = (unsigned)(a_base[j] + shift_l) < (unsigned)a_len[j];   // one unsigned compare: row inside its utterance (and live)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + j * 8 * BK), 16, ok ? a_off[j] : K2_OOB,
@@ -254,7 +255,8 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     step_advance(live);
   };
   auto wait_newest_step_only = [&]() {   // everything but the PIECES newest VMEM operations of this wave has completed
-    if constexpr (BN == 128) K2_WAIT_VMCNT(12); else K2_WAIT_VMCNT(10);
+    if constexpr ((K2_ABL & 256) != 0) { if constexpr (BN == 128) K2_WAIT_VMCNT(5); else K2_WAIT_VMCNT(3); }
+    else if constexpr (BN == 128) K2_WAIT_VMCNT(12); else K2_WAIT_VMCNT(10);
   };
   // ---- the stager: runs two k-steps ahead of the contraction, straight across part boundaries ----
   // All k-steps of all parts of this workgroup form one sequence; step c is contracted out of ring slot c % 3 while
