@@ -1,4 +1,4 @@
-"""Per-kernel roofline table from a rocprofv3 kernel-stats CSV (tools/dbstats.py) and the PMC summary
+"""Per-kernel roofline table from a rocprofv3 kernel-stats CSV (rocprofv3 --stats --output-format csv, or tools/dbstats.py) and the PMC summary
 (tools/pmc_traffic.py) of the SAME command: average duration, HBM-side GB/s (corrected FETCH+WRITE bytes /
 duration) against 8 TB/s, MfmaUtil.   python tools/roofline_table.py <kernel_stats.csv> <pmc.json> > table.md"""
 import csv
@@ -11,7 +11,7 @@ print("| kernel | launches | avg µs | % of kernel time | HBM-side MB/launch | G
 print("|---|---|---|---|---|---|---|---|")
 for name, r in sorted(stats.items(), key=lambda kv: -float(kv[1]["Percentage"]))[:14]:
     p = pmc.get(name)
-    us = float(r["AverageUs"])
+    us = float(r["AverageUs"]) if "AverageUs" in r else float(r["AverageNs"]) / 1e3    # rocprofv3 kernel_stats.csv reports ns, tools/dbstats.py us
     if p:
         mb = p["hbm_mbytes_per_launch_corrected"]
         gbs = mb / us * 1e3
