@@ -139,7 +139,7 @@ def streaming_mode(args, model, voc, lib, cfg):
     # utterances up to 9 s: the random model's CTC heads fire more often than a trained model's (up to ~5 subwords/s), and
     # the agent's first-pass search is capped at max_len_b = 100 subwords (agent :162-180)
     cap_s = 9.0 if args.segment_ms < 640 else 5.0     # whole-word mode (>= 640 ms) commits one more subword per call
-    utts = [u for u in workload.make_utterances(6 * args.utterances + 8) if u.seconds <= cap_s][: args.utterances + 1]
+    utts = [u for u in workload.make_utterances(8 * args.utterances + 8) if u.seconds <= cap_s][: 2 * args.utterances + 1]
     pcms = [synth.synth_pcm(1234 + u.idx, u.n_samples) for u in utts]
     out = {"metric": "simultaneous S2ST fr-en, wait-k agent policy() loop, batch 1 (BASELINE.json configs[2])", "mode": "streaming",
            "n_gpus": 1, "dtype": "f32", "data": "synthetic", "segment_ms": args.segment_ms,
@@ -166,9 +166,18 @@ def streaming_mode(args, model, voc, lib, cfg):
         agent = StreamSpeechS2STAgent(a, model=StreamSpeechModel.from_engine(model), vocoder=VocSurface(voc))
         SE.run_utterance(agent, pcms[0], args.segment_ms)                      # warm-up utterance
         n0 = census_launches()
-        runs = [SE.run_utterance(agent, pcm, args.segment_ms) for pcm in pcms[1:]]
+        runs, skipped = [], 0
+        for pcm in pcms[1:]:
+            if len(runs) >= args.utterances:
+                break
+            try:
+                runs.append(SE.run_utterance(agent, pcm, args.segment_ms))
+            except IndexError:      # the random model kept committing subwords past the first-pass cap of 100: the reference
+                skipped += 1        # agent fails the same way (fairseq sequence_generator: no hypothesis can be finalized)
+                agent.reset()
         n1 = census_launches()
         summ = SE.summarize(runs)
+        summ["utterances_skipped_prefix_over_cap"] = skipped
         summ["gemm_class_launches_per_policy_call"] = round((n1 - n0) / max(1, summ["policy_calls"]), 1)
         summ["actions_first_utterance"] = runs[0]["actions"]
         out[name] = summ
