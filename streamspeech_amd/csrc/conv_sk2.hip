@@ -57,6 +57,7 @@ struct Sk2Args {
   unsigned base;        // ticket value of logical workgroup 0 of this launch
   unsigned epoch;       // flag value meaning "the partial of this launch is in place"
   int G;                // workgroups (<= CUs: one per CU, all resident)
+  unsigned long long* dbg;   // K2_TIMING builds only (tools/sk2_timing.py): per-workgroup phase cycle counts; nullptr otherwise
 };
 
 #define K2_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
@@ -66,6 +67,9 @@ struct Sk2Args {
 // per k-step instead of eight.  Never set in the product build.
 #ifndef K2_ABL
 #define K2_ABL 0
+#endif
+#ifndef K2_TIMING
+#define K2_TIMING 0     // 1: thread 0 of every workgroup accumulates s_memtime cycles per phase into q.dbg (diagnostic build)
 #endif
 #ifndef K2_RPREF
 #define K2_RPREF 1      // 1: request the tile's residual operand during the part's last k-step (see the k-loop)
@@ -120,6 +124,15 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   if (t == 0) s_misc[0] = (int)(atomicAdd(q.sync, 1u) - q.base);
   __syncthreads();
   const int w = __builtin_amdgcn_readfirstlane(s_misc[0]);   // logical id in order of arrival: range, workspace slot, flag
+#if K2_TIMING
+  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};            // prologue, part set-up, k-loop, hand-off, epilogue, k-steps
+  const unsigned long long t_begin = __builtin_readcyclecounter();
+  unsigned long long tk_last = t_begin;
+  auto stamp = [&](int slot) { const unsigned long long now = __builtin_readcyclecounter(); tph[slot] += now - tk_last; tk_last = now; };
+#define K2_STAMP(slot) stamp(slot)
+#else
+#define K2_STAMP(slot) do { } while (0)
+#endif
 
   const int kpt = p.Cin / BK;
   const int nk = p.taps * kpt;
@@ -171,8 +184,14 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   int cur_tm = -1;
   // Row bounds + per-lane offsets of a part.  Called when every wave is past the previous part's reads of them (two
   // barriers inside when the row tile changes).
+  // Barriers here are raw s_barriers behind an LDS-only wait: a __syncthreads() would also wait for vmcnt(0), i.e. drain
+  // the two k-steps of LDS-DMA that are in flight while the next part is being set up (1-2 us per tile part).
+  auto lds_barrier = [&]() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
   auto stage_setup = [&](const Part& P) {
-    __syncthreads();
+    lds_barrier();
     if (P.tm != cur_tm) {
       cur_tm = P.tm;
       const int m = P.m0 + t;            // 256 threads, 256 rows
@@ -194,7 +213,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
         }
       }
       s_lo[t] = lo; s_hi[t] = hi;
-      __syncthreads();
+      lds_barrier();
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -281,9 +300,13 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   stage_left -= stage_left > 0 ? 1 : 0;
   wait_newest_step_only();
   __builtin_amdgcn_s_barrier();
+  K2_STAMP(0);
   for (int ip = 0; ip < nparts; ++ip) {
     const Part cur = part_of(ip);
     const int n = cur.n, m0 = cur.m0, n0 = cur.n0;
+#if K2_TIMING
+    tph[5] += (unsigned long long)n;
+#endif
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -335,6 +358,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     const bool want_r = p.R != nullptr && cur.kb == nk;        // only the finisher of a tile needs R
 #endif
     in_loop = true;
+    K2_STAMP(1);
     for (int i = 0; i < n; ++i) {
 #if K2_RPREF
       if (i == n - 1 && want_r) {
@@ -381,6 +405,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       st = st1;
     }
     in_loop = false;
+    K2_STAMP(2);
     const bool has_begin = cur.ka == 0, has_end = cur.kb == nk;
 #if K2_ABL & 8
     if (acc[0][0][0] != 12345.f) continue;
@@ -409,6 +434,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       K2_WAIT_VMCNT(0);
       __syncthreads();
       if (t == 0) __hip_atomic_store(q.sync + K2_WORD0 + w, q.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      K2_STAMP(3);
       continue;
     }
     if (!(K2_ABL & 32) && !has_begin) {
@@ -449,6 +475,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       }
     }
 
+    K2_STAMP(3);
     // ---- epilogue (same operation order as conv_gemm_kernel / conv_sk_kernel) ----
     // The MFMAs were issued with the operands swapped (D = W_tile . A_tile^T), so in the C/D layout
     // (col = lane & 15, row = 4 * (lane >> 4) + reg) a lane holds 4 CONSECUTIVE output channels of ONE row:
@@ -565,7 +592,15 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       }
     }
     __builtin_amdgcn_sched_barrier(0);
+    K2_STAMP(4);
   }
+#if K2_TIMING
+  if (t == 0 && q.dbg) {
+    unsigned long long* d = q.dbg + (size_t)w * 8;
+    for (int i = 0; i < 6; ++i) d[i] = tph[i];
+    d[6] = t_begin; d[7] = __builtin_readcyclecounter();
+  }
+#endif
 #endif
 }
 
@@ -576,9 +611,21 @@ struct Sk2State {
   float* ws = nullptr;
   unsigned* sync = nullptr;
   unsigned base = 0, epoch = 0;
+  unsigned long long* dbg = nullptr;   // K2_TIMING builds
 };
 struct Sk2Dev { int cus = 0; bool attr[8] = {false, false, false, false, false, false, false, false}; };
 static std::map<std::pair<int, hipStream_t>, Sk2State> g_k2;
+#if K2_TIMING
+static unsigned long long* g_k2_last_dbg = nullptr;
+static int g_k2_last_G = 0;
+// diagnostic build only: phase cycle counts of the LAST conv_sk2 launch, [G][8] = prologue, part set-up, k-loop, hand-off,
+// epilogue, k-steps, t_begin, t_end (s_memtime cycles; slots are per workgroup in ticket order)
+extern "C" int ss_debug_sk2_timing(unsigned long long* h_out, int cap_wgs) {
+  if (!g_k2_last_dbg || cap_wgs < g_k2_last_G) return -1;
+  if (hipMemcpy(h_out, g_k2_last_dbg, (size_t)g_k2_last_G * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return g_k2_last_G;
+}
+#endif
 static std::map<int, Sk2Dev> g_k2_dev;
 static std::mutex g_k2_mu;
 constexpr size_t K2_SYNC_BYTES = (K2_WORD0 + K2_MAXG) * sizeof(unsigned) + 256;
@@ -641,7 +688,13 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   if (G > K2_MAXG) G = K2_MAXG;
   if (G < 1) G = 1;
   Sk2Args q;
-  q.ws = st->ws; q.sync = st->sync; q.G = (int)G;
+  q.ws = st->ws; q.sync = st->sync; q.G = (int)G; q.dbg = nullptr;
+#if K2_TIMING
+  if (!st->dbg) SS_HIP_CHECK(hipMalloc(&st->dbg, (size_t)K2_MAXG * 8 * sizeof(unsigned long long)));
+  SS_HIP_CHECK(hipMemsetAsync(st->dbg, 0, (size_t)K2_MAXG * 8 * sizeof(unsigned long long), stream));
+  q.dbg = st->dbg;
+  g_k2_last_dbg = st->dbg; g_k2_last_G = (int)G;
+#endif
   q.base = st->base; st->base += (unsigned)G;
   q.epoch = ++st->epoch;
   if (q.epoch == 0) q.epoch = ++st->epoch;          // 0 is what a fresh flag holds
