@@ -55,19 +55,13 @@ def run_utterance(model, voc, pcm, utt):
 run_batch = workload.run_batch      # the timed step; tests/test_bench_config_gpu.py checks this very function against the oracle
 
 
-def cpu_baseline(sd, vsd, cfg, vcfg, utts, budget_s=25.0):
-    """The CPU oracle (torch fp32, all host cores) on a bounded sample of the same workload."""
-    from oracle import kaldi_fbank as K
-    from oracle import streamspeech_oracle as O
-    osd, ovsd = O.SD(sd), O.SD(vsd)
-    g_mean, g_std = np.zeros(80, np.float32), np.ones(80, np.float32)
-    # torch's default (all cores) is far from the best setting for these small ops on a many-core
-    # host: probe a few thread counts on one encoder+vocoder pass and keep the fastest
+def _pick_threads(O, osd, ovsd, cfg, vcfg, probe_seconds):
+    """torch's default (all cores) is far from the best setting for these small ops on a many-core host: probe a few
+    thread counts on a short encoder + vocoder pass and keep the fastest."""
     ncores = os.cpu_count() or 1
     best_t, best_dt = torch.get_num_threads(), None
     with torch.inference_mode():
-        probe = utts[0]
-        fb0 = synth.synth_fbank(1, int(probe.seconds * 100) - 2)
+        fb0 = synth.synth_fbank(1, int(probe_seconds * 100) - 2)
         for nt in sorted({min(ncores, c) for c in (8, 16, 32, 64)}):
             torch.set_num_threads(nt)
             O.encoder_forward(osd, fb0, cfg, n_layers=2)
@@ -78,34 +72,81 @@ def cpu_baseline(sd, vsd, cfg, vcfg, utts, budget_s=25.0):
             if best_dt is None or dt < best_dt:
                 best_t, best_dt = nt, dt
     torch.set_num_threads(best_t)
-    audio, wall, n = 0.0, 0.0, 0
+    return best_t
+
+
+CPU_STAGES = ("a1_fbank_cmvn", "a2_a7_encoder", "a8_ctc_heads", "a9_a10_mt_greedy_and_features", "a11_a13_t2u_unit_decoder_ctc",
+              "a14_a15_vocoder")
+
+
+def cpu_baseline(sd, vsd, cfg, vcfg, utts, reps=5, warm=2, budget_s=30.0):
+    """The CPU oracle (torch fp32, the box's host cores) on a bounded sample of the same workload, timed as BASELINE.md
+    §3 / SURVEY.md §8d prescribe: per utterance `warm` untimed passes, then `reps` timed passes, MEDIAN per stage
+    (a1 ... a15) and end to end.  The sample is three utterances spread over the length distribution (short / median /
+    long), cut short if the budget runs out (the entry says what was measured)."""
+    from oracle import kaldi_fbank as K
+    from oracle import streamspeech_oracle as O
+    osd, ovsd = O.SD(sd), O.SD(vsd)
+    g_mean, g_std = np.zeros(80, np.float32), np.ones(80, np.float32)
+    by_len = sorted(utts[:64], key=lambda u: u.seconds)
+    sample = [by_len[len(by_len) // 8], by_len[len(by_len) // 2], by_len[(7 * len(by_len)) // 8]]
+    nthreads = _pick_threads(O, osd, ovsd, cfg, vcfg, sample[1].seconds)
+
+    def one_pass(u, pcm):
+        st = {}
+        t = time.perf_counter()
+        fb = K.global_cmvn(K.fbank(pcm * np.float32(32768.0)), g_mean, g_std)
+        t, st["a1_fbank_cmvn"] = time.perf_counter(), time.perf_counter() - t
+        enc = O.encoder_forward(osd, fb, cfg)
+        t, st["a2_a7_encoder"] = time.perf_counter(), time.perf_counter() - t
+        O.ctc_head(osd, enc, "source_unigram", cfg)
+        O.ctc_head(osd, enc, "ctc_target_unigram", cfg)
+        t, st["a8_ctc_heads"] = time.perf_counter(), time.perf_counter() - t
+        toks = O.mt_greedy(osd, enc, cfg, max_new_tokens=u.n_mt)
+        if toks[-1] == cfg.eos:
+            toks = toks[:-1]
+        feats = O.mt_decoder_features(osd, [cfg.eos] + toks, enc, cfg)
+        t, st["a9_a10_mt_greedy_and_features"] = time.perf_counter(), time.perf_counter() - t
+        logits = O.unit_decoder_logits(osd, O.t2u_encoder(osd, feats, cfg), cfg)
+        units, _ = O.unit_ctc_generate(logits, cfg)
+        units = workload.resize_units(units, u.n_units, u.idx)
+        t, st["a11_a13_t2u_unit_decoder_ctc"] = time.perf_counter(), time.perf_counter() - t
+        O.vocoder_forward(ovsd, units, vcfg, True, forced_dur=u.durations)
+        st["a14_a15_vocoder"] = time.perf_counter() - t
+        st["end_to_end"] = sum(st.values())
+        return st
+
+    t_begin = time.perf_counter()
+    audio, wall, per_utt = 0.0, 0.0, []
+    stage_tot = {k: 0.0 for k in CPU_STAGES}
     with torch.inference_mode():
-        for i, u in enumerate(utts):
+        for u in sample:
             pcm = synth.synth_pcm(1234 + u.idx, u.n_samples)
-            t0 = time.perf_counter()
-            fb = K.global_cmvn(K.fbank(pcm * np.float32(32768.0)), g_mean, g_std)
-            enc = O.encoder_forward(osd, fb, cfg)
-            O.ctc_head(osd, enc, "source_unigram", cfg)
-            O.ctc_head(osd, enc, "ctc_target_unigram", cfg)
-            toks = O.mt_greedy(osd, enc, cfg, max_new_tokens=u.n_mt)
-            if toks[-1] == cfg.eos:
-                toks = toks[:-1]
-            feats = O.mt_decoder_features(osd, [cfg.eos] + toks, enc, cfg)
-            logits = O.unit_decoder_logits(osd, O.t2u_encoder(osd, feats, cfg), cfg)
-            units, _ = O.unit_ctc_generate(logits, cfg)
-            units = workload.resize_units(units, u.n_units, u.idx)
-            O.vocoder_forward(ovsd, units, vcfg, True, forced_dur=u.durations)
-            dt = time.perf_counter() - t0
-            if i == 0:
-                continue  # warm-up utterance (thread pools, allocator)
+            n_warm = warm if time.perf_counter() - t_begin < budget_s else 0
+            for _ in range(n_warm):
+                one_pass(u, pcm)
+            runs = []
+            for r in range(reps):
+                runs.append(one_pass(u, pcm))
+                if time.perf_counter() - t_begin > budget_s and len(runs) >= 3:
+                    break
+            med = {k: float(np.median([x[k] for x in runs])) for k in runs[0]}
             audio += u.seconds
-            wall += dt
-            n += 1
-            if wall > budget_s:
+            wall += med["end_to_end"]
+            for k in CPU_STAGES:
+                stage_tot[k] += med[k]
+            per_utt.append({"seconds": round(u.seconds, 2), "warmups": n_warm, "reps": len(runs),
+                            "median_ms": round(1e3 * med["end_to_end"], 1), "rtfx": round(u.seconds / med["end_to_end"], 2)})
+            if time.perf_counter() - t_begin > budget_s:
                 break
-    return {"value": audio / wall, "unit": "x real-time (audio s / wall s)", "utterances_per_sec": n / wall,
-            "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} utterances ({audio:.1f} s of audio) of the same synthetic workload, after 1 warm-up"}
+    return {"value": round(audio / wall, 3), "unit": "x real-time (audio s / wall s)", "utterances_per_sec": round(len(per_utt) / wall, 3),
+            "cores": nthreads, "host_cpus": os.cpu_count(), "kind": "port",
+            "sample": f"{len(per_utt)} utterances of the same synthetic workload (short / median / long: "
+                      + ", ".join(f"{p['seconds']} s" for p in per_utt) + f"; {audio:.1f} s of audio), each {warm} warm-ups then "
+                      f"{reps} timed passes, median per stage and end to end",
+            "per_utterance": per_utt,
+            "stage_ms_per_audio_second": {k: round(1e3 * v / audio, 2) for k, v in stage_tot.items()},
+            "port_vs_reference_modules": "profiles/r03_cpu_port_vs_reference.json (this container, same inputs and threads)"}
 
 
 def census(lib):
@@ -121,12 +162,27 @@ def census(lib):
     return out
 
 
-def streaming_mode(args, model, voc, lib, cfg):
-    """BASELINE.json configs[2]: the drop-in SimulEval agent (streamspeech_amd/agent.py) fed 320-ms chunks of synthetic
+def _agent_args(segment_ms, **over):
+    from streamspeech_amd.agent import StreamSpeechS2STAgent
+    p = argparse.ArgumentParser()
+    StreamSpeechS2STAgent.add_args(p)
+    a = p.parse_args(["--model-path", "synthetic:0", "--data-bin", "/nonexistent", "--vocoder", "synthetic:0", "--dur-prediction",
+                      "--sample-rate", "16000"])
+    a.source_segment_size, a.device = segment_ms, "gpu"
+    for k, v in over.items():
+        setattr(a, k, v)
+    return a
+
+
+def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=None, cpu_utts=0, long_seconds=()):
+    """BASELINE.json configs[2]: the drop-in SimulEval agent (streamspeech_amd/agent.py) fed `segment_ms` chunks of synthetic
     CVSS-C-shaped utterances, one at a time -- with the incremental encoder + receptive-field vocoder tail (default)
-    and with the reference's full recompute at every policy() call.  Random weights: the READ/WRITE pattern and the
-    MT / unit lengths are whatever the random model emits (CTC heads fire on most frames, the unit decoder collapses
-    to few units), so per-call costs are indicative, not CVSS-C statistics."""
+    and with the reference's full recompute at every policy() call (agent :425-435, 686-689, 748-751).  With `cpu_sd`
+    = (sd, vsd, vcfg) the SAME agent class runs over the CPU oracle engine (oracle/engine.py: full recompute per call,
+    the reference's semantics) on the first `cpu_utts` of the same utterances: the CPU baseline of this config.
+    `long_seconds`: the incremental-state claim of SURVEY.md §8f-1 measured where it can matter -- see long_prefix_sweep.
+    Random weights: the READ/WRITE pattern and the MT / unit lengths are whatever the random model emits (CTC heads fire on
+    most frames, the unit decoder collapses to few units), so per-call costs are indicative, not CVSS-C statistics."""
     from streamspeech_amd import streaming_eval as SE
     from streamspeech_amd.agent import StreamSpeechS2STAgent
     from streamspeech_amd.modules import CodeHiFiGANVocoderWithDur, StreamSpeechModel
@@ -138,14 +194,18 @@ def streaming_mode(args, model, voc, lib, cfg):
 
     # utterances up to 9 s: the random model's CTC heads fire more often than a trained model's (up to ~5 subwords/s), and
     # the agent's first-pass search is capped at max_len_b = 100 subwords (agent :162-180)
-    cap_s = 9.0 if args.segment_ms < 640 else 5.0     # whole-word mode (>= 640 ms) commits one more subword per call
-    utts = [u for u in workload.make_utterances(8 * args.utterances + 8) if u.seconds <= cap_s][: 2 * args.utterances + 1]
+    cap_s = 9.0 if segment_ms < 640 else 5.0     # whole-word mode (>= 640 ms) commits one more subword per call
+    utts = [u for u in workload.make_utterances(8 * n_utts + 8) if u.seconds <= cap_s][: 2 * n_utts + 1]
     pcms = [synth.synth_pcm(1234 + u.idx, u.n_samples) for u in utts]
     out = {"metric": "simultaneous S2ST fr-en, wait-k agent policy() loop, batch 1 (BASELINE.json configs[2])", "mode": "streaming",
-           "n_gpus": 1, "dtype": "f32", "data": "synthetic", "segment_ms": args.segment_ms,
-           "config": {"workload": f"{args.utterances} synthetic CVSS-C-shaped utterances (LogNormal(ln 4.5 s, 0.45) clipped to [1,15] s), "
-                                  f"{args.segment_ms}-ms source segments at 16 kHz, StreamSpeechS2STAgent.policy() per segment, "
-                                  "random-init weights of the streamspeech.simultaneous.fr-en architecture"}}
+           "n_gpus": 1, "dtype": "f32", "data": "synthetic", "segment_ms": segment_ms,
+           "config": {"workload": f"{n_utts} synthetic CVSS-C-shaped utterances (LogNormal(ln 4.5 s, 0.45) clipped to [1,15] s, <= {cap_s:.0f} s kept), "
+                                  f"{segment_ms}-ms source segments at 16 kHz, StreamSpeechS2STAgent.policy() per segment, "
+                                  "random-init weights of the streamspeech.simultaneous.fr-en architecture"},
+           "scorer": "streamspeech_amd/streaming_eval.py: restatement of SimulEval's SpeechOutputInstance timing + RTF/StartOffset/EndOffset "
+                     "scorers (SimulEval itself cannot import here: yt_dlp / soundfile / textgrid absent; the reference files do not exist on the "
+                     "GPU box); pinned against the reference's RTFScorer / StartOffsetScorer / EndOffsetScorer classes loaded from "
+                     "/root/reference by tests/test_streaming_eval_cpu.py"}
 
     def census_launches():
         tot = 0
@@ -155,23 +215,18 @@ def streaming_mode(args, model, voc, lib, cfg):
             tot += n.value
         return tot
 
+    kept_ids = None
     for name, over in (("incremental", {}), ("full_recompute", {"full_recompute_encoder": True, "vocoder_context_units": 0})):
-        p = argparse.ArgumentParser()
-        StreamSpeechS2STAgent.add_args(p)
-        a = p.parse_args(["--model-path", "synthetic:0", "--data-bin", "/nonexistent", "--vocoder", "synthetic:0", "--dur-prediction",
-                          "--sample-rate", "16000"])
-        a.source_segment_size, a.device = args.segment_ms, "gpu"
-        for k, v in over.items():
-            setattr(a, k, v)
-        agent = StreamSpeechS2STAgent(a, model=StreamSpeechModel.from_engine(model), vocoder=VocSurface(voc))
-        SE.run_utterance(agent, pcms[0], args.segment_ms)                      # warm-up utterance
+        agent = StreamSpeechS2STAgent(_agent_args(segment_ms, **over), model=StreamSpeechModel.from_engine(model), vocoder=VocSurface(voc))
+        SE.run_utterance(agent, pcms[0], segment_ms)                      # warm-up utterance
         n0 = census_launches()
-        runs, skipped = [], 0
-        for pcm in pcms[1:]:
-            if len(runs) >= args.utterances:
+        runs, skipped, ids = [], 0, []
+        for j, pcm in enumerate(pcms[1:], 1):
+            if len(runs) >= n_utts:
                 break
             try:
-                runs.append(SE.run_utterance(agent, pcm, args.segment_ms))
+                runs.append(SE.run_utterance(agent, pcm, segment_ms))
+                ids.append(j)
             except IndexError:      # the random model kept committing subwords past the first-pass cap of 100: the reference
                 skipped += 1        # agent fails the same way (fairseq sequence_generator: no hypothesis can be finalized)
                 agent.reset()
@@ -181,9 +236,101 @@ def streaming_mode(args, model, voc, lib, cfg):
         summ["gemm_class_launches_per_policy_call"] = round((n1 - n0) / max(1, summ["policy_calls"]), 1)
         summ["actions_first_utterance"] = runs[0]["actions"]
         out[name] = summ
+        kept_ids = kept_ids or ids
     out["value"] = out["incremental"]["rtfx_compute"]
     out["unit"] = "x real-time (audio s / policy() compute s, one utterance at a time)"
     out["higher_is_better"] = True
+    out["incremental_speedup_over_full_recompute"] = round(out["full_recompute"]["compute_s"] / out["incremental"]["compute_s"], 3)
+
+    if cpu_sd is not None and cpu_utts > 0:
+        # the reference's per-chunk full recompute on the host cores: same agent class, oracle engine (kind "port")
+        from oracle.engine import OracleEngine, OracleVocoder
+        sd, vsd, vcfg = cpu_sd
+        a = _agent_args(segment_ms, full_recompute_encoder=True, vocoder_context_units=0)
+        agent = StreamSpeechS2STAgent(a, model=StreamSpeechModel.from_engine(OracleEngine(sd, cfg)), vocoder=OracleVocoder(vsd, vcfg))
+        runs = []
+        t_begin = time.perf_counter()
+        with torch.inference_mode():
+            for j in kept_ids[:cpu_utts]:
+                runs.append(SE.run_utterance(agent, pcms[j], segment_ms, sync=False))
+                if time.perf_counter() - t_begin > 20.0:
+                    break
+        cs = SE.summarize(runs)
+        out["cpu_baseline"] = {"value": cs["rtfx_compute"], "unit": out["unit"], "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"the first {len(runs)} of the same utterances ({cs['audio_s']} s of audio), the same agent class over the CPU "
+                                         "oracle engine with the reference's full recompute at every policy() call, one pass",
+                               "ms_per_policy_call_mean": cs["ms_per_policy_call_mean"], "ms_per_policy_call_p95": cs["ms_per_policy_call_p95"],
+                               "RTF": cs["RTF"], "RTF_CA": cs["RTF_CA"], "StartOffset_CA_ms": cs["StartOffset_CA_ms"], "EndOffset_CA_ms": cs["EndOffset_CA_ms"]}
+    if long_seconds:
+        out["long_prefix_sweep"] = long_prefix_sweep(model, voc, cfg, segment_ms, long_seconds)
+    return out
+
+
+def long_prefix_sweep(model, voc, cfg, segment_ms, seconds):
+    """SURVEY.md §8f-1 measured where it can matter: for a `d`-second source, the model-side work of every policy() call that
+    depends on the audio received so far -- fbank + encoder (+ both CTC heads) over the growing prefix, and the vocoder over the
+    growing unit sequence -- with the incremental state (ss_encoder_stream_forward: only non-final rows; vocoder: the last
+    new + receptive-field units) and as the reference's full recompute (O(n^2) over the utterance).  The agent loop itself is
+    not used here: with random weights its first-pass search overruns max_len_b = 100 on sources this long (the reference's
+    generator raises too), so the sweep drives the same entry points directly, one call per `segment_ms` of new audio."""
+    from streamspeech_amd.agent import synthesize_tail
+    from streamspeech_amd.modules import CodeHiFiGANVocoderWithDur
+
+    class VocSurface:
+        def __init__(self, hv):
+            self.hip = hv
+        __call__ = CodeHiFiGANVocoderWithDur.__call__
+
+    vs = VocSurface(voc)
+    chunk = max(1, segment_ms // 40)
+    conv_chunk = 16 if chunk >= 16 else 8
+    step = 16 * segment_ms
+    rf = voc.cfg.receptive_field_frames()
+    res = []
+    for d in seconds:
+        n = int(d * 16000)
+        pcm = torch.from_numpy(synth.synth_pcm(4242, n)).to(model.device)
+        units_all = [int(x) for x in synth.uniform(7, f"sweep_units/{d}", (int(30 * d),), 0, 1000)]   # ~30 units per source second so far (CVSS-C: ~37)
+        row = {"source_s": d, "policy_calls": -(-n // step)}
+        for mode in ("incremental", "full_recompute"):
+            for rep in range(2):                      # first pass warms shapes
+                model.encoder_stream_reset()
+                torch.cuda.synchronize()
+                t_enc = t_voc = 0.0
+                pos, k_prev = 0, 0
+                while pos < n:
+                    pos = min(n, pos + step)
+                    t0 = time.perf_counter()
+                    fb = model.fbank_cmvn(pcm[:pos])
+                    if fb.shape[0] > 0:
+                        enc = (model.encoder_stream_forward(fb, chunk, conv_chunk) if mode == "incremental"
+                               else model.encoder_forward(fb, chunk, conv_chunk))
+                        model.ctc_greedy(0, enc)
+                        model.ctc_greedy(1, enc)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    k = min(len(units_all), int(30 * pos / 16000))
+                    if k > k_prev:
+                        synthesize_tail(vs, units_all[:k], k - k_prev, True, (rf + 8) if mode == "incremental" else 0, rf)
+                        k_prev = k
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                    t_enc += t1 - t0
+                    t_voc += t2 - t1
+            row[mode] = {"encoder_side_ms_total": round(1e3 * t_enc, 2), "vocoder_side_ms_total": round(1e3 * t_voc, 2),
+                         "ms_per_call_mean": round(1e3 * (t_enc + t_voc) / row["policy_calls"], 3)}
+        fi, ff = row["incremental"], row["full_recompute"]
+        row["speedup_encoder_side"] = round(ff["encoder_side_ms_total"] / fi["encoder_side_ms_total"], 3)
+        row["speedup_vocoder_side"] = round(ff["vocoder_side_ms_total"] / fi["vocoder_side_ms_total"], 3)
+        row["speedup_total"] = round((ff["encoder_side_ms_total"] + ff["vocoder_side_ms_total"])
+                                     / (fi["encoder_side_ms_total"] + fi["vocoder_side_ms_total"]), 3)
+        res.append(row)
+    return res
+
+
+def streaming_mode(args, model, voc, lib, cfg, sd, vsd, vcfg):
+    out = streaming_measure(model, voc, lib, cfg, args.segment_ms, args.utterances,
+                            cpu_sd=None if args.no_cpu_baseline else (sd, vsd, vcfg), cpu_utts=4, long_seconds=(15, 30))
     print(json.dumps(out), flush=True)
 
 
@@ -205,6 +352,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the optional second line (same batches, split-bf16 vocoder convs)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--no-multilingual", action="store_true", help="skip the configs[4] sub-object (fr/es/de weight sets resident together)")
+    ap.add_argument("--no-streaming-line", action="store_true", help="skip the configs[2] sub-object (320-ms agent policy() loop + its CPU baseline)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak (default): --steps batches PER GPU; strong: --steps batches in TOTAL (configs[3] literally: "
+                         "steps x batch utterances / N per GPU)")
     ap.add_argument("--streams", type=int, default=8,
                     help="concurrent HIP streams per GPU (own scratch context each)")
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the single-stream latency measurement")
@@ -247,13 +399,15 @@ def main():
     voc = HipVocoder(vsd, vcfg, device=dev)
     lib = L.load()
     if args.mode == "streaming":
-        return streaming_mode(args, model, voc, lib, cfg)
+        return streaming_mode(args, model, voc, lib, cfg, sd, vsd, vcfg)
 
     Ksteps, Wsteps, Bsz = max(1, args.steps), max(0, args.warmup), max(1, args.batch)
-    K = Ksteps * Bsz                         # timed utterances per rank
-    Kpool = min(K, 2048)                     # distinct synthetic utterances per rank (cycled beyond that)
+    strong = args.scaling == "strong"
     Wn = 3                                   # single-utterance warm-ups (first-touch of every code path)
-    mine, groups = workload.bench_plan(Ksteps, Bsz, rank, world, bucket=not args.no_length_bucketing, warm=Wn)
+    mine, groups = workload.bench_plan(Ksteps, Bsz, rank, world, bucket=not args.no_length_bucketing, warm=Wn, strong=strong)
+    K = sum(len(g) for g in groups)          # timed utterances on this rank
+    steps_here = len(groups)                 # timed steps on this rank (= --steps unless --scaling strong)
+    Kpool = len(mine) - Wn                   # distinct synthetic utterances on this rank (cycled beyond 2048)
     pcms = [torch.from_numpy(synth.synth_pcm(1234 + u.idx, u.n_samples)).to(dev) for u in mine]
     timed_ids = [i for g in groups for i in g]
     torch.cuda.synchronize()
@@ -321,7 +475,7 @@ def main():
             m, v = ctxs[wi]
             with torch.cuda.stream(streams[wi]):
                 run_utterance(m, v, pcms[longest], mine[longest])   # warm this context at the largest shapes
-                if Bsz > 1:
+                if Bsz > 1 and work:
                     big = max(work, key=lambda w: w[1].numel())
                     run_batch(m, v, big[1], big[0])
                 streams[wi].synchronize()
@@ -470,40 +624,56 @@ def main():
     # bf16(x) + bf16(x - bf16(x)) (ss_vocoder_set_bf16x3; f32 accumulation, everything else -- every argmax stage, the
     # duration predictor, the narrow vocoder stages -- stays f32).  Untimed for `value`; tests/test_bf16x3_gpu.py holds
     # its parity bars (durations identical, waveform RMS <= 1e-3 vs the FP32 oracle).
+    def region_pass(pick=None):
+        """All timed batches once more over the same S streams (untimed for `value`); pick(wi, i) -> (model, vocoder)
+        context for work item i on worker wi (default: the worker's own fr-en context)."""
+        nxt, errs = [0], []
+
+        def w2(wi):
+            try:
+                torch.cuda.set_device(local_rank)
+                with torch.cuda.stream(streams[wi]):
+                    while True:
+                        with lock:
+                            i = nxt[0]
+                            nxt[0] += 1
+                        if i >= len(work):
+                            break
+                        m, v = ctxs[wi] if pick is None else pick(wi, i)
+                        run_batch(m, v, work[i][1], work[i][0])
+                    streams[wi].synchronize()
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=w2, args=(i,)) for i in range(S)]
+        torch.cuda.synchronize()
+        t_p = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t_p
+        if errs:
+            raise errs[0]
+        return dt
+
+    # What the HIP-event brackets (two classes, enabled inside the timed region so that `in_region` exists) cost the headline:
+    # the same region once more with the brackets on and off (VERDICT r2 "quantify once").
+    bracket_ab = None
+    if world == 1 and dom is not None and work and Bsz > 1:
+        mask = (1 << dom) | ((1 << dom_conv) if dom_conv is not None else 0)
+        region_pass()
+        lib.ss_prof_enable(mask)
+        on = min(region_pass(), region_pass())
+        lib.ss_prof_enable(0)
+        off = min(region_pass(), region_pass())
+        lib.ss_prof_reset()
+        bracket_ab = {"region_ms_with_event_brackets": round(1e3 * on, 2), "region_ms_without": round(1e3 * off, 2),
+                      "with_over_without": round(on / off, 4), "note": "best of two region passes each, right after the timed region"}
+
     bf16x3_line = None
     if world == 1 and Bsz > 1 and work and not args.no_bf16x3_line:
-        def region_pass():
-            nxt, errs = [0], []
-
-            def w2(wi):
-                try:
-                    torch.cuda.set_device(local_rank)
-                    m, v = ctxs[wi]
-                    with torch.cuda.stream(streams[wi]):
-                        while True:
-                            with lock:
-                                i = nxt[0]
-                                nxt[0] += 1
-                            if i >= len(work):
-                                break
-                            run_batch(m, v, work[i][1], work[i][0])
-                        streams[wi].synchronize()
-                except Exception as e:  # noqa: BLE001
-                    errs.append(e)
-
-            th = [threading.Thread(target=w2, args=(i,)) for i in range(S)]
-            torch.cuda.synchronize()
-            t_p = time.perf_counter()
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t_p
-            if errs:
-                raise errs[0]
-            return dt
-
         wav_f32 = [w.clone() for w in run_batch(model, voc, work[0][1], work[0][0])[0]]
         for _, v in ctxs:
             v.set_bf16x3(True)
@@ -522,6 +692,44 @@ def main():
                        "wav_rms_vs_f32_path": round((num / max(n_s, 1)) ** 0.5, 9), "wav_rel_rms_vs_f32_path": round((num / max(den, 1e-30)) ** 0.5, 9),
                        "note": "optional second line, NOT the headline: same timed batches and streams, best of two passes after one warm "
                                "pass; durations and unit ids are identical by construction (only the vocoder's generator convs change)"}
+
+    # BASELINE.json configs[4]: fr-en + es-en + de-en weight sets resident together (3 x (model + vocoder)), the SAME timed
+    # batches dealt round-robin over the languages inside the same S-stream region (untimed for `value`); parity of exactly
+    # this arrangement against the oracle: tests/test_multilingual_gpu.py.
+    multilingual = None
+    if world == 1 and Bsz > 1 and work and not args.no_multilingual:
+        golden = os.path.join(ROOT, "tests", "golden")
+        per_lang = {"fr": ctxs}
+        weights_mb = 4e-6 * (model.blob.numel() + voc.blob.numel())
+        for seed, lang in ((1, "es"), (2, "de")):
+            g = np.load(os.path.join(golden, f"gcmvn_{lang}-en.npz"))      # configs/{es,de}-en/gcmvn.npz of the reference
+            m = HipModel(synth.make_model_state_dict(seed, cfg), cfg, device=dev, cmvn_mean=g["mean"], cmvn_std=g["std"])
+            v = HipVocoder(synth.make_vocoder_state_dict(seed, vcfg), vcfg, device=dev)
+            weights_mb += 4e-6 * (m.blob.numel() + v.blob.numel())
+            per_lang[lang] = [(m, v)] + [(m.new_context(), v.new_context()) for _ in range(S - 1)]
+        order = ("fr", "es", "de")
+        big = max(work, key=lambda w: w[1].numel())
+        # the workload pins the MT length by max_new_tokens; a random es/de model may emit </s> earlier than the forced
+        # position, which run_batch reports -- min_len pins it (ss_batch_mt_greedy bans </s> before min_len)
+        for lang in order[1:]:
+            for wi, (m, v) in enumerate(per_lang[lang]):
+                with torch.cuda.stream(streams[wi]):
+                    run_batch(m, v, big[1], big[0])
+        torch.cuda.synchronize()
+        pick = lambda wi, i: per_lang[order[i % 3]][wi]   # noqa: E731
+        region_pass(pick)                                  # warm pass over every (language, stream) context
+        dt_ml = min(region_pass(pick), region_pass(pick))
+        dt_1 = min(region_pass(), region_pass())           # the single-language set measured the same way, same moment
+        multilingual = {"value": round(audio / dt_ml, 2), "unit": "x real-time (audio s / wall s)", "utterances_per_sec": round(nutt / dt_ml, 3),
+                        "ms_per_step": round(1e3 * dt_ml / max(1, len(work)), 3), "languages": list(order),
+                        "weights_mb": round(weights_mb, 1), "contexts": 3 * S,
+                        "single_language_same_method": {"value": round(audio / dt_1, 2), "ms_per_step": round(1e3 * dt_1 / max(1, len(work)), 3)},
+                        "multilingual_over_single": round(dt_1 / dt_ml, 4),
+                        "note": "BASELINE.json configs[4]: three weight sets (seeds 0/1/2 of the same architecture, es/de with the reference's "
+                                "gcmvn statistics) resident together, the same timed batches dealt round-robin over the languages on the same "
+                                "streams; best of two passes after one warm pass, next to the single-language set timed the same way"}
+        del per_lang["es"], per_lang["de"]
+        torch.cuda.empty_cache()
 
     # Strict configs[1] form: ONE utterance per call (the single-utterance entry points, no ragged packs),
     # 8 utterances in flight on 8 streams (untimed for `value`).
@@ -566,9 +774,10 @@ def main():
             "metric": "real-time factor (RTFx = audio seconds / wall seconds) + utterances/sec, offline S2ST fr-en",
             "value": round(audio / wall, 2), "unit": "x real-time",
             "utterances_per_sec": round(nutt / wall, 3),
-            "n_gpus": world, "steps": Ksteps, "warmup": Wsteps, "ms_per_step": round(1e3 * wall / Ksteps, 3),
-            "utterances_per_step": Bsz, "ms_per_utterance": round(1e3 * wall / K, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "n_gpus": world, "steps": Ksteps, "warmup": Wsteps, "ms_per_step": round(1e3 * wall / max(1, steps_here), 3),
+            "steps_per_gpu": steps_here,
+            "utterances_per_step": Bsz, "ms_per_utterance": round(1e3 * wall / max(1, K), 4),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "offline S2ST fr-en, B=1 semantics per utterance (ragged no-padding batches), synthetic CVSS-C-shaped utterances "
                                    "(LogNormal(ln 4.5 s, 0.45) clipped to [1,15] s, seed 1234), full "
                                    "fbank+encoder+CTC+AR-MT+T2U+NAR-unit+vocoder HIP path, random-init weights "
@@ -585,6 +794,8 @@ def main():
             "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),   # must be 0 (bounded waits of the stream-K fix-up); also asserted for the timed region
             "roofline": roofline,
             "bf16x3": bf16x3_line,
+            "multilingual": multilingual,
+            "event_bracket_perturbation": bracket_ab,
             "roofline_second_kernel": roofline_conv,
             "process_census": census(lib),
             "per_rank": per_rank,
@@ -594,6 +805,16 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, workload.make_utterances(Wn + Kpool + 1)[Wn:])
         else:
             out["cpu_baseline"] = None
+        if world == 1 and not args.no_streaming_line:
+            # BASELINE.json configs[2] inside the driver's line: the agent's policy() loop on 320-ms segments (incremental state
+            # and the reference's full recompute), its CPU baseline on the same utterances, and the long-source sweep
+            st = streaming_measure(model, voc, lib, cfg, 320, args.utterances, cpu_sd=None if args.no_cpu_baseline else (sd, vsd, vcfg),
+                                   cpu_utts=3, long_seconds=(15, 30))
+            for k in ("metric", "mode", "n_gpus", "dtype", "data", "higher_is_better"):
+                st.pop(k, None)
+            out["streaming_320ms"] = st
+        else:
+            out["streaming_320ms"] = None
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -83,20 +83,32 @@ def run_batch(model, voc, pcm_packed, utts, detail: bool = False):
 
 
 def bench_plan(steps: int, batch: int, rank: int = 0, world: int = 1, bucket: bool = True, warm: int = 3,
-               pool_cap: int = 2048):
+               pool_cap: int = 2048, strong: bool = False):
     """The utterance set and ragged-batch grouping of `bench.py --steps steps --batch batch` on one rank.
     -> (mine, groups): `mine` = this rank's utterances (the `warm` single-utterance warm-ups first), `groups`
-    = the timed steps as lists of indices into `mine`, in dispatch order.  Weak scaling: every rank gets the same
-    number of utterances; the pool is length-sorted before the round-robin deal so audio seconds
-    balance too.  Like fairseq-generate (dataset.ordered_indices() sorts by source length before batch_by_size)
-    batches are formed from length-sorted utterances, longest first (LPT over the concurrent streams)."""
+    = the timed steps as lists of indices into `mine`, in dispatch order.  Weak scaling (default): every rank gets
+    `steps` batches; strong scaling (BASELINE.json configs[3] read literally: ONE set of steps x batch utterances
+    split over the ranks): the set is dealt round-robin, so a rank times ~steps / world batches.  Either way the pool
+    is length-sorted before the deal so audio seconds balance too.  Like fairseq-generate
+    (dataset.ordered_indices() sorts by source length before batch_by_size) batches are formed from length-sorted
+    utterances, longest first (LPT over the concurrent streams)."""
     K = steps * batch
-    pool = min(K, pool_cap)
-    all_utts = make_utterances((pool + warm) * world)
-    warm_all, timed_all = all_utts[:warm * world], all_utts[warm * world:]
-    timed_all = sorted(timed_all, key=lambda u: -u.seconds)
-    mine = shard(warm_all, rank, world) + shard(timed_all, rank, world)
-    ids = [warm + (i % pool) for i in range(K)]
+    if strong:
+        pool_total = min(K, pool_cap * world)
+        timed_all = make_utterances(pool_total)               # the SAME set whatever the world size
+        warm_all = make_utterances(warm * world, seed=4321)
+        timed_all = sorted(timed_all, key=lambda u: -u.seconds)
+        share = shard(timed_all, rank, world)
+        mine = shard(warm_all, rank, world) + share
+        n_mine = len(range(rank, K, world))          # this rank's part of the K timed utterances
+        ids = [warm + (i % max(1, len(share))) for i in range(n_mine)] if share else []
+    else:
+        pool = min(K, pool_cap)
+        all_utts = make_utterances((pool + warm) * world)
+        warm_all, timed_all = all_utts[:warm * world], all_utts[warm * world:]
+        timed_all = sorted(timed_all, key=lambda u: -u.seconds)
+        mine = shard(warm_all, rank, world) + shard(timed_all, rank, world)
+        ids = [warm + (i % pool) for i in range(K)]
     if batch > 1 and bucket:
         ids = sorted(ids, key=lambda i: -mine[i].n_samples)
     groups = [ids[g0:g0 + batch] for g0 in range(0, len(ids), batch)]

@@ -59,3 +59,28 @@ def test_balanced_shards():
     assert sorted(i for s in sh for i in s) == list(range(64))
     loads = [sum(durs[i] for i in s) for s in sh]
     assert max(loads) / min(loads) < 1.15
+
+
+def test_strong_scaling_plan_partitions_one_fixed_set():
+    """bench.py --scaling strong (BASELINE.json configs[3] literally: ONE 1024-utterance set split over the GPUs):
+    the ranks' timed utterances partition the N = 1 set, audio seconds balance, and the weak plan is unchanged."""
+    steps, batch = 32, 32
+    one, g1 = workload.bench_plan(steps, batch, 0, 1, strong=True)
+    ref = sorted((one[i].idx, one[i].n_samples) for g in g1 for i in g)
+    assert len(ref) == steps * batch and len(g1) == steps
+    for world in (2, 4, 8):
+        seen, audio = [], []
+        for r in range(world):
+            mine, groups = workload.bench_plan(steps, batch, r, world, strong=True)
+            assert len(groups) == steps // world and all(len(g) == batch for g in groups)
+            ids = [(mine[i].idx, mine[i].n_samples) for g in groups for i in g]
+            seen += ids
+            audio.append(sum(mine[i].seconds for g in groups for i in g))
+            for g in groups:        # length-bucketed: batches hold neighbours of the sorted order
+                secs = [mine[i].seconds for i in g]
+                assert secs == sorted(secs, reverse=True)
+        assert sorted(seen) == ref                                              # a partition of the very set N = 1 runs
+        assert max(audio) / min(audio) < 1.02
+    # fewer steps than ranks: the 64 utterances still split 8 ways (one short batch per rank)
+    assert sum(len(workload.bench_plan(2, 32, r, 8, strong=True)[1]) for r in range(8)) == 8 and \
+        all(len(g) == 8 for r in range(8) for g in workload.bench_plan(2, 32, r, 8, strong=True)[1])
