@@ -73,6 +73,14 @@ int ss_fbank_cmvn(ss_model* m, void* stream, const float* d_pcm16k, int n_sample
 int ss_resample(void* stream, const float* d_in, int64_t n_in, int up, int down, const float* d_taps,
                 int half_len, float* d_out, int64_t n_out);
 
+/* Offline driver only: d_out[r] = max over the vocabulary, ids mask0..2 skipped (< 0: none), of
+ * log_softmax(d_logits[r, :]) -- the per-position score `lprobs.max(dim=2)` of the reference's offline unit search
+ * (researches/ctc_unity/ctc_generator.py:55-63: pad / unk / eos set to -inf AFTER the softmax), which fairseq-generate
+ * prints as `H-`/`D-` score (their sum) and `P-` positional scores (fairseq/fairseq_cli/generate.py:274-291).
+ * d_logits [rows, vocab] dense, as ss_t2u_units returns them. */
+int ss_row_max_logprob(void* stream, const float* d_logits, int rows, int vocab, int mask0, int mask1, int mask2,
+                       float* d_out);
+
 /* ---- a2-a7: model.encoder(src_tokens, src_lengths) for one utterance (agent :433-435 ->
  * chunk_unity/models/s2t_conformer.py:111-163).  d_fbank [T,80] -> d_enc_out [T',256].
  * attn_chunk = encoder.chunk_size, conv_chunk = ChunkCausalConv1d.chunk_size as the agent sets

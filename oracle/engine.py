@@ -70,6 +70,13 @@ class OracleEngine:
         return toks, torch.tensor(raw, dtype=torch.int32), (logits if want_logits else None)
 
 
+    def unit_scores(self, mt_feats, t2u_causal=False):
+        """researches/ctc_unity/ctc_generator.py:55-63: log_softmax, pad / unk / eos -> -inf, max over the vocabulary."""
+        t2u = O.t2u_encoder(self.sd, mt_feats.cpu(), self.cfg, causal=t2u_causal)
+        lp = torch.log_softmax(O.unit_decoder_logits(self.sd, t2u, self.cfg).float(), -1)
+        lp[:, [self.cfg.pad, self.cfg.unk, self.cfg.eos]] = float("-inf")
+        return lp.max(-1).values
+
     # ---- ragged-batch method set (one utterance after the other: the B = 1 arithmetic is the definition) ----
     def batch_fbank_cmvn(self, pcm_packed, n_samples, pcm_scale=32768.0):
         feats, T, off = [], [], 0

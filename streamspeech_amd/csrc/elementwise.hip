@@ -227,6 +227,47 @@ int launch_masked_argmax(const float* logits, int ld, int M, int N, int mask0, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Per-row maximum log-probability: out[m] = max_{n not masked} logits[m,n] - logsumexp_n logits[m,:]
+// = what `lprobs = log_softmax(logits); lprobs[:, masked] = -inf; lprobs.max(-1)` gives
+// (researches/ctc_unity/ctc_generator.py:55-63: the score / positional_scores of fairseq-generate's H- / P- lines).
+// One workgroup per row; two passes (max, then sum of exp) in f32 like torch's log_softmax.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_max_logprob_kernel(const float* __restrict__ logits, int ld, int N,
+                                                              int mask0, int mask1, int mask2, float* __restrict__ out) {
+  __shared__ float sa[4], sb[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* r = logits + (size_t)blockIdx.x * ld;
+  float mx = -INFINITY, best = -INFINITY;
+  for (int n = t; n < N; n += 256) {
+    const float v = r[n];
+    mx = fmaxf(mx, v);
+    if (n != mask0 && n != mask1 && n != mask2) best = fmaxf(best, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mx = fmaxf(mx, __shfl_xor(mx, o, 64)); best = fmaxf(best, __shfl_xor(best, o, 64)); }
+  if (lane == 0) { sa[wave] = mx; sb[wave] = best; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3]));
+  best = fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int n = t; n < N; n += 256) sum += __expf(r[n] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  if (lane == 0) sa[wave] = sum;
+  __syncthreads();
+  if (t == 0) out[blockIdx.x] = (best - mx) - __logf(sa[0] + sa[1] + sa[2] + sa[3]);
+}
+
+int launch_row_max_logprob(const float* logits, int ld, int M, int N, int mask0, int mask1, int mask2, float* out,
+                           hipStream_t stream) {
+  if (M <= 0) return SS_OK;
+  hipLaunchKernelGGL(row_max_logprob_kernel, dim3(M), dim3(256), 0, stream, logits, ld, N, mask0, mask1, mask2, out);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // CTC collapse: single workgroup, chunks of 1024 frames with a running output offset.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void ctc_collapse_kernel(const int* __restrict__ raw, int T, int blank, int pad,

@@ -37,6 +37,10 @@ int launch_masked_argmax(const float* logits, int ld, int M, int N, int mask0, i
                          int force, int* ids, hipStream_t stream, const int* row_max_len = nullptr, int step = 0,
                          int force_id = -1);  // row_max_len: force `force_id` on rows with step >= row_max_len[row]
 
+// out[m] = max_{n not in masks} log_softmax(logits[m,:])[n]   (researches/ctc_unity/ctc_generator.py:55-63)
+int launch_row_max_logprob(const float* logits, int ld, int M, int N, int mask0, int mask1, int mask2, float* out,
+                           hipStream_t stream);
+
 // CTC collapse (reference agent/ctc_decoder.py:66-88): drop repeats, then drop `blank` and `pad`.
 // tokens/index get the survivors and their frame index; *count their number.  Single workgroup.
 int launch_ctc_collapse(const int* raw, int T, int blank, int pad, int* tokens, int* index, int* count,

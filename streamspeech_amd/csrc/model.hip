@@ -281,6 +281,12 @@ extern "C" int ss_resample(void* stream, const float* d_in, int64_t n_in, int up
   return launch_resample(d_in, n_in, up, down, d_taps, half_len, d_out, n_out, (hipStream_t)stream);
 }
 
+extern "C" int ss_row_max_logprob(void* stream, const float* d_logits, int rows, int vocab, int mask0, int mask1, int mask2,
+                                  float* d_out) {
+  if (!d_logits || !d_out || rows < 0 || vocab <= 0) return SS_ERR_ARG;
+  return launch_row_max_logprob(d_logits, vocab, rows, vocab, mask0, mask1, mask2, d_out, (hipStream_t)stream);
+}
+
 extern "C" int ss_fbank_num_frames(int n) { return n < 400 ? 0 : 1 + (n - 400) / 160; }
 
 extern "C" int ss_fbank_cmvn(ss_model* m, void* stream, const float* d_pcm, int n_samples, float pcm_scale,

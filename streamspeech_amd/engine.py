@@ -287,6 +287,18 @@ class HipModel(BatchMixin):
         return host[U:U + k].tolist(), host[:U], logits
 
 
+    def unit_scores(self, mt_feats: torch.Tensor, t2u_causal: bool = False):
+        """Per-position maximum log-probability (natural log, pad / unk / eos masked after the softmax) of the unit
+        decoder over the 25 n positions -- the offline search's positional scores (researches/ctc_unity/ctc_generator.py:
+        55-63).  -> float32 [U] on the host.  Offline driver with --scores only; not on the timed path."""
+        _, _, logits = self.t2u_units(mt_feats, t2u_causal=t2u_causal, mask_eos=True, want_logits=True)
+        U, V = logits.shape
+        out = torch.empty((U,), dtype=torch.float32, device=self.device)
+        c = self.cfg
+        L.check(self.lib.ss_row_max_logprob(_stream(), _ptr(logits), U, V, c.pad, c.unk, c.eos, _ptr(out)), "ss_row_max_logprob")
+        return out.cpu()
+
+
 class HipVocoder:
     """ss_vocoder handle (CodeHiFiGANVocoderWithDur replacement)."""
 

@@ -16,8 +16,12 @@ utterance keeps its B = 1 arithmetic).  Sharding mirrors `--num-shards/--shard-i
 The `score` column of H-/D- is the sum of the per-position maximum log-probabilities in the
 reference (ctc_generator.py:60-91); the HIP path takes the argmax of the logits without ever forming
 log-probabilities, so the column is written as 0 and `P-` lines are omitted unless --scores is
-given (then both come from one extra log-softmax over the unit logits of the single-utterance entry
-point).
+given (then both come from ss_row_max_logprob over the unit logits of the single-utterance entry
+point: one more kernel, no torch arithmetic).  `T-` lines (generate.py:258-259) are written when
+the manifest carries target units (`tgt_audio` column, as the reference's S2UT manifests do).
+
+Pinned against the reference's own generator classes run on CPU (oracle/ref_offline.py ->
+tests/golden/offline_generator.json; tests/test_offline_generator_cpu.py, tests/test_offline_generator_gpu.py).
 """
 import argparse
 import math
@@ -59,7 +63,7 @@ def ordered_batches(lengths: Sequence[int], batch_size: int, max_tokens: int = 0
 def generate(model, vocoder, items: Sequence[Tuple[int, torch.Tensor]], dicts: Dict[str, object], results_path: str,
              subset: str = "test", batch_size: int = 32, max_tokens: int = 0, max_len_a: float = 0.0,
              max_len_b: int = 200, max_len_a_mt: float = 0.0, max_len_b_mt: int = 200, dur_prediction: bool = True, dump_wav: bool = True, t2u_causal: bool = False,
-             scores: bool = False, log=None) -> Dict[int, Dict]:
+             scores: bool = False, log=None, targets: Optional[Dict[int, Sequence[int]]] = None) -> Dict[int, Dict]:
     """items: (sample id, 16 kHz float PCM in [-1, 1] on the device).  Writes generate-<subset>.log/.txt,
     the cut .asr/.tgt/.unit files and pred_wav/<n>_pred.wav; returns the per-id hypotheses."""
     cfg = model.cfg
@@ -109,6 +113,8 @@ def generate(model, vocoder, items: Sequence[Tuple[int, torch.Tensor]], dicts: D
             score, pos = 0.0, None
             if scores:
                 score, pos = _unit_scores(model, feats[b][: n[b]], t2u_causal)
+            if targets is not None and sid in targets:
+                print(f"T-{sid}\t" + " ".join(str(u) for u in targets[sid]), file=res_f)
             print(f"H-{sid}\t{score}\t{unit_str}", file=res_f)
             print(f"D-{sid}\t{score}\t{unit_str}", file=res_f)
             if pos is not None:
@@ -122,13 +128,10 @@ def generate(model, vocoder, items: Sequence[Tuple[int, torch.Tensor]], dicts: D
 
 
 def _unit_scores(model, feats: torch.Tensor, t2u_causal: bool):
-    """Sum / per-position max log-probabilities in base 2 (generate.py:274,289), pad/unk/eos masked as in
-    ctc_generator.py:55-59."""
-    _, _, logits = model.t2u_units(feats.contiguous(), t2u_causal=t2u_causal, want_logits=True)
-    lp = torch.log_softmax(logits.float(), dim=-1)
-    cfg = model.cfg
-    lp[:, [cfg.pad, cfg.unk, cfg.eos]] = -math.inf
-    best = lp.max(dim=-1).values / math.log(2)
+    """Sum / per-position max log-probabilities in base 2 (generate.py:274,289), pad / unk / eos masked as in
+    ctc_generator.py:55-59.  The log-softmax + max runs in the engine (HIP: ss_row_max_logprob); the base change and the
+    sum (a float64 host sum like `scores[b].sum()` -> utils.item) are glue."""
+    best = model.unit_scores(feats.contiguous(), t2u_causal=t2u_causal).double() / math.log(2)
     return float(best.sum()), best.tolist()
 
 
@@ -152,17 +155,24 @@ def _cut_files(hyps: Dict[int, Dict], results_path: str, subset: str, dump_wav: 
                 frontend.write_wav(os.path.join(wdir, f"{n}_pred.wav"), w.detach().cpu().numpy(), 16000)
 
 
-def load_manifest(path: str) -> List[Tuple[int, str]]:
+def load_manifest(path: str, targets: Optional[Dict[int, List[int]]] = None) -> List[Tuple[int, str]]:
     """fairseq S2T/S2S manifest (TSV with header, columns `id` and `audio` = src_audio): one WAV per row.
-    The sample id fairseq prints is the row index."""
+    The sample id fairseq prints is the row index.  With `targets` given, the target units of the `tgt_audio` column
+    (space-separated ids, SpeechToSpeechDataset: fairseq/data/audio/speech_to_speech_dataset.py) are collected per id."""
     rows = []
     with open(path, encoding="utf-8") as f:
         header = f.readline().rstrip("\n").split("\t")
         col = header.index("src_audio") if "src_audio" in header else header.index("audio")
+        tcol = header.index("tgt_audio") if "tgt_audio" in header else -1
         for i, line in enumerate(f):
             parts = line.rstrip("\n").split("\t")
             if len(parts) > col and parts[col]:
                 rows.append((i, parts[col]))
+                if targets is not None and 0 <= tcol < len(parts):
+                    try:
+                        targets[i] = [int(u) for u in parts[tcol].split()]
+                    except ValueError:      # a wav path, not units (S2ST with spectrogram targets)
+                        pass
     return rows
 
 
@@ -208,6 +218,7 @@ def main(argv: Optional[List[str]] = None):
             vcfg = json.load(f)
     voc = CodeHiFiGANVocoderWithDur(a.vocoder, vcfg, device=a.device).hip
 
+    targets: Dict[int, List[int]] = {}
     if a.synthetic > 0:
         from . import workload, synth
         utts = workload.make_utterances(a.synthetic)
@@ -217,7 +228,7 @@ def main(argv: Optional[List[str]] = None):
             with open(a.wav_list) as f:
                 rows = [(i, ln.strip()) for i, ln in enumerate(f) if ln.strip()]
         else:
-            rows = load_manifest(os.path.join(a.data, a.gen_subset + ".tsv"))
+            rows = load_manifest(os.path.join(a.data, a.gen_subset + ".tsv"), targets)
         entries = []
         for i, path in rows:
             x, sr = frontend.read_wav(path)
@@ -232,7 +243,7 @@ def main(argv: Optional[List[str]] = None):
     sub = a.gen_subset if a.num_shards == 1 else f"{a.gen_subset}.shard{a.shard_id}"
     hyps = generate(model, voc, items, holder.dict, a.results_path, sub, a.batch_size, a.max_tokens, a.max_len_a,
                     a.max_len_b, a.max_len_a_mt, a.max_len_b_mt, a.dur_prediction, not a.no_wav,
-                    getattr(holder.model, "uni_encoder", False), a.scores)
+                    getattr(holder.model, "uni_encoder", False), a.scores, targets=targets or None)
     print(f"| generated {len(hyps)} utterances into {a.results_path}", file=sys.stderr)
 
 

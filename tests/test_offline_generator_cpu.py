@@ -1,0 +1,59 @@
+"""streamspeech_amd/offline.py (host driver, here over the CPU oracle engine) against the reference's offline generator
+classes: researches/ctc_unity/sequence_generator_multi_decoder_ctc.py (A-/S-/D- prints),
+researches/ctc_unity/ctc_generator.py (eos-masked unit search, score / positional scores) and the T-/H-/D-/P- lines of
+fairseq/fairseq_cli/generate.py:257-300 -- via the committed fixture, and live when /root/reference is present."""
+import json
+
+import numpy as np
+import pytest
+
+from tests import offline_fixture as OF
+from tests.oracle_engine import OracleEngine, OracleVocoder
+
+
+@pytest.fixture(scope="module")
+def oracle_model(synth_weights, golden_dir):
+    import os
+    cfg, vcfg, sd, vsd = synth_weights
+    g = np.load(os.path.join(golden_dir, "gcmvn_fr-en.npz"))
+    return OracleEngine(sd, cfg, cmvn_mean=g["mean"], cmvn_std=g["std"])
+
+
+def test_offline_driver_lines_equal_reference_generator_output(oracle_model, synth_weights, tmp_path):
+    cfg, vcfg, sd, vsd = synth_weights
+    r = OF.run_and_compare(oracle_model, OracleVocoder(vsd, vcfg), cfg, "short_search", tmp_path, score_rel=1e-6, pos_abs=1.5e-4)
+    # the files pred.offline-s2st.sh cuts out of the two generate files
+    units = open(tmp_path / "generate-test.unit").read().splitlines()
+    assert units == [" ".join(str(u) for u in r["hyps"][i]["units"]) for i in sorted(r["ids"])]
+    assert (tmp_path / "pred_wav" / "0_pred.wav").exists()
+
+
+def test_offline_driver_default_search_length(oracle_model, synth_weights, tmp_path):
+    """max_len_a_mt / max_len_b_mt = 0 / 200, the task's defaults: the random model never emits </s>, so the first pass runs
+    to 200 tokens in the reference (with incremental states) and here."""
+    cfg, vcfg, sd, vsd = synth_weights
+    OF.run_and_compare(oracle_model, None, cfg, "default_search", tmp_path, score_rel=1e-6, pos_abs=1.5e-4)
+
+
+def test_fixture_is_what_the_reference_generator_prints_now():
+    """Live re-run of one sample through the reference classes (skipped where /root/reference is absent)."""
+    from oracle import ref_loader
+    if not ref_loader.available():
+        pytest.skip("/root/reference not present")
+    import os
+    from oracle import kaldi_fbank as K
+    from oracle import make_golden_offline as MG
+    from oracle import ref_offline as RO
+    from streamspeech_amd import synth
+    from streamspeech_amd.config import ModelConfig
+    cfg = ModelConfig()
+    fix = OF.load()
+    gen, _, dicts = RO.build_generator(synth.make_model_state_dict(0, cfg), cfg, max_len_b_mt=fix["groups"]["short_search"]["max_len_b_mt"])
+    g = np.load(os.path.join(MG.ROOT, "tests", "golden", "gcmvn_fr-en.npz"))
+    sid, seed, n = MG.SAMPLES[0]
+    fb = K.global_cmvn(K.fbank(MG.sample_pcm(seed, n) * np.float32(32768.0)), g["mean"], g["std"])
+    r = RO.run_sample(gen, dicts, sid, fb, target_units=MG.sample_targets(sid))
+    ref = fix["groups"]["short_search"]["hypotheses"][str(sid)]
+    assert r["log"] == ref["log"] and r["units"] == ref["units"]
+    assert [ln.split("\t")[0] for ln in r["result"]] == [ln.split("\t")[0] for ln in ref["result"]]
+    assert abs(r["score"] - ref["score"]) < 1e-6 * abs(ref["score"])
