@@ -93,7 +93,14 @@ bool conv_pair_eligible(int C, int taps, int dil, int lda, int ldc, int nseg, lo
 int launch_conv_pair(const float* A, int lda, const float* W1, const float* b1, const float* W2, const float* b2, float* C,
                      int ldc, const float* R2, int ldr2, float div, float* C2, int ldc2, float c2_slope, int Cch, int taps,
                      int dil, int M, int in_len, float slope, const int* segs, int nseg, hipStream_t stream);
-   // number of bounded-spin time-outs seen so far (must stay 0)
+
+// Fused ResBlock of the narrow stages (resblock.hip): the three (dilated conv, conv, residual) pairs of one ResBlock in one
+// persistent launch, raw residual stream in registers, activated / intermediate slabs in LDS, Y = [R2 +] resblock(X) [/ div].
+// W1 / B1 / W2 / B2 / dil: the three pairs' matrices ([C][taps*C] tap-major), biases and dilations.  X must not alias Y.
+bool resblock_fused_eligible(int C, int taps, const int* dil, int ldx, int ldy, int nseg, long long M);
+int launch_resblock_fused(const float* X, int ldx, const float* const* W1, const float* const* B1, const float* const* W2,
+                          const float* const* B2, const int* dil, float* Y, int ldy, const float* R2, int ldr2, float div, int C,
+                          int taps, int M, float slope, const int* segs, int nseg, hipStream_t stream);
 
 // True when launch_conv_gemm would route `a` to the small-M kernel (the only one with the fused
 // LayerNorm prologue).

@@ -798,6 +798,7 @@ extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
 // HBM-bound late stages (C < 64) the extra write would cost more than the VALU, so the activation
 // stays on the consumer's A-fragment path there.
 // -------------------------------------------------------------------------------------------------
+static int g_no_resblock_fusion = getenv("SS_NO_RESBLOCK_FUSION") ? atoi(getenv("SS_NO_RESBLOCK_FUSION")) : 0;   // test hook / env knob (ss_debug_force_tile(4, ...)): narrow-stage ResBlocks as separate pair / conv launches
 static int g_no_pair_fusion = getenv("SS_NO_PAIR_FUSION") ? atoi(getenv("SS_NO_PAIR_FUSION")) : 0;   // test hook / env knob (ss_debug_force_tile(3, ...)): run the narrow-stage pairs as two launches
 struct GenBufs { float *bx, *bt, *br, *bs, *bxa, *bra, *bsa, *br2; };
 
@@ -842,6 +843,18 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
       geom(scale, gM, gsegs, gnseg);
       // measured per kernel size (rocprofv3, batch 32): fused wins 20-25 % at k = 3 (HBM-bound), ties at k = 7, loses
       // 10-30 % at k = 11 (MFMA-bound: halo rows of conv1 are extra work and the 54-KB footprint halves the occupancy)
+      // narrow stages: the whole ResBlock (three pairs) as ONE persistent launch (resblock.hip); bit-identical to the
+      // pair / two-launch forms below, which stay as the A/B and fallback path
+      if (!pa && !g_no_resblock_fusion && resblock_fused_eligible(C, kr, c.resblock_dilations[j], C, C, gnseg, gM)) {
+        const float *W1[3], *B1[3], *W2[3], *B2[3];
+        for (int dd = 0; dd < 3; ++dd) {
+          const int idx = (i * c.n_res + j) * 3 + dd;
+          W1[dd] = v->rb_c1[idx].w; B1[dd] = v->rb_c1[idx].b; W2[dd] = v->rb_c2[idx].w; B2[dd] = v->rb_c2[idx].b;
+        }
+        RET(launch_resblock_fused(b.bs, C, W1, B1, W2, B2, c.resblock_dilations[j], b.bx, C, j > 0 ? b.bx : nullptr, C,
+                                  j == c.n_res - 1 ? (float)c.n_res : 0.f, C, kr, gM, 0.1f, gsegs, gnseg, s));
+        continue;
+      }
       const bool fuse = !pa && !g_no_pair_fusion && kr == 3 &&
                         conv_pair_eligible(C, kr, c.resblock_dilations[j][2], C, C, gnseg, gM);
       const float* cur = b.bs;
@@ -1417,8 +1430,9 @@ extern "C" int ss_prof_num_classes(void) { return kNumTileCfg; }
 extern "C" const char* ss_prof_class_name(int cls) { return prof_cfg_name(cls); }
 
 extern "C" int ss_debug_force_tile(int bm, int bn, int ks) {
+  if (bm == 4 || bm == 0) g_no_resblock_fusion = (bm == 4);        // bm = 4: narrow-stage ResBlocks as separate launches (A/B of resblock.hip)
   if (bm == 3 || bm == 0) g_no_pair_fusion = (bm == 3);            // bm = 3: narrow-stage resblock pairs as two launches (A/B of the fused kernel)
-  debug_force_tile(bm == 3 ? 0 : bm, bn, ks);
+  debug_force_tile((bm == 3 || bm == 4) ? 0 : bm, bn, ks);
   return SS_OK;
 }
 extern "C" int ss_debug_sk_errors(void) { return conv_sk_error_count() + conv_sk2_error_count(); }

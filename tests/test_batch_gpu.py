@@ -276,3 +276,34 @@ def test_fused_resblock_pairs_equal_the_two_launch_form_bitwise(hip_vocoder, syn
     for a, b in zip(fused, plain):
         assert torch.equal(a, b)
     assert torch.equal(f1, p1)
+
+
+def test_fused_narrow_resblocks_equal_the_multi_launch_form_bitwise(hip_vocoder):
+    """resblock_fused_kernel (resblock.hip: the three (dilated conv, conv, residual) pairs of a C = 32 / 16 ResBlock in one
+    persistent launch, raw residual stream in registers, halo rows recomputed) performs the same per-element arithmetic as
+    the conv_pair / conv_slab launches it replaces (hifigan.py:95-102,159-165): waveforms are bit-identical -- ragged batch
+    with a one-frame utterance and a long one (several row blocks per utterance, block edges inside and at utterance
+    edges), and the single-utterance entry point."""
+    from streamspeech_amd import lib as L, synth
+    lib = L.load()
+    codes = [[int(c) for c in synth.uniform(17, f"frb/{i}", (k,), 0, 1000)] for i, k in enumerate((120, 1, 33, 2, 260, 7))]
+    durs = [[1 + (j % 3 == 1) for j in range(len(c))] for c in codes]
+    one = lambda i: hip_vocoder.forward(torch.tensor(codes[i], dtype=torch.int32, device="cuda:0"), True,   # noqa: E731
+                                        forced_dur=torch.tensor(durs[i], dtype=torch.int32, device="cuda:0"))[0].clone()
+    fused = [w.clone() for w in hip_vocoder.batch_forward(codes, True, forced_dur=durs)[0]]
+    f_single = [one(i) for i in (1, 4)]
+    lib.ss_debug_force_tile(4, 0, 0)           # narrow-stage ResBlocks as pair / two-launch kernels
+    try:
+        plain = [w.clone() for w in hip_vocoder.batch_forward(codes, True, forced_dur=durs)[0]]
+        p_single = [one(i) for i in (1, 4)]
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)
+    for i, (a, b) in enumerate(zip(fused, plain)):
+        assert a.numel() == 320 * sum(durs[i]) and torch.isfinite(a).all()
+        assert torch.equal(a, b), f"utterance {i}: max diff {(a - b).abs().max().item()}"
+    # single-utterance entry point: the long one takes the same slab kernels in the multi-launch form -> bitwise; the
+    # one-frame utterance (160 / 320 rows per narrow stage) runs there on the LDS-tiled conv_gemm kernel (M < 2048), whose
+    # summation tree differs -> float noise only
+    assert torch.equal(f_single[1], p_single[1])
+    assert (f_single[0] - p_single[0]).abs().max().item() < 2e-5
+    assert torch.equal(f_single[1], fused[4]) and torch.equal(f_single[0], fused[1])  # ragged pack == single-utterance entry point
