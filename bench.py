@@ -352,6 +352,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the optional second line (same batches, split-bf16 vocoder convs)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--no-bracket-ab", action="store_true", help="skip the event-bracket on / off A/B of the timed region (five more region passes)")
     ap.add_argument("--no-multilingual", action="store_true", help="skip the configs[4] sub-object (fr/es/de weight sets resident together)")
     ap.add_argument("--no-streaming-line", action="store_true", help="skip the configs[2] sub-object (320-ms agent policy() loop + its CPU baseline)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -555,7 +556,11 @@ def main():
             kv = pm.get("classes", {}).get(name)
             if kv:
                 traffic = round(kv["hbm_mbytes_per_launch_corrected"] * 1e6)          # HBM-side bytes per launch (counters)
-                traffic_detail = {"mbytes_per_launch": kv["hbm_mbytes_per_launch_corrected"],
+                from tools.pmc_traffic import csrc_sha16
+                traffic_detail = {"measured_by": "a separate rocprofv3 --pmc run of an earlier process (NOT this run)",
+                                  "pmc_run_kernel_sources_sha16": pm.get("csrc_sha16"), "this_build_kernel_sources_sha16": csrc_sha16(),
+                                  "same_kernel_sources": pm.get("csrc_sha16") == csrc_sha16(),
+                                  "mbytes_per_launch": kv["hbm_mbytes_per_launch_corrected"],
                                   "algorithmic_mbytes_per_launch_of_the_pmc_run": kv.get("algo_mbytes_per_launch"),
                                   "traffic_over_algorithmic": kv.get("traffic_over_algorithmic"),
                                   "mfma_util_pct": kv.get("mfma_util_pct"),
@@ -661,7 +666,7 @@ def main():
     # What the HIP-event brackets (two classes, enabled inside the timed region so that `in_region` exists) cost the headline:
     # the same region once more with the brackets on and off (VERDICT r2 "quantify once").
     bracket_ab = None
-    if world == 1 and dom is not None and work and Bsz > 1:
+    if world == 1 and dom is not None and work and Bsz > 1 and S > 1 and not args.no_bracket_ab:
         mask = (1 << dom) | ((1 << dom_conv) if dom_conv is not None else 0)
         region_pass()
         lib.ss_prof_enable(mask)

@@ -207,7 +207,9 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
             # FIR edge), so the newest fbank frame is not settled: the incremental encoder must not cache rows
             # that can see it
             if hasattr(eng, "encoder_stream_set_tail"):
-                eng.encoder_stream_set_tail(1 if int(args.sample_rate) != SAMPLE_RATE else 0)
+                from .frontend import unsettled_fbank_frames
+                eng.encoder_stream_set_tail(unsettled_fbank_frames(int(args.sample_rate), SAMPLE_RATE,
+                                                                   int(args.shift_size * SAMPLE_RATE / 1000)))
 
         # dictionaries: target units + the three multitask text dictionaries
         self.dict = {"tgt": Dictionary.units(1000)}

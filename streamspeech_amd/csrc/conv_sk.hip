@@ -42,7 +42,8 @@ struct SkArgs {
   int NG;               // 8: tiles are split over the 8 XCDs first (workgroup i runs on XCD i % 8), 1: no grouping
 };
 
-constexpr int SK_BM = 128, SK_BK = 32, SK_FLAG0 = 16, SK_MAXG = 512;
+constexpr int SK_BM = 128, SK_BK = 32, SK_MAXG = 512;
+[[maybe_unused]] constexpr int SK_FLAG0 = 16;
 [[maybe_unused]] constexpr unsigned SK_SPIN_LIMIT = 1u << 22;
 [[maybe_unused]] constexpr int SK_NUM_RECORDS = 0x7ffffff0;          // buffer range: every real offset is below, SK_OOB is above
 [[maybe_unused]] constexpr unsigned SK_OOB = 0x80000000u;
@@ -80,6 +81,9 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
   if (t == 0) s_misc[0] = (int)(atomicAdd(q.sync + grp, 1u) - q.base[grp]);
   __syncthreads();
   const int rank = __builtin_amdgcn_readfirstlane(s_misc[0]);
+  // a ticket outside [0, Gg) means the host's ticket base and the device counter disagree (two host threads driving one
+  // context): count it like a bounded-wait time-out and leave, instead of indexing tiles / workspace slots with it
+  if ((unsigned)rank >= (unsigned)Gg) { if (t == 0) atomicAdd(q.sync + 8, 1u); return; }
   const int w = grp * Gg + rank;                 // logical id: workspace slot / flag index
 
   const int kpt = p.Cin / BK;
@@ -400,38 +404,10 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-struct SkState {
-  float* ws = nullptr;
-  unsigned* sync = nullptr;
-  unsigned base[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned epoch = 0;
-};
-static std::map<hipStream_t, SkState> g_sk;
-static std::mutex g_sk_mu;
-static int g_sk_cus = 0;
+// Workspace, ticket counters and flags belong to the calling execution context (SkWorkspace, gemm.hpp).
 static int g_sk_groups = 0;   // XCD tile grouping: measured neutral on time and -6 % on L2 misses (profiles/r01_sk_sweep.txt), so off;
                               // tools: debug_force_tile(1, 8, g) switches it on
 void conv_sk_set_groups(int on) { g_sk_groups = on; }
-constexpr size_t SK_SYNC_BYTES = (SK_FLAG0 + SK_MAXG) * sizeof(unsigned) + 256;
-
-static int sk_state(hipStream_t stream, SkState** out) {
-  std::lock_guard<std::mutex> lk(g_sk_mu);
-  if (!g_sk_cus) {
-    int dev = 0;
-    SS_HIP_CHECK(hipGetDevice(&dev));
-    SS_HIP_CHECK(hipDeviceGetAttribute(&g_sk_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    if (g_sk_cus <= 0) g_sk_cus = 256;
-    if (2 * g_sk_cus > SK_MAXG) g_sk_cus = SK_MAXG / 2;
-  }
-  SkState& st = g_sk[stream];
-  if (!st.ws) {
-    SS_HIP_CHECK(hipMalloc(&st.ws, (size_t)SK_MAXG * SK_BM * 128 * sizeof(float)));
-    SS_HIP_CHECK(hipMalloc(&st.sync, SK_SYNC_BYTES));
-    SS_HIP_CHECK(hipMemsetAsync(st.sync, 0, SK_SYNC_BYTES, stream));
-  }
-  *out = &st;
-  return SS_OK;
-}
 
 bool conv_sk_eligible(const GemmArgs& a) {
   return a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && a.Cin % SK_BK == 0 && (a.lda & 3) == 0 &&
@@ -440,30 +416,24 @@ bool conv_sk_eligible(const GemmArgs& a) {
          (size_t)a.N * a.taps * a.Cin * 4 < 0x7ff00000ull && (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f));
 }
 
-int conv_sk_error_count() {
-  std::lock_guard<std::mutex> lk(g_sk_mu);
-  int total = 0;
-  for (auto& kv : g_sk) {
-    unsigned v = 0;
-    if (kv.second.sync && hipMemcpy(&v, kv.second.sync + 8, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) total += (int)v;
-  }
-  return total;
-}
+int conv_sk_error_count() { return sk_workspace_error_count(); }   // both stream-K generations share the workspaces
 
 template <int BN, bool LRELU>
 static int launch_sk(const GemmArgs& a, hipStream_t stream, int g_force) {
   constexpr size_t kLds = 2 * (size_t)(SK_BM + BN) * SK_BK * sizeof(float) + (2 * SK_BM + 4) * sizeof(int);
   SS_MAX_LDS_ONCE((&conv_sk_kernel<BN, LRELU>), kLds);
-  SkState* st = nullptr;
-  int rc = sk_state(stream, &st);
+  SkWorkspace* st = nullptr;
+  int rc = sk_workspace_acquire(stream, &st);
   if (rc != SS_OK) return rc;
+  const int cus = 2 * st->cus > SK_MAXG ? SK_MAXG / 2 : st->cus;
   const long long nk = (long long)a.taps * (a.Cin / SK_BK);
   const long long U = (long long)cdiv(a.M, SK_BM) * (a.N / BN) * nk;
   // every workgroup gets >= 8 k-steps so that the fix-up (one 64-KB partial) stays a small fraction
-  long long G = g_force > 0 ? g_force : 2LL * g_sk_cus;
+  long long G = g_force > 0 ? g_force : 2LL * cus;
   if (G > U / 8) G = U / 8;
   if (G < 1) G = 1;
   if (G > SK_MAXG) G = SK_MAXG;
+  if (G > 2LL * st->cus) G = 2LL * st->cus;               // the workspace holds 2 x 64 KB per CU
   const long long tiles = (long long)cdiv(a.M, SK_BM) * (a.N / BN);
   // data-parallel special case: when the tile count itself nearly fills the resident grid, one tile per
   // workgroup needs no fix-up at all (U/G = nk exactly)
@@ -471,15 +441,19 @@ static int launch_sk(const GemmArgs& a, hipStream_t stream, int g_force) {
   const int NG = (g_sk_groups && G >= 64 && tiles >= 64) ? 8 : 1;
   if (NG > 1) G -= G % NG;
   SkArgs q;
-  q.ws = st->ws; q.sync = st->sync;
-  q.epoch = ++st->epoch; q.G = (int)G; q.NG = NG;
-  for (int x = 0; x < 8; ++x) q.base[x] = st->base[x];
-  for (int x = 0; x < NG; ++x) st->base[x] += (unsigned)(G / NG);
+  q.ws = st->ws; q.sync = st->sync1;
+  unsigned epoch = st->epoch1 + 1;
+  if (epoch == 0) epoch = 1;                              // 0 is what a fresh flag holds
+  q.epoch = epoch; q.G = (int)G; q.NG = NG;
+  for (int x = 0; x < 8; ++x) q.base[x] = st->base1[x];
   ProfRec rec{}; bool prof = false;
   rc = prof_begin(a, stream, 15, rec, prof);
   if (rc != SS_OK) return rc;
   hipLaunchKernelGGL((conv_sk_kernel<BN, LRELU>), dim3((unsigned)G), dim3(256), kLds, stream, a, q);
   SS_LAUNCH_CHECK();
+  // the launch is in the stream: only now do the tickets it will draw and its epoch become part of the context's state
+  for (int x = 0; x < NG; ++x) st->base1[x] += (unsigned)(G / NG);
+  st->epoch1 = epoch;
   return prof_end(stream, rec, prof);
 }
 

@@ -29,8 +29,7 @@
 //     thrashed the instruction cache and cost 25+ us per tile part).
 #include "gemm.hpp"
 
-#include <map>
-#include <mutex>
+#include <cstdlib>
 
 namespace ss {
 
@@ -44,7 +43,7 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 constexpr int K2_BM = 256, K2_BK = 32;
 [[maybe_unused]] constexpr int K2_SC1 = 16;                              // buffer cache policy bit: agent scope
 constexpr int K2_MAXG = 512;
-constexpr int K2_WORD0 = 16;                            // sync[K2_WORD0 + w] = flag of logical workgroup w
+[[maybe_unused]] constexpr int K2_WORD0 = 16;                            // sync[K2_WORD0 + w] = flag of logical workgroup w
 [[maybe_unused]] constexpr unsigned K2_SPIN_LIMIT = 1u << 22;
 [[maybe_unused]] constexpr int K2_NUM_RECORDS = 0x7ffffff0;
 [[maybe_unused]] constexpr unsigned K2_OOB = 0x80000000u;
@@ -61,15 +60,28 @@ struct Sk2Args {
 };
 
 #define K2_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-// Timing-only ablation builds (tools/sk2_bench.py with SS_EXTRA_FLAGS=-DK2_ABL=<mask>; results are wrong by design):
-// 1 no LDS-DMA in the k-loop, 2 no wait + barrier in the k-loop, 4 no ds_reads in the k-loop, 8 no epilogue / hand-off,
-// 16 no MFMAs, 32 no hand-off (every part runs the epilogue), 64 no C / C2 stores, 128 no R / R2 loads, 256 one A piece
-// per k-step instead of eight.  Never set in the product build.
-#ifndef K2_ABL
-#define K2_ABL 0
-#endif
-#ifndef K2_TIMING
-#define K2_TIMING 0     // 1: thread 0 of every workgroup accumulates s_memtime cycles per phase into q.dbg (diagnostic build)
+// Diagnostic hook points.  The product build compiles every one of them to nothing.  The timing-only ablation switches
+// (results wrong by design) and the per-phase cycle stamps that produced profiles/r02_sk2_ablation*.txt and
+// profiles/r02_sk2_timing*.txt live in tools/src/conv_sk2_diag.hpp, which is only included by the diagnostic library
+// build (tools/sk2_bench.py / tools/sk2_timing.py: SS_EXTRA_FLAGS="-DK2_DIAGNOSTIC_BUILD -DK2_ABL=<mask>" or "-DK2_TIMING=1").
+#ifdef K2_DIAGNOSTIC_BUILD
+#include "../../tools/src/conv_sk2_diag.hpp"
+#else
+#define K2D_SKIP_DMA(in_loop) false
+#define K2D_SKIP_A_PIECE(in_loop, j) false
+#define K2D_SKIP_WAIT_BARRIER 0
+#define K2D_SKIP_DS_READ(in_loop) false
+#define K2D_SKIP_TAIL false
+#define K2D_SKIP_MFMA false
+#define K2D_SKIP_HANDOFF false
+#define K2D_SKIP_STORES false
+#define K2D_SKIP_R_LOADS false
+#define K2D_ONE_A_PIECE 0
+#define K2D_TIMING 0
+#define K2D_TIMING_DECL
+#define K2_STAMP(slot) do { } while (0)
+#define K2D_COUNT_STEPS(n) do { } while (0)
+#define K2D_TIMING_FLUSH do { } while (0)
 #endif
 #ifndef K2_RPREF
 #define K2_RPREF 1      // 1: request the tile's residual operand during the part's last k-step (see the k-loop)
@@ -124,15 +136,10 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   if (t == 0) s_misc[0] = (int)(atomicAdd(q.sync, 1u) - q.base);
   __syncthreads();
   const int w = __builtin_amdgcn_readfirstlane(s_misc[0]);   // logical id in order of arrival: range, workspace slot, flag
-#if K2_TIMING
-  unsigned long long tph[6] = {0, 0, 0, 0, 0, 0};            // prologue, part set-up, k-loop, hand-off, epilogue, k-steps
-  const unsigned long long t_begin = __builtin_readcyclecounter();
-  unsigned long long tk_last = t_begin;
-  auto stamp = [&](int slot) { const unsigned long long now = __builtin_readcyclecounter(); tph[slot] += now - tk_last; tk_last = now; };
-#define K2_STAMP(slot) stamp(slot)
-#else
-#define K2_STAMP(slot) do { } while (0)
-#endif
+  // a ticket outside [0, G) means the host's ticket base and the device counter disagree (two host threads driving one
+  // context): count it like a bounded-wait time-out and leave, instead of indexing tiles / workspace slots with it
+  if ((unsigned)w >= (unsigned)q.G) { if (t == 0) atomicAdd(q.sync + 8, 1u); return; }
+  K2D_TIMING_DECL
 
   const int kpt = p.Cin / BK;
   const int nk = p.taps * kpt;
@@ -250,17 +257,16 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   // `live` = false turns a piece into a zero fill (offset beyond the buffer range: no memory traffic): when nothing is
   // left to stage the k-loop keeps issuing into ring slots nobody reads any more, so its body has no branches and the
   // wait count is the same every iteration.
-  bool in_loop = false;
+  [[maybe_unused]] bool in_loop = false;          // read by the diagnostic hooks only
   auto issueA = [&](int stage, int j, bool live) {
-    if ((K2_ABL & 1) && in_loop) return;
-    if ((K2_ABL & 256) && in_loop && j > 0) return;     // timing-only: one A piece per step (what an A slab resident across the taps would issue)
+    if (K2D_SKIP_DMA(in_loop) || K2D_SKIP_A_PIECE(in_loop, j)) return;
     float* sA = smem + stage * STAGE + (wave * 64) * BK;
     const bool ok = (unsigned)(a_base[j] + shift_l) < (unsigned)a_len[j];   // one unsigned compare: row inside its utterance (and live)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_ptr_t)(sA + j * 8 * BK), 16, ok ? a_off[j] : K2_OOB,
                                              __builtin_amdgcn_readfirstlane(soffA), 0, 0);
   };
   auto issueW = [&](int stage, int j, bool live) {
-    if ((K2_ABL & 1) && in_loop) return;
+    if (K2D_SKIP_DMA(in_loop)) return;
     float* sW = smem + stage * STAGE + BM * BK + (wave * (BN / 4)) * BK;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_ptr_t)(sW + j * 8 * BK), 16, live ? w_off[j] : K2_OOB,
                                              __builtin_amdgcn_readfirstlane(soffW), 0, 0);
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     step_advance(live);
   };
   auto wait_newest_step_only = [&]() {   // everything but the PIECES newest VMEM operations of this wave has completed
-    if constexpr ((K2_ABL & 256) != 0) { if constexpr (BN == 128) K2_WAIT_VMCNT(5); else K2_WAIT_VMCNT(3); }
+    if constexpr (K2D_ONE_A_PIECE != 0) { if constexpr (BN == 128) K2_WAIT_VMCNT(5); else K2_WAIT_VMCNT(3); }
     else if constexpr (BN == 128) K2_WAIT_VMCNT(12); else K2_WAIT_VMCNT(10);
   };
   // ---- the stager: runs two k-steps ahead of the contraction, straight across part boundaries ----
@@ -304,9 +310,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   for (int ip = 0; ip < nparts; ++ip) {
     const Part cur = part_of(ip);
     const int n = cur.n, m0 = cur.m0, n0 = cur.n0;
-#if K2_TIMING
-    tph[5] += (unsigned long long)n;
-#endif
+    K2D_COUNT_STEPS(n);
     f32x4 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -314,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     auto load_frag = [&](const float* S, int half, int u, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {   // fragment u of a half-step: B 0..3, A 4..
-      if ((K2_ABL & 4) && in_loop) return;
+      if (K2D_SKIP_DS_READ(in_loop)) return;
       if (u < TN) {
         bf[u] = *reinterpret_cast<const f32x4*>(S + (half ? rdW1 : rdW0) + u * 16 * BK);
         if (X3) bf[u] = k2_split_bf16(bf[u]);
@@ -331,7 +335,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     // 8 MFMAs: k4 slice e of row tiles 2q, 2q+1 against all 4 column tiles (8 independent accumulators; the same
     // accumulator comes back 4 * TM MFMAs later)
     auto mma8 = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN], int e, int qd) {
-      if (K2_ABL & 16) return;
+      if (K2D_SKIP_MFMA) return;
       if (X3 && e == 3) return;              // split-bf16: three terms per k-slice of 16 (e = 0: hi.hi, 1: hi.lo, 2: lo.hi)
 #pragma unroll
       for (int i = 2 * qd; i < 2 * qd + 2; ++i)
@@ -393,7 +397,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 #pragma unroll
       for (int sl = 0; sl < 2 * HG; ++sl) mma8(ay, by, sl / HG, sl % HG);
       // ---- step c + 1 landed for every wave, every wave is done with slot st - 1 and with X ----
-#if !(K2_ABL & 2)
+#if !K2D_SKIP_WAIT_BARRIER
       wait_newest_step_only();
       __builtin_amdgcn_s_barrier();
 #endif
@@ -407,16 +411,14 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     in_loop = false;
     K2_STAMP(2);
     const bool has_begin = cur.ka == 0, has_end = cur.kb == nk;
-#if K2_ABL & 8
-    if (acc[0][0][0] != 12345.f) continue;
-#endif
+    if (K2D_SKIP_TAIL && acc[0][0][0] != 12345.f) continue;
 
     // Everything below derives its per-lane addresses from `le`, which the compiler cannot see through: otherwise it
     // computes the hand-off / epilogue addresses BEFORE the k-loop and carries ~100 VGPRs through it.
     int le = lane;
     asm volatile("" : "+v"(le));
     const int r_e = le & 15, g_e = le >> 4;
-    if (!(K2_ABL & 32) && !has_end) {
+    if (!K2D_SKIP_HANDOFF && !has_end) {
       // ---- contributor: park the partial tile, raise the flag ----
       // Partials move as sc1 (agent-scope) b128 buffer stores / loads and the flags as sc1 relaxed atomics: they write
       // through / read past the per-XCD L2, so no L2 write-back or invalidate (which would evict the weights every
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
       K2_STAMP(3);
       continue;
     }
-    if (!(K2_ABL & 32) && !has_begin) {
+    if (!K2D_SKIP_HANDOFF && !has_begin) {
       // ---- finisher: add the partials of the workgroups that own k-steps [0, ka) of this tile, in workgroup order ----
       const long long ut0 = (long long)(t_last - ip) * nk;
       const int wf = (int)(((ut0 + 1) * q.G - 1) / U);       // workgroup that owns the tile's first unit
@@ -501,14 +503,14 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
         for (int j = 0; j < TN; ++j) {
           const int nn = n0 + wcol + j * 16 + g_e * 4;
 #if K2_RPREF
-          if (p.R && !(K2_ABL & 128)) {
+          if (p.R && !K2D_SKIP_R_LOADS) {
             if (qq * 2 + i < PT) rr[i][j] = rall[qq * 2 + i < PT ? qq * 2 + i : 0][j];
             else rr[i][j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nn);
           }
 #else
-          if (p.R && !(K2_ABL & 128)) rr[i][j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nn);
+          if (p.R && !K2D_SKIP_R_LOADS) rr[i][j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + nn);
 #endif
-          if (p.R2 && !(K2_ABL & 128)) rr2[i][j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + nn);
+          if (p.R2 && !K2D_SKIP_R_LOADS) rr2[i][j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)m * p.ldr2 + nn);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[i][j][e] *= p.alpha;
-      if (p.R && !(K2_ABL & 128)) {
+      if (p.R && !K2D_SKIP_R_LOADS) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -558,7 +560,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[i][j][e] += rr[i][j][e];
       }
-      if (p.R2 && !(K2_ABL & 128)) {
+      if (p.R2 && !K2D_SKIP_R_LOADS) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -581,8 +583,8 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int nn = n0 + wcol + j * 16 + g_e * 4;
-          if (!(K2_ABL & 64) || v[i][j][0] == 12345.f) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + nn) = v[i][j];
-          if (p.C2 && !(K2_ABL & 64)) {
+          if (!K2D_SKIP_STORES || v[i][j][0] == 12345.f) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + nn) = v[i][j];
+          if (p.C2 && !K2D_SKIP_STORES) {
             f32x4 w2;
 #pragma unroll
             for (int e = 0; e < 4; ++e) w2[e] = v[i][j][e] > 0.f ? v[i][j][e] : v[i][j][e] * p.c2_slope;
@@ -594,28 +596,13 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
     __builtin_amdgcn_sched_barrier(0);
     K2_STAMP(4);
   }
-#if K2_TIMING
-  if (t == 0 && q.dbg) {
-    unsigned long long* d = q.dbg + (size_t)w * 8;
-    for (int i = 0; i < 6; ++i) d[i] = tph[i];
-    d[6] = t_begin; d[7] = __builtin_readcyclecounter();
-  }
-#endif
+  K2D_TIMING_FLUSH;
 #endif
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-// Workspace / flags / function attributes / CU count live per (device, stream): two devices in one process may both
-// use the null stream, and a workspace belongs to the device it was allocated on.
-struct Sk2State {
-  float* ws = nullptr;
-  unsigned* sync = nullptr;
-  unsigned base = 0, epoch = 0;
-  unsigned long long* dbg = nullptr;   // K2_TIMING builds
-};
-struct Sk2Dev { int cus = 0; bool attr[8] = {false, false, false, false, false, false, false, false}; };
-static std::map<std::pair<int, hipStream_t>, Sk2State> g_k2;
-#if K2_TIMING
+// Workspace, ticket counter and flags belong to the calling execution context (SkWorkspace, gemm.hpp).
+#if K2D_TIMING
 static unsigned long long* g_k2_last_dbg = nullptr;
 static int g_k2_last_G = 0;
 // diagnostic build only: phase cycle counts of the LAST conv_sk2 launch, [G][8] = prologue, part set-up, k-loop, hand-off,
@@ -626,9 +613,7 @@ extern "C" int ss_debug_sk2_timing(unsigned long long* h_out, int cap_wgs) {
   return g_k2_last_G;
 }
 #endif
-static std::map<int, Sk2Dev> g_k2_dev;
-static std::mutex g_k2_mu;
-constexpr size_t K2_SYNC_BYTES = (K2_WORD0 + K2_MAXG) * sizeof(unsigned) + 256;
+static const int g_k2_spare_cus = getenv("SS_SK2_SPARE_CUS") ? atoi(getenv("SS_SK2_SPARE_CUS")) : 0;   // tuning knob (measured flat)
 
 bool conv_sk2_eligible(const GemmArgs& a) {
   return a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && a.Cin % K2_BK == 0 && (a.lda & 3) == 0 &&
@@ -638,71 +623,45 @@ bool conv_sk2_eligible(const GemmArgs& a) {
          (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f));
 }
 
-int conv_sk2_error_count() {
-  std::lock_guard<std::mutex> lk(g_k2_mu);
-  int total = 0;
-  for (auto& kv : g_k2) {
-    unsigned v = 0;
-    if (kv.second.sync && hipMemcpy(&v, kv.second.sync + 8, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) total += (int)v;
-  }
-  return total;
-}
+int conv_sk2_error_count() { return 0; }   // counted with the shared workspaces: conv_sk_error_count()
 
 template <int BN, bool LRELU, bool X3>
 static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   constexpr size_t kLds = k2_lds_bytes(BN);
-  constexpr int kVariant = (BN == 128 ? 0 : 2) + (LRELU ? 1 : 0) + (X3 ? 4 : 0);
-  int dev = 0;
-  SS_HIP_CHECK(hipGetDevice(&dev));
-  Sk2State* st = nullptr;
-  int cus = 0;
-  {
-    std::lock_guard<std::mutex> lk(g_k2_mu);
-    Sk2Dev& d = g_k2_dev[dev];
-    if (!d.cus) {
-      SS_HIP_CHECK(hipDeviceGetAttribute(&d.cus, hipDeviceAttributeMultiprocessorCount, dev));
-      if (d.cus <= 0) d.cus = 256;
-      if (d.cus > K2_MAXG) d.cus = K2_MAXG;
-      // SS_SK2_SPARE_CUS = n: leave n CUs to the other streams' small kernels (a stream-K workgroup owns its CU: 480 of
-      // the 512 registers per SIMD, 147 KB of LDS -- nothing can be co-resident with it)
-      if (const char* e = getenv("SS_SK2_SPARE_CUS")) { const int n = atoi(e); if (n > 0 && n < d.cus) d.cus -= n; }
-    }
-    if (!d.attr[kVariant]) {
-      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_sk2_kernel<BN, LRELU, X3>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds));
-      d.attr[kVariant] = true;
-    }
-    cus = d.cus;
-    st = &g_k2[std::make_pair(dev, stream)];
-    if (!st->ws) {
-      SS_HIP_CHECK(hipMalloc(&st->ws, (size_t)K2_MAXG * K2_BM * 128 * sizeof(float)));
-      SS_HIP_CHECK(hipMalloc(&st->sync, K2_SYNC_BYTES));
-      SS_HIP_CHECK(hipMemsetAsync(st->sync, 0, K2_SYNC_BYTES, stream));
-    }
-  }
+  SS_MAX_LDS_ONCE((&conv_sk2_kernel<BN, LRELU, X3>), kLds);
+  SkWorkspace* st = nullptr;
+  int rc = sk_workspace_acquire(stream, &st);
+  if (rc != SS_OK) return rc;
+  int cus = st->cus > K2_MAXG ? K2_MAXG : st->cus;
+  // SS_SK2_SPARE_CUS = n: leave n CUs to the other streams' small kernels (a stream-K workgroup owns its CU: 480 of
+  // the 512 registers per SIMD, 147 KB of LDS -- nothing can be co-resident with it)
+  if (g_k2_spare_cus > 0 && g_k2_spare_cus < cus) cus -= g_k2_spare_cus;
   const long long nk = (long long)a.taps * (a.Cin / K2_BK);
   const long long U = (long long)cdiv(a.M, K2_BM) * (a.N / BN) * nk;
   long long G = g_force > 0 ? g_force : cus;        // one workgroup per CU (147 | 123 KB of LDS each), all resident
   if (G > cus) G = cus;
   if (G > U / 4) G = U / 4;                         // at least 4 k-steps per workgroup
-  if (G > K2_MAXG) G = K2_MAXG;
   if (G < 1) G = 1;
   Sk2Args q;
-  q.ws = st->ws; q.sync = st->sync; q.G = (int)G; q.dbg = nullptr;
-#if K2_TIMING
+  q.ws = st->ws; q.sync = st->sync2; q.G = (int)G; q.dbg = nullptr;
+#if K2D_TIMING
   if (!st->dbg) SS_HIP_CHECK(hipMalloc(&st->dbg, (size_t)K2_MAXG * 8 * sizeof(unsigned long long)));
   SS_HIP_CHECK(hipMemsetAsync(st->dbg, 0, (size_t)K2_MAXG * 8 * sizeof(unsigned long long), stream));
   q.dbg = st->dbg;
   g_k2_last_dbg = st->dbg; g_k2_last_G = (int)G;
 #endif
-  q.base = st->base; st->base += (unsigned)G;
-  q.epoch = ++st->epoch;
-  if (q.epoch == 0) q.epoch = ++st->epoch;          // 0 is what a fresh flag holds
+  unsigned epoch = st->epoch2 + 1;
+  if (epoch == 0) epoch = 1;                        // 0 is what a fresh flag holds
+  q.base = st->base2;
+  q.epoch = epoch;
   ProfRec rec{}; bool prof = false;
-  int rc = prof_begin(a, stream, X3 ? 19 : 18, rec, prof);
+  rc = prof_begin(a, stream, X3 ? 19 : 18, rec, prof);
   if (rc != SS_OK) return rc;
   hipLaunchKernelGGL((conv_sk2_kernel<BN, LRELU, X3>), dim3((unsigned)G), dim3(256), kLds, stream, a, q);
   SS_LAUNCH_CHECK();
+  // the launch is in the stream: only now do the tickets it will draw and its epoch become part of the context's state
+  st->base2 += (unsigned)G;
+  st->epoch2 = epoch;
   return prof_end(stream, rec, prof);
 }
 

@@ -10,6 +10,7 @@
 // C/D layout (MI355X guide §3): col = lane&15, row = (lane>>4)*4 + reg.
 #include "gemm.hpp"
 
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <map>
@@ -624,9 +625,10 @@ int prof_read(int cls, double* ms_total, double* flops_total, long long* launche
 // Always-on launch census (no events, no synchronisation): launches, algorithmic FLOPs and bytes per tile class since the
 // library was loaded.  Lets a profile of a WHOLE process (rocprofv3 kernel stats, PMC passes) be divided by the
 // algorithmic work of exactly the launches it saw.
-struct ProfTotals { double flops = 0, bytes = 0; long long launches = 0; };
+// (relaxed atomics: eight host threads launch concurrently in bench.py; integer FLOP / byte counts -- 2^64 is ~18 EFLOP)
+struct ProfTotals { std::atomic<unsigned long long> flops{0}, bytes{0}, launches{0}; };
 static ProfTotals g_prof_totals[kNumTileCfg];
-static std::mutex g_tot_mu;
+static std::mutex g_tot_mu;          // SS_SHAPE_LOG table only
 // SS_SHAPE_LOG=<path>: per-(class, N, taps, Cin, operands) launch table written at process exit (tuning aid: which
 // layers land on which kernel)
 struct ShapeTot { long launches = 0; double rows = 0, flops = 0, bytes = 0; };
@@ -646,10 +648,9 @@ static void shape_log_dump() {
 }
 int prof_totals(int cls, double* flops, double* bytes, long long* launches) {
   if (cls < 0 || cls >= kNumTileCfg) return SS_ERR_ARG;
-  std::lock_guard<std::mutex> lk(g_tot_mu);
-  if (flops) *flops = g_prof_totals[cls].flops;
-  if (bytes) *bytes = g_prof_totals[cls].bytes;
-  if (launches) *launches = g_prof_totals[cls].launches;
+  if (flops) *flops = (double)g_prof_totals[cls].flops.load(std::memory_order_relaxed);
+  if (bytes) *bytes = (double)g_prof_totals[cls].bytes.load(std::memory_order_relaxed);
+  if (launches) *launches = (long long)g_prof_totals[cls].launches.load(std::memory_order_relaxed);
   return SS_OK;
 }
 static void algo_work(const GemmArgs& a, double& flops, double& bytes) {
@@ -665,10 +666,12 @@ int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, boo
   {
     double fl, by;
     algo_work(a, fl, by);
-    std::lock_guard<std::mutex> lk(g_tot_mu);
-    g_prof_totals[cls].flops += fl; g_prof_totals[cls].bytes += by; g_prof_totals[cls].launches += 1;
+    g_prof_totals[cls].flops.fetch_add((unsigned long long)(fl + 0.5), std::memory_order_relaxed);
+    g_prof_totals[cls].bytes.fetch_add((unsigned long long)(by + 0.5), std::memory_order_relaxed);
+    g_prof_totals[cls].launches.fetch_add(1ull, std::memory_order_relaxed);
     static const bool shape_log = getenv("SS_SHAPE_LOG") != nullptr;
     if (shape_log) {
+      std::lock_guard<std::mutex> lk(g_tot_mu);
       if (!g_shapes) { g_shapes = new std::map<ShapeKey, ShapeTot>(); atexit(shape_log_dump); }
       const int ops = (a.R ? 1 : 0) | (a.R2 ? 2 : 0) | (a.C2 ? 4 : 0) | (a.in_act != ACT_NONE ? 8 : 0) | (a.act != ACT_NONE ? 16 : 0) | (a.glu ? 32 : 0) | (a.nseg > 0 ? 64 : 0);
       ShapeTot& z = (*g_shapes)[ShapeKey(cls, a.N, a.taps, a.Cin, ops)];
@@ -735,6 +738,75 @@ static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
 static double g_sk_min_flops = 4e9;   // below this the small-tile kernels win (tools/conv_bench.py sk)
+// ---- stream-K workspaces (see gemm.hpp) -----------------------------------------------------------
+constexpr size_t SKW_SYNC_BYTES = (16 + 1024) * sizeof(unsigned) + 256;      // >= both kernels' flag tables
+static std::mutex g_skw_mu;
+static std::vector<SkWorkspace*> g_skw_live;                                 // for the error count only
+static std::map<std::pair<int, hipStream_t>, SkWorkspace*> g_skw_fallback;  // launches outside any context scope
+static thread_local SkWorkspace* t_skw = nullptr;
+
+SkWorkspace* sk_workspace_new() {
+  SkWorkspace* w = new SkWorkspace();
+  std::lock_guard<std::mutex> lk(g_skw_mu);
+  g_skw_live.push_back(w);
+  return w;
+}
+void sk_workspace_free(SkWorkspace* w) {
+  if (!w) return;
+  {
+    std::lock_guard<std::mutex> lk(g_skw_mu);
+    for (size_t i = 0; i < g_skw_live.size(); ++i)
+      if (g_skw_live[i] == w) { g_skw_live.erase(g_skw_live.begin() + i); break; }
+  }
+  if (w->ws) (void)hipFree(w->ws);
+  if (w->sync1) (void)hipFree(w->sync1);
+  if (w->sync2) (void)hipFree(w->sync2);
+  if (w->dbg) (void)hipFree(w->dbg);
+  delete w;
+}
+SkScope::SkScope(SkWorkspace* w) : prev(t_skw) { t_skw = w; }
+SkScope::~SkScope() { t_skw = prev; }
+
+int sk_workspace_acquire(hipStream_t stream, SkWorkspace** out) {
+  *out = nullptr;
+  int dev = 0;
+  SS_HIP_CHECK(hipGetDevice(&dev));
+  SkWorkspace* w = t_skw;
+  if (!w) {
+    std::lock_guard<std::mutex> lk(g_skw_mu);
+    SkWorkspace*& slot = g_skw_fallback[std::make_pair(dev, stream)];
+    if (!slot) { slot = new SkWorkspace(); g_skw_live.push_back(slot); }
+    w = slot;
+  }
+  if (!w->ws) {
+    int cus = 0;
+    SS_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (cus <= 0) cus = 256;
+    if (cus > 512) cus = 512;
+    w->dev = dev; w->cus = cus;
+    SS_HIP_CHECK(hipMalloc(&w->ws, (size_t)cus * 256 * 128 * sizeof(float)));
+    SS_HIP_CHECK(hipMalloc(&w->sync1, SKW_SYNC_BYTES));
+    SS_HIP_CHECK(hipMalloc(&w->sync2, SKW_SYNC_BYTES));
+    SS_HIP_CHECK(hipMemsetAsync(w->sync1, 0, SKW_SYNC_BYTES, stream));
+    SS_HIP_CHECK(hipMemsetAsync(w->sync2, 0, SKW_SYNC_BYTES, stream));
+  } else if (w->dev != dev) {
+    return SS_ERR_ARG;                 // a context belongs to the device it first ran on
+  }
+  *out = w;
+  return SS_OK;
+}
+
+int sk_workspace_error_count() {
+  std::lock_guard<std::mutex> lk(g_skw_mu);
+  int total = 0;
+  for (SkWorkspace* w : g_skw_live)
+    for (unsigned* sy : {w->sync1, w->sync2}) {
+      unsigned v = 0;
+      if (sy && hipMemcpy(&v, sy + 8, sizeof(v), hipMemcpyDeviceToHost) == hipSuccess) total += (int)v;
+    }
+  return total;
+}
+
 void debug_force_tile(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn; g_force_ks = ks; conv_sk_set_groups(bm == 1 && bn == 8); }
 
 bool smallm_eligible(const GemmArgs& a) {

@@ -69,6 +69,31 @@ struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int cls; };
 int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, bool& prof);
 int prof_end(hipStream_t stream, ProfRec& rec, bool prof);
 
+// Stream-K hand-off state (partial-tile workspace, ticket counter, per-workgroup flags) of ONE execution context: an
+// ss_model / ss_vocoder handle owns one and frees it with the handle; every C-ABI entry point opens an SkScope, and the
+// stream-K launchers take the scoped workspace of the calling thread (a context is driven by one host thread on one stream
+// at a time -- the C ABI's contract -- so nothing here needs a lock).  Launches outside any scope (ss_op_* unit-test entry
+// points) fall back to a process-wide table keyed by (device, stream).
+struct SkWorkspace {
+  int dev = -1, cus = 0;
+  float* ws = nullptr;                 // [cus] parked partial tiles of 128 KB (conv_sk2: 256 x 128, conv_sk: 2 x 128 x 128 per CU)
+  unsigned* sync1 = nullptr;           // conv_sk: ticket counters, time-out counter, flags
+  unsigned* sync2 = nullptr;           // conv_sk2
+  unsigned base1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, epoch1 = 0;
+  unsigned base2 = 0, epoch2 = 0;
+  unsigned long long* dbg = nullptr;   // diagnostic builds only
+};
+SkWorkspace* sk_workspace_new();
+void sk_workspace_free(SkWorkspace* w);
+struct SkScope {                       // RAII: the calling thread's stream-K launches use `w` until the scope ends
+  explicit SkScope(SkWorkspace* w);
+  ~SkScope();
+  SkWorkspace* prev;
+};
+// the workspace a launch on `stream` should use (scoped one, else the fallback entry), device memory allocated; nullptr + rc on failure
+int sk_workspace_acquire(hipStream_t stream, SkWorkspace** out);
+int sk_workspace_error_count();        // bounded-wait time-outs recorded by any live workspace (must stay 0)
+
 // Persistent stream-K conv-GEMM (conv_sk.hip): 128 x BN tiles, the (tile, k-step) space is cut into
 // equal contiguous ranges, one per resident workgroup, so every CU gets the same MFMA work whatever
 // the tile count.  g_force > 0 fixes the grid size (tuning hook).

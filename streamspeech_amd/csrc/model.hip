@@ -114,6 +114,7 @@ struct DecLayer {
 struct ss_model {
   ss_config cfg;
   WeightTable wt;
+  SkWorkspace* skws = nullptr;       // stream-K hand-off state of this context (freed with the handle)
   // encoder
   Lin sub0, sub1, enc_linear, ctc_asr, ctc_st;
   std::vector<EncLayer> enc;
@@ -193,8 +194,10 @@ extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t
   if (cfg->enc_dim / cfg->enc_heads != 64 || cfg->dec_dim / cfg->dec_heads != 64) return SS_ERR_ARG;
   ss_model* m = new ss_model();
   m->cfg = *cfg;
+  m->skws = sk_workspace_new();
+  SkScope sk_scope(m->skws);       // the pos_proj GEMM below may take a stream-K kernel
   int rc = m->wt.build(d_blob, blob_floats, names, offsets, numels, n_slots);
-  if (rc != SS_OK) { delete m; return rc; }
+  if (rc != SS_OK) { sk_workspace_free(m->skws); delete m; return rc; }
   WeightTable& w = m->wt;
   const int d = cfg->enc_dim, f = cfg->enc_ffn, D = cfg->dec_dim, F = cfg->dec_ffn, k = cfg->conv_kernel;
   const int Tm = cfg->max_rel_pos;
@@ -244,7 +247,7 @@ extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t
   m->unit_ln = {w.get("unit.ln.g", D), w.get("unit.ln.b", D)};
   m->unit_out = {w.get("unit.out.w", (int64_t)cfg->unit_vocab * D), nullptr};
   m->unit_pos_row = w.get("unit.pos_row", D);
-  if (!w.missing.empty()) { delete m; return SS_ERR_MISSING_WEIGHT; }
+  if (!w.missing.empty()) { sk_workspace_free(m->skws); delete m; return SS_ERR_MISSING_WEIGHT; }
 
   // projected rel-pos table for every layer at once: [2Tm-1, d] x [L*d, d]^T (linear_pos has no
   // bias, espnet_multihead_attention.py:125).  Depends only on the relative offset, so it is
@@ -271,6 +274,7 @@ extern "C" void ss_model_destroy(ss_model* m) {
   m->mt_tok.release(); m->seg_buf.release(); m->bmt_self.release();
   m->es_qkv.release(); m->es_glu.release(); m->es_out.release();
   if (m->mt_tok_host) (void)hipHostFree(m->mt_tok_host);
+  sk_workspace_free(m->skws);
   delete m;
 }
 
@@ -307,6 +311,7 @@ extern "C" int ss_encoder_out_len(int T) {
 extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
                                   int conv_chunk, float* d_enc_out) {
   if (!m || T <= 0) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int d = c.enc_dim, f = c.enc_ffn, k = c.conv_kernel, Ld = c.enc_layers * d;
@@ -426,6 +431,7 @@ extern "C" int ss_encoder_stream_set_tail(ss_model* m, int unsettled_fbank_frame
 extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
                                          int conv_chunk, float* d_enc_out, int32_t* n_final, int32_t* n_computed) {
   if (!m || T <= 0) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int d = c.enc_dim, f = c.enc_ffn, k = c.conv_kernel, Ld = c.enc_layers * d, L = c.enc_layers;
@@ -525,6 +531,7 @@ extern "C" int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d
                              int32_t* d_raw, int32_t* d_tokens, int32_t* d_index, int32_t* d_count,
                              float* d_logits) {
   if (!m || Tp <= 0 || head < 0 || head > 1) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int V = head == 0 ? c.src_vocab : c.tgt_vocab;
@@ -579,6 +586,7 @@ static int dec_layer(hipStream_t s, const ss_config& c, const DecLayer& L, float
 
 extern "C" int ss_mt_begin(ss_model* m, void* stream, const float* d_enc_out, int Tp) {
   if (!m || Tp <= 0) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int D = c.dec_dim;
@@ -601,6 +609,7 @@ extern "C" int ss_mt_truncate(ss_model* m, int len) {
 extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, int n, int pos0, int ban_eos,
                             int force_eos, float* d_feats, int32_t* d_next, int n_tail_pad) {
   if (!m || n <= 0 || pos0 < 0 || pos0 > m->mt_len || m->mt_Tp <= 0) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   const ss_config& c = m->cfg;
   if (pos0 + n + 2 > c.max_tgt_pos) return SS_ERR_CAPACITY;
   hipStream_t s = (hipStream_t)stream;
@@ -638,6 +647,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
                             float* d_feats, int* h_n_feats) {
   if (!m || !d_enc_out || Tp <= 0 || n_prefix < 0 || max_len < n_prefix || !h_out_tokens || !h_n_out || !d_feats)
     return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   const ss_config& c = m->cfg;
   if (max_len + 3 > c.max_tgt_pos) return SS_ERR_CAPACITY;
   hipStream_t s = (hipStream_t)stream;
@@ -682,6 +692,7 @@ extern "C" int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, 
                             int mask_eos, int32_t* d_raw, int32_t* d_tokens, int32_t* d_count, float* d_logits,
                             int n_tail_pad) {
   if (!m || n <= 0) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int D = c.dec_dim, F = c.dec_ffn, U = n * c.ctc_upsample, V = c.unit_vocab;
@@ -724,6 +735,7 @@ struct ConvW { const float* w = nullptr; const float* b = nullptr; };
 struct ss_vocoder {
   ss_vocoder_config cfg;
   WeightTable wt;
+  SkWorkspace* skws = nullptr;       // stream-K hand-off state of this context (freed with the handle)
   const float* dict = nullptr;
   ConvW dur_c1, dur_c2, dur_proj, pre, post;
   LN dur_ln1, dur_ln2;
@@ -739,8 +751,9 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
   if (!cfg || !d_blob || !out || cfg->n_up > 8 || cfg->n_res > 4) return SS_ERR_ARG;
   ss_vocoder* v = new ss_vocoder();
   v->cfg = *cfg;
+  v->skws = sk_workspace_new();
   int rc = v->wt.build(d_blob, blob_floats, names, offsets, numels, n_slots);
-  if (rc != SS_OK) { delete v; return rc; }
+  if (rc != SS_OK) { sk_workspace_free(v->skws); delete v; return rc; }
   WeightTable& w = v->wt;
   const int E = cfg->embedding_dim, Hd = cfg->dur_hidden, kd = cfg->dur_kernel;
   v->dict = w.get("voc.dict", (int64_t)cfg->num_embeddings * E);
@@ -769,7 +782,7 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
     C = Co;
   }
   v->post = {w.get("voc.post.w", (int64_t)7 * C), w.get("voc.post.b", 1)};
-  if (!w.missing.empty()) { delete v; return SS_ERR_MISSING_WEIGHT; }
+  if (!w.missing.empty()) { sk_workspace_free(v->skws); delete v; return SS_ERR_MISSING_WEIGHT; }
   *out = v;
   return SS_OK;
 }
@@ -783,6 +796,7 @@ extern "C" int ss_vocoder_set_bf16x3(ss_vocoder* v, int on) {
 extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
   if (!v) return;
   v->ws.release(); v->small.release(); v->segs.release();
+  sk_workspace_free(v->skws);
   delete v;
 }
 
@@ -907,6 +921,7 @@ extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_
                                   const int32_t* d_forced_dur, float* d_wav, int64_t wav_capacity,
                                   int32_t* d_dur, int64_t* h_n_samples) {
   if (!v || K <= 0 || !d_codes || !d_wav || !d_dur) return SS_ERR_ARG;
+  SkScope sk_scope(v->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_vocoder_config& c = v->cfg;
   const int E = c.embedding_dim, Hd = c.dur_hidden;
@@ -1017,6 +1032,7 @@ extern "C" int ss_batch_fbank_cmvn(ss_model* m, void* stream, int B, const float
 extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const float* d_fbank, const int32_t* h_T,
                                         int attn_chunk, int conv_chunk, float* d_enc_out, int32_t* h_Tp) {
   if (!m || B <= 0) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int d = c.enc_dim, f = c.enc_ffn, k = c.conv_kernel, Ld = c.enc_layers * d;
@@ -1096,6 +1112,7 @@ extern "C" int ss_batch_ctc_greedy(ss_model* m, void* stream, int head, int B, c
                                    const int32_t* h_Tp, int32_t* d_raw, int32_t* d_tokens, int32_t* d_index,
                                    int32_t* d_counts) {
   if (!m || B <= 0 || head < 0 || head > 1) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const Offsets o = prefix(h_Tp, B);
@@ -1117,6 +1134,7 @@ extern "C" int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float*
                                   const int32_t* h_max_len, int min_len, int32_t* h_out_tokens, int out_stride,
                                   int32_t* h_n_out, float* d_feats, int feat_rows) {
   if (!m || B <= 0 || B > 128 || !d_feats) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int D = c.dec_dim, F = c.dec_ffn, V = c.tgt_vocab, H = c.dec_heads;
@@ -1209,6 +1227,7 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
                                   const int32_t* h_n, int t2u_causal, int mask_eos, int32_t* d_raw, int32_t* d_tokens,
                                   int32_t* d_counts) {
   if (!m || B <= 0) return SS_ERR_ARG;
+  SkScope sk_scope(m->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int D = c.dec_dim, F = c.dec_ffn, V = c.unit_vocab, H = c.dec_heads, up = c.ctc_upsample;
@@ -1273,6 +1292,7 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
                                         int64_t wav_capacity, int32_t* d_dur, int64_t* h_wav_start,
                                         int64_t* h_n_samples) {
   if (!v || B <= 0 || !d_codes || !d_wav || !d_dur) return SS_ERR_ARG;
+  SkScope sk_scope(v->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_vocoder_config& c = v->cfg;
   const int E = c.embedding_dim, Hd = c.dur_hidden;

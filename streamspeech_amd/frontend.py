@@ -26,6 +26,21 @@ def design_filter(up: int, down: int) -> np.ndarray:
     return h / h.sum() * up
 
 
+def unsettled_fbank_frames(sr_in: int, sr_out: int = 16000, shift_samples: int = 160) -> int:
+    """How many of the newest fbank frames may still change when more audio arrives: the resampler's output samples whose
+    FIR window reaches past the end of the received input (zero-padded there) are recomputed on the next call -- that edge
+    is half_len / down output samples of design_filter's low-pass -- and every fbank frame that overlaps it is unsettled.
+    0 when nothing is resampled.  (ss_encoder_stream_set_tail: such frames must not be cached as final.)"""
+    import math
+    g = math.gcd(int(sr_in), int(sr_out))
+    up, down = int(sr_out) // g, int(sr_in) // g
+    if up == down:
+        return 0
+    half_len = (len(design_filter(up, down)) - 1) // 2
+    edge = math.ceil(half_len / down)                       # output samples that still see zero padding
+    return max(1, math.ceil(edge / shift_samples))
+
+
 def read_wav(path: str):
     """PCM WAV (8/16/32-bit integer) -> (float32 mono samples in [-1, 1), sample rate): the `list[float]`
     the SimulEval dataloader hands the agent (SimulEval/simuleval/data/dataloader/s2t_dataloader.py).
@@ -74,22 +89,30 @@ class OnlineFeatureExtractor:
         self._np = np.zeros(0, np.float32)
         self._dev = None
         self._n_dev = 0
+        self._src_id = None
 
     def _samples(self, samples, n):
         """float32 array of samples[:n].  SimulEval hands the WHOLE sample history as a Python list at every policy() call
         (states.source only grows within an utterance); converting 15 s of floats costs ~10 ms per call, so only the new
-        tail is converted and the rest comes from the cache.  The cache is dropped when the history does not extend it
-        (new utterance / reset): length shrank, or a spot check of cached values fails."""
+        tail is converted and the rest comes from the cache.  The cache belongs to ONE source list: it is dropped when
+        another list object comes in (AgentStates.reset() starts a new list, SimulEval/simuleval/agents/states.py), when
+        the history shrank, or when a spot check of eight cached values (compared as float32, the cache's type) fails.
+        The agents also call clear_cache() in reset(); a caller that reuses an extractor for unrelated audio must do the same."""
         c = getattr(self, "_np", None)
         if c is None:
             self.clear_cache()
             c = self._np
         k = len(c)
-        ok = k <= n and (k == 0 or (float(samples[0]) == float(c[0]) and np.float32(samples[k - 1]) == c[k - 1]
-                                    and np.float32(samples[k // 2]) == c[k // 2]))
+        ok = k <= n and (k == 0 or getattr(self, "_src_id", None) == id(samples))
+        if ok and k:
+            for i in {0, k - 1, k // 2, k // 3, k // 5, (2 * k) // 3, (4 * k) // 5, k // 7}:
+                if np.float32(samples[i]) != c[i]:
+                    ok = False
+                    break
         if not ok:
             self.clear_cache()
             c, k = self._np, 0
+        self._src_id = id(samples)
         if n > k:
             c = np.concatenate([c, np.asarray(samples[k:n], dtype=np.float32)])
             self._np = c

@@ -11,13 +11,27 @@ fraction per kernel (mean over its launches).
 Units: the counters report KB.  gfx950 correction (guide): FETCH_SIZE counts 128-B requests as 64 B
 for wide coalesced reads -> HBM read bytes ~= 2 * FETCH_SIZE * 1024; WRITE_SIZE is taken as is."""
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
 from collections import defaultdict
 
+
+def csrc_sha16():
+    """Hash of the kernel sources the profiled library was built from (bench.py compares it with the running build's)."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "streamspeech_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".hpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
 CLASSES = [("void ss::conv_sk2_kernel", "conv_sk2<256,128,32>"), ("void ss::conv_sk2_kernel", "conv_sk2_bf16x3<256,128,32>"), ("void ss::conv_sk_kernel", "conv_sk<128,BN,32>"), ("void ss::conv_slab_kernel<32", "conv_slab<32>"),
            ("void ss::conv_slab_kernel<16", "conv_slab<16>"),
+           ("void ss::resblock_fused_kernel<32", "resblock_fused<32>"), ("void ss::resblock_fused_kernel<16", "resblock_fused<16>"),
            ("void ss::conv_gemm_kernel<32, 64, 32", "conv_gemm<32,64,32,2,2>"), ("void ss::conv_gemm_kernel<32, 32, 32", "conv_gemm<32,32,32,2,2>"),
            ("void ss::conv_gemm_kernel<128, 32, 32", "conv_gemm<128,32,32,4,1>"), ("void ss::conv_gemm_kernel<128, 16, 16", "conv_gemm<128,16,16,4,1>"),
            ("void ss::smallm_gemm_kernel<4, 1", "smallm_gemm<4,1>")]
@@ -77,7 +91,8 @@ def main():
                 c["traffic_over_algorithmic"] = round(c["hbm_mbytes_per_launch_corrected"] / c["algo_mbytes_per_launch"], 3)
                 c["algo_gflop_per_launch"] = round(z["algo_tflop"] * 1e3 / z["launches"], 3)
     top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_mbytes_per_launch_corrected"] * kv[1]["launches"])[:16])
-    json.dump({"note": sys.argv[4] if len(sys.argv) > 4 else "", "classes": classes, "kernels": top}, open(sys.argv[3], "w"), indent=1)
+    json.dump({"note": sys.argv[4] if len(sys.argv) > 4 else "", "csrc_sha16": csrc_sha16(), "classes": classes, "kernels": top},
+              open(sys.argv[3], "w"), indent=1)
     print(json.dumps(classes, indent=1))
 
 

@@ -1,6 +1,6 @@
 """Where a conv_sk2 launch spends its cycles, per workgroup (diagnostic build -DK2_TIMING=1: thread 0 of every workgroup
 accumulates s_memtime cycles per phase).  python tools/sk2_timing.py   with SS_HIP_LIB=tools/libss_k2timing.so
-(SS_EXTRA_FLAGS=-DK2_TIMING=1 SS_BUILD_DIR=build/k2timing SS_OUT_LIB=../../tools/libss_k2timing.so bash streamspeech_amd/csrc/build.sh)"""
+(SS_EXTRA_FLAGS="-DK2_DIAGNOSTIC_BUILD -DK2_TIMING=1" SS_BUILD_DIR=build/k2timing SS_OUT_LIB=../../tools/libss_k2timing.so bash streamspeech_amd/csrc/build.sh)"""
 import ctypes as C
 import os
 import sys
