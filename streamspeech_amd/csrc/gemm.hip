@@ -815,7 +815,10 @@ bool smallm_eligible(const GemmArgs& a) {
   const bool plain_linear = a.taps == 1 && a.stride == 1 && a.pad == 0 && !a.glu && a.nseg == 0 && a.chunk == 0 &&
                             a.in_act == ACT_NONE && !a.R2 && !a.C2 && a.div == 0.f &&
                             (a.act == ACT_NONE || a.act == ACT_SILU || a.act == ACT_RELU);
-  return plain_linear && M <= 128 && M > 0 && a.Cin % 64 == 0 && (a.lda & 3) == 0;
+  // row limit of the no-LDS kernel: every 16-row tile re-streams its W columns from L2, so it only pays while the whole
+  // problem is latency-bound (SS_SMALLM_MAX_ROWS: tuning knob, tools/latency_breakdown.py)
+  static const int max_rows = getenv("SS_SMALLM_MAX_ROWS") ? atoi(getenv("SS_SMALLM_MAX_ROWS")) : 128;
+  return plain_linear && M <= max_rows && M > 0 && a.Cin % 64 == 0 && (a.lda & 3) == 0;
 }
 
 
