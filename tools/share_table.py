@@ -1,0 +1,47 @@
+"""Kernel-time share against algorithmic-FLOP share per kernel class of ONE process: a rocprofv3 kernel-stats CSV and the
+`process_census` of the bench.py line that process printed (the census counts the algorithmic FLOPs of exactly the launches
+the profile saw).  A class whose time share is far above its FLOP share is the one running below the others' efficiency.
+    python tools/share_table.py <kernel_stats.csv> <bench.json> > table.md"""
+import csv
+import json
+import sys
+
+# profiler class (bench.py process_census key) -> kernel-name prefixes of the profile
+CLASSES = [("conv_sk2<256,128,32>", ["void ss::conv_sk2_kernel"]),
+           ("conv_sk<128,BN,32>", ["void ss::conv_sk_kernel"]),
+           ("conv_slab<32>", ["void ss::conv_slab_kernel<32", "void ss::conv_pair_kernel<32", "void ss::resblock_fused_kernel<32"]),
+           ("conv_slab<16>", ["void ss::conv_slab_kernel<16", "void ss::conv_pair_kernel<16", "void ss::resblock_fused_kernel<16"]),
+           ("conv_gemm<32,64,32,2,2>", ["void ss::conv_gemm_kernel<32, 64, 32"]),
+           ("conv_gemm<32,32,32,2,2>", ["void ss::conv_gemm_kernel<32, 32, 32"]),
+           ("conv_gemm<32,64,16,2,2>", ["void ss::conv_gemm_kernel<32, 64, 16"]),
+           ("conv_gemm<128,32,32,4,1>", ["void ss::conv_gemm_kernel<128, 32, 32"]),
+           ("conv_gemm<128,16,16,4,1>", ["void ss::conv_gemm_kernel<128, 16, 16"]),
+           ("smallm_gemm<4,1>", ["void ss::smallm_gemm_kernel<4, 1"]),
+           ("smallm_gemm<2,2>", ["void ss::smallm_gemm_kernel<2, 2"]),
+           ("smallm_gemm<1,4>", ["void ss::smallm_gemm_kernel<1, 4"])]
+
+
+def main():
+    rows = list(csv.DictReader(open(sys.argv[1])))
+    census = json.load(open(sys.argv[2]))["process_census"]
+    total_ns = sum(float(r["TotalDurationNs"]) for r in rows)
+    total_tf = sum(c["algo_tflop"] for c in census.values())
+    print("| kernel class | launches | kernel time ms | share of kernel time | algorithmic TFLOP | share of FLOPs | TFLOP/s | of 157.3 |")
+    print("|---|---|---|---|---|---|---|---|")
+    seen = 0.0
+    for cls, prefixes in CLASSES:
+        rs = [r for r in rows if any(r["Name"].startswith(p) for p in prefixes)]
+        if not rs or cls not in census:
+            continue
+        ns = sum(float(r["TotalDurationNs"]) for r in rs)
+        seen += ns
+        tf = census[cls]["algo_tflop"]
+        print(f"| `{cls}` | {sum(int(r['Calls']) for r in rs)} | {ns / 1e6:.1f} | {100 * ns / total_ns:.1f} % | {tf:.2f} | {100 * tf / total_tf:.1f} % | "
+              f"{tf / (ns * 1e-9):.1f} | {tf / (ns * 1e-9) / 157.3:.2f} |")
+    print(f"| everything else (attention, LayerNorm, depthwise conv, argmax, fbank, GEMVs, copies) | | {(total_ns - seen) / 1e6:.1f} | "
+          f"{100 * (total_ns - seen) / total_ns:.1f} % | | | | |")
+    print(f"| **all kernels** | | {total_ns / 1e6:.1f} | 100 % | {total_tf:.2f} | 100 % | {total_tf / (total_ns * 1e-9):.1f} | {total_tf / (total_ns * 1e-9) / 157.3:.2f} |")
+
+
+if __name__ == "__main__":
+    main()
