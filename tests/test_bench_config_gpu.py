@@ -126,5 +126,8 @@ def test_timed_step_matches_oracle_on_8_streams(hip_model, hip_vocoder, synth_we
             assert durs == [d for u in utts for d in u.durations]
     fb_rms = (fb_sq / fb_n) ** 0.5
     assert worst["fbank"] < 5e-3 and fb_rms < 1e-4, (worst, fb_rms)
+    if worst["rms"] >= 1e-4:     # observed ~1e-6: report a regression that the north-star bar (1e-3) would let through
+        import warnings
+        warnings.warn(f"bench-config waveform RMS {worst['rms']:.2e} is past the tight bar 1e-4 (north-star bar 1e-3 still met)")
     print(f"bench-config parity: 96 utterances, {n_pos_total} unit positions, {n_units_total} vocoder units, "
           f"worst fbank err {worst['fbank']:.2e} (rms {fb_rms:.2e}), worst wav rms {worst['rms']:.2e}")

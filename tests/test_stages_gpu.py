@@ -15,6 +15,16 @@ pytestmark = pytest.mark.gpu
 ENC_TOL = 5e-4       # encoder_out abs error after 12 conformer layers (values are O(1) post-LN)
 FEAT_TOL = 5e-4      # decoder feature abs error
 WAV_RMS_TOL = 1e-3   # north_star: vocoder waveform within 1e-3 RMS per sample
+# What is actually observed is 50-1000x tighter (encoder ~1e-5, features ~1e-5, waveform RMS ~1e-6: pure summation-order
+# noise).  A regression that stays inside the bars above but leaves that regime (a wrong summation tree, a dropped term of
+# 1e-4 relative size) is REPORTED through these second, tight bars: a warning in the test log, not a failure.
+ENC_TIGHT, FEAT_TIGHT, WAV_RMS_TIGHT = 5e-5, 5e-5, 1e-4
+
+
+def _tight(value, bar, what):
+    import warnings
+    if value >= bar:
+        warnings.warn(f"{what}: {value:.3e} is past the tight bar {bar:.0e} (hard bar still met) -- look at the summation order", stacklevel=2)
 
 
 def _gold(golden_dir, name):
@@ -32,6 +42,7 @@ def test_encoder_vs_reference_golden(hip_model, golden_dir, tag, ac, cc):
     assert out.shape == ref.shape
     err = np.abs(out - ref).max()
     assert np.isfinite(out).all() and err < ENC_TOL, f"encoder {tag}: max abs err {err}"
+    _tight(err, ENC_TIGHT, f"encoder {tag} vs reference golden")
 
 
 @pytest.mark.parametrize("T,ac,cc", [(435, 999999, 999999), (435, 8, 8), (1203, 999999, 999999), (31, 8, 8), (9, 8, 8)])
@@ -45,6 +56,7 @@ def test_encoder_vs_oracle(hip_model, synth_weights, T, ac, cc):
     assert out.shape == ref.shape
     err = np.abs(out - ref).max()
     assert err < ENC_TOL, f"T={T} chunk={ac}: {err}"
+    _tight(err, ENC_TIGHT, f"encoder T={T} chunk={ac} vs oracle")
 
 
 @pytest.mark.parametrize("tag", ["offline", "c8"])
@@ -66,6 +78,7 @@ def test_mt_decoder_features_and_greedy(hip_model, golden_dir):
     feats, _ = hip_model.mt_append(toks, 0, ban_eos=False, force_eos=False, want_next=False)
     err = np.abs(feats.cpu().numpy() - gd["mt_features"]).max()
     assert err < FEAT_TOL, f"mt features: {err}"
+    _tight(err, FEAT_TIGHT, "mt features")
     # incremental (KV cache) decoding must give the same features as the one-shot pass
     hip_model.mt_begin(enc)
     f1, _ = hip_model.mt_append(toks[:4], 0, False, False, want_next=False)
@@ -134,6 +147,7 @@ def test_vocoder_vs_reference_golden(hip_vocoder, golden_dir):
     assert dur1.cpu().tolist() == [1] * len(g["codes"])
     rms1 = float(np.sqrt(np.mean((wav1.cpu().numpy() - g["wav_nodur"]) ** 2)))
     assert rms1 < WAV_RMS_TOL, f"rms {rms1}"
+    _tight(rms1, WAV_RMS_TIGHT, "vocoder vs reference golden")
 
 
 def test_vocoder_long_vs_oracle(hip_vocoder, synth_weights):
@@ -147,6 +161,7 @@ def test_vocoder_long_vs_oracle(hip_vocoder, synth_weights):
     assert dur.cpu().tolist() == rd.tolist()
     rms = float(torch.sqrt(torch.mean((wav.cpu() - rw) ** 2)))
     assert rms < WAV_RMS_TOL, f"rms {rms}"
+    _tight(rms, WAV_RMS_TIGHT, "waveform rms")
 
 
 def test_fbank_cmvn_vs_oracle(hip_model, golden_dir):
@@ -180,6 +195,7 @@ def test_offline_utterance_units_and_wav(hip_model, hip_vocoder, synth_weights):
     assert out["dur"].cpu().tolist() == ref["dur"].tolist()
     rms = float(torch.sqrt(torch.mean((out["wav"].cpu() - ref["wav"]) ** 2)))
     assert rms < WAV_RMS_TOL, f"rms {rms}"
+    _tight(rms, WAV_RMS_TIGHT, "waveform rms")
 
 
 @pytest.mark.parametrize("segment_ms", [320, 640])
@@ -213,6 +229,7 @@ def test_streaming_agent_matches_oracle_agent(hip_model, hip_vocoder, synth_weig
     assert w_hip.shape == w_ora.shape
     rms = float(np.sqrt(np.mean((w_hip - w_ora) ** 2)))
     assert rms < WAV_RMS_TOL, f"rms {rms}"
+    _tight(rms, WAV_RMS_TIGHT, "waveform rms")
     # second utterance through the same agents (longer, different audio): reset() drops the encoder cache
     pcm2 = synth.synth_pcm(18, int(16000 * 3.3))
     w2_hip, a2_hip = stream(hip_agent, pcm2, segment_ms)
@@ -340,3 +357,4 @@ def test_offline_parity_sweep_vs_oracle(hip_model, hip_vocoder, synth_weights, s
         assert out["dur"].cpu().tolist() == ref["dur"].tolist()
         rms = float(torch.sqrt(torch.mean((out["wav"].cpu() - ref["wav"]) ** 2)))
         assert rms < WAV_RMS_TOL, f"rms {rms}"
+    _tight(rms, WAV_RMS_TIGHT, "waveform rms")
