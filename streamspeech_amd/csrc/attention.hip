@@ -186,6 +186,13 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(AttnArgs p) {
   for (int j0 = wave * 64; j0 < kmax; j0 += 256) {
     const int j = j0 + lane;
     const bool vis = j < kmax;
+    // The tile's V rows are requested BEFORE its scores are formed (their addresses do not depend on the scores), so the
+    // kernel pays one memory latency per tile instead of two -- it is launched ~8 times per MT decode step, each a link
+    // of a dependent chain.  Rows past the last visible key are clamped to it: their probability is exactly 0, and
+    // fmaf(0, v, acc) == acc, so the sum is the one the 16-row groups of the earlier form produced.
+    float vv[64];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) vv[u] = p.V[(size_t)min(j0 + u, kmax - 1) * p.ldv + hoff + lane];
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (vis) {
       const float4* kr = reinterpret_cast<const float4*>(p.K + (size_t)j * p.ldk + hoff);
@@ -203,15 +210,8 @@ __global__ __launch_bounds__(256) void attention_decode_kernel(AttnArgs p) {
     l_run = l_run * corr + wave_sum(pe);
     acc *= corr;
     m_run = mn;
-    const int cnt = min(64, kmax - j0);
-    for (int jj0 = 0; jj0 < cnt; jj0 += 16) {   // 16 independent row loads in flight, then the FMAs
-      float vv[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u)
-        vv[u] = (jj0 + u < cnt) ? p.V[(size_t)(j0 + jj0 + u) * p.ldv + hoff + lane] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc = fmaf(rdlane(pe, jj0 + u), vv[u], acc);
-    }
+    for (int u = 0; u < 64; ++u) acc = fmaf(rdlane(pe, u), vv[u], acc);
   }
   if (lane == 0) { part_m[wave] = m_run; part_l[wave] = l_run; }
   part_acc[wave][lane] = acc;

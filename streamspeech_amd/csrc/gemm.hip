@@ -737,7 +737,7 @@ static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
 }
 
 static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
-static double g_sk_min_flops = 4e9;   // below this the small-tile kernels win (tools/conv_bench.py sk)
+static double g_sk_min_flops = getenv("SS_SK_MIN_GFLOP") ? 1e9 * atof(getenv("SS_SK_MIN_GFLOP")) : 4e9;   // below this the small-tile kernels win (tools/conv_bench.py sk; SS_SK_MIN_GFLOP: tuning knob)
 // ---- stream-K workspaces (see gemm.hpp) -----------------------------------------------------------
 constexpr size_t SKW_SYNC_BYTES = (16 + 1024) * sizeof(unsigned) + 256;      // >= both kernels' flag tables
 static std::mutex g_skw_mu;
