@@ -529,6 +529,9 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemmArgs p) {
           const f32x4 bt = *reinterpret_cast<const f32x4*>(p.ln_b + k0 + it * 256 + 4 * lane);
 #pragma unroll
           for (int e = 0; e < 4; ++e) x[e] = (x[e] - mean) * rstd * gm[e] + bt[e];
+          // the waves of column 0 cover the whole row between them: they also publish the normalised row
+          if (p.ln_out && blockIdx.x == 0 && wave < KS)
+            *reinterpret_cast<f32x4*>(p.ln_out + (size_t)m * K + k0 + it * 256 + 4 * lane) = x;
         }
         a0 = fmaf(x[0], wv[it][0], a0); a1 = fmaf(x[1], wv[it][1], a1);
         a2 = fmaf(x[2], wv[it][2], a2); a3 = fmaf(x[3], wv[it][3], a3);
@@ -831,6 +834,7 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   const bool k32 = (a.Cin % 32) == 0;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   if (!g_force_bm && gemv_eligible(a)) return launch_gemv(a, stream);
+  if (a.ln_out) return SS_ERR_ARG;      // only the GEMV form publishes the normalised rows
   if (smallm_eligible(a)) {
     const long wgs16 = (long)cdiv(M, 16) * cdiv(a.N, 16);
     if (a.Cin >= 1024 || wgs16 <= 1024) return launch_smallm<4, 1>(a, stream, 12);

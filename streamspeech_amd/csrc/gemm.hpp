@@ -47,6 +47,8 @@ struct GemmArgs {
   // A' = (A - mean) * rstd * ln_g + ln_b, eps 1e-5 -- saves the separate LayerNorm launch.
   const float* ln_g = nullptr;
   const float* ln_b = nullptr;
+  float* ln_out = nullptr;    // gemv path only (M <= 4): the normalised rows are also written here (row stride Cin) -- the MT
+                              // decode step's final LayerNorm feeds both the vocabulary projection and the returned features
   // 1: the caller guarantees a "same" row mapping -- stride 1, output row m reads input rows
   // m - pad + j*dil of the same packed buffer, segments (if any) are contiguous with
   // out_start == in_start and out_len == in_len.  Makes the launch eligible for the persistent
@@ -127,6 +129,8 @@ int launch_resblock_fused(const float* X, int ldx, const float* const* W1, const
                           const float* const* B2, const int* dil, float* Y, int ldy, const float* R2, int ldr2, float div, int C,
                           int taps, int M, float slope, const int* segs, int nseg, hipStream_t stream);
 
+// True when launch_conv_gemm would route `a` to the decode GEMV (M <= 4 rows; the only form that honours ln_out).
+bool gemv_eligible(const GemmArgs& a);
 // True when launch_conv_gemm would route `a` to the small-M kernel (the only one with the fused
 // LayerNorm prologue).
 bool smallm_eligible(const GemmArgs& a);

@@ -63,6 +63,7 @@ struct Lin { const float* w = nullptr; const float* b = nullptr; };
 struct LN { const float* g = nullptr; const float* b = nullptr; };
 
 #define RET(x) do { int _r = (x); if (_r != SS_OK) return _r; } while (0)
+static const int g_no_mt_ln_fusion = getenv("SS_NO_MT_LN_FUSION") ? atoi(getenv("SS_NO_MT_LN_FUSION")) : 0;   // A/B knob: separate final LayerNorm launch in the MT decode step
 
 int linear(hipStream_t s, const float* A, int lda, int M, const Lin& l, int N, int K, float* C, int ldc,
            int act = ACT_NONE, float alpha = 1.f, const float* R = nullptr, int ldr = 0, int glu = 0) {
@@ -629,10 +630,17 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
     RET(dec_layer(s, c, m->mt[l], x, n, pos0, selfbuf, true, cross, m->mt_Tp, h, q2, ff, n_tail_pad, 0));
   }
   float* fo = d_feats ? d_feats : feats;
-  RET(launch_layernorm(x, D, fo, D, m->mt_ln.g, m->mt_ln.b, n, D, 1e-5f, s));
   m->mt_len = pos0 + n;
+  Lin proj{m->mt_emb, nullptr};  // tied output projection, no bias
+  GemmArgs g;                    // decode step (one new token): final LayerNorm in the prologue of the vocabulary GEMV,
+  g.A = x; g.lda = D; g.W = proj.w; g.C = logits; g.ldc = V; g.M = 1; g.N = V; g.Cin = D; g.in_len = 1; g.same_rows = 1;
+  g.ln_g = m->mt_ln.g; g.ln_b = m->mt_ln.b; g.ln_out = fo;   // which also writes the features row: one launch fewer per step
+  if (n == 1 && d_next && gemv_eligible(g) && D <= 512 && !g_no_mt_ln_fusion) {
+    RET(launch_conv_gemm(g, s));
+    return launch_masked_argmax(logits, V, 1, V, c.pad, ban_eos ? c.eos : -1, -1, force_eos ? c.eos : -1, d_next, s);
+  }
+  RET(launch_layernorm(x, D, fo, D, m->mt_ln.g, m->mt_ln.b, n, D, 1e-5f, s));
   if (d_next) {
-    Lin proj{m->mt_emb, nullptr};  // tied output projection, no bias
     RET(linear(s, fo + (size_t)(n - 1) * D, D, 1, proj, V, D, logits, V));
     RET(launch_masked_argmax(logits, V, 1, V, c.pad, ban_eos ? c.eos : -1, -1, force_eos ? c.eos : -1, d_next, s));
   }
