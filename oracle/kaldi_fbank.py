@@ -1,11 +1,16 @@
 """CPU ORACLE (test infrastructure): Kaldi-compatible log-mel filterbank + global CMVN.
 
-PARITY UNPINNED: the arithmetic lives in ``torchaudio.compliance.kaldi.fbank`` (third party,
-pinned only as torchaudio>=0.8.0 by the reference's fairseq/setup.py:190; README env
-PyTorch 2.0.1 => torchaudio 2.0.x), which is NOT vendored under /root/reference and not
-installed in this image.  This restates the published Kaldi/torchaudio algorithm for the
-arguments the reference passes (fairseq/data/audio/audio_utils.py:241-247:
-num_mel_bins=80, sample_frequency=16000, everything else default) -- SURVEY.md Appendix C.
+The arithmetic lives in ``torchaudio.compliance.kaldi.fbank`` (third party, pinned only as
+torchaudio>=0.8.0 by the reference's fairseq/setup.py:190; README env PyTorch 2.0.1 =>
+torchaudio 2.0.x), which is NOT vendored under /root/reference and not installable in this
+image.  This restates the published Kaldi/torchaudio algorithm for the arguments the reference
+passes (fairseq/data/audio/audio_utils.py:241-247: num_mel_bins=80, sample_frequency=16000,
+everything else default) -- SURVEY.md Appendix C.
+PINNED (round 3) against an independent third-party implementation of the same algorithm with the
+same arguments: transformers' SeamlessM4TFeatureExtractor numpy path ("to mimic Kaldi", checked
+upstream against torchaudio.compliance.kaldi.fbank) -- oracle/make_golden_fbank.py ->
+tests/golden/kaldi_fbank_hf.npz, tests/test_oracle_golden.py (max 1.5e-4, RMS 1-3e-6 on log-mel
+values ~20).  NOT pinned against torchaudio's own code: that needs the package.
 The reference call sites are agent/speech_to_speech.streamspeech.agent.py:66-98
 (OnlineFeatureExtractor) and fairseq/examples/speech_to_text/data_utils.py:73-98 (x 2^15).
 """

@@ -177,6 +177,26 @@ def test_fbank_cmvn_vs_oracle(hip_model, golden_dir):
     assert err < 1e-3, f"fbank max abs err {err}"
 
 
+def test_fbank_kernel_vs_third_party_kaldi_implementation(hip_model, golden_dir):
+    """The fused fbank+CMVN kernel against the committed outputs of transformers' Kaldi-compliance fbank (the third-party
+    implementation the oracle is pinned to, oracle/make_golden_fbank.py): log-mel values (CMVN undone) within 5e-3 max /
+    2e-4 RMS on noise, tonal, ragged-length and one-frame inputs; the near-silent input sits on the log floor, where float32
+    cancellation in the power spectrum is the whole signal, and gets the same bars relative to its own scale."""
+    from oracle import make_golden_fbank as MG
+    g = _gold(golden_dir, "gcmvn_fr-en.npz")
+    hf = _gold(golden_dir, "kaldi_fbank_hf.npz")
+    for name, (kind, seed, n) in MG.CASES.items():
+        pcm = MG.waveform(kind, seed, n)
+        feat = hip_model.fbank_cmvn(torch.from_numpy(pcm).cuda()).cpu().numpy()
+        logmel = feat * g["std"] + g["mean"]
+        ref = hf[name]
+        assert logmel.shape == ref.shape, name
+        err = np.abs(logmel - ref)
+        rms = float(np.sqrt(np.mean(err.astype(np.float64) ** 2)))
+        bar_max, bar_rms = (5e-3, 2e-4) if kind != "quiet" else (5e-2, 5e-3)
+        assert err.max() < bar_max and rms < bar_rms, (name, float(err.max()), rms)
+
+
 def test_offline_utterance_units_and_wav(hip_model, hip_vocoder, synth_weights):
     """BASELINE.json configs[1] end to end on one 4.35 s synthetic utterance: identical ASR / ST /
     unit id sequences and waveform RMS <= 1e-3 vs the CPU oracle (teacher-forced MT tokens)."""
