@@ -31,18 +31,29 @@ def waveform(kind, seed, n):
     return (1e-4 * noise).astype(np.float32)      # near-silence: exercises the log floor region
 
 
-def hf_extractor():
-    from transformers import SeamlessM4TFeatureExtractor
-    return SeamlessM4TFeatureExtractor(feature_size=80, sampling_rate=16000, num_mel_bins=80, stride=1)
+def hf_fbank(x):
+    """transformers' Kaldi-compliance log-mel features [frames, 80] of a float waveform in [-1, 1)."""
+    # oracle/ref_agent.py parks name-only `torchaudio` / `soundfile` stubs in sys.modules for the reference agent files; transformers probes
+    # torchaudio with importlib.util.find_spec (lazily, at import and at call time), which chokes on a module without
+    # __spec__ -- the stubs are hidden for the duration
+    import sys
+    probed = ("torchaudio", "soundfile", "librosa", "torchcodec", "omegaconf", "yt_dlp", "textgrid")   # what transformers looks for / the loaders stub
+    hidden = {k: sys.modules.pop(k) for k in list(sys.modules)
+              if k.split(".")[0] in probed and getattr(sys.modules[k], "__spec__", None) is None}
+    try:
+        from transformers import SeamlessM4TFeatureExtractor
+        fe = SeamlessM4TFeatureExtractor(feature_size=80, sampling_rate=16000, num_mel_bins=80, stride=1)
+        return np.asarray(fe._extract_fbank_features(np.asarray(x, np.float32)), np.float32)
+    finally:
+        sys.modules.update(hidden)
 
 
 def main():
     import transformers
-    fe = hf_extractor()
     out = {"transformers_version": np.array(transformers.__version__)}
     for name, (kind, seed, n) in CASES.items():
         x = waveform(kind, seed, n)
-        out[name] = fe._extract_fbank_features(x.astype(np.float32)).astype(np.float32)
+        out[name] = hf_fbank(x)
         print(name, out[name].shape, float(out[name].mean()))
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")

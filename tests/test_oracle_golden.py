@@ -140,10 +140,12 @@ def test_fbank_oracle_matches_third_party_kaldi_implementation(golden_dir):
 
 def test_fbank_oracle_matches_live_transformers_extractor():
     """The same, live, on a waveform that is not in the fixture (skipped where transformers is not importable)."""
-    pytest.importorskip("transformers")
     from oracle import make_golden_fbank as MG
     x = MG.waveform("tonal", 99, 23456)
-    ref = MG.hf_extractor()._extract_fbank_features(x.astype(np.float32))
+    try:
+        ref = MG.hf_fbank(x)       # imports transformers with the reference loader's torchaudio stub hidden
+    except ImportError:
+        pytest.skip("transformers not importable")
     mine = K.fbank(x * np.float32(32768.0))
     assert mine.shape == ref.shape and np.abs(mine - ref).max() < FBANK_MAX_TOL
 
