@@ -792,6 +792,7 @@ int sk_workspace_acquire(hipStream_t stream, SkWorkspace** out) {
     SS_HIP_CHECK(hipMalloc(&w->sync2, SKW_SYNC_BYTES));
     SS_HIP_CHECK(hipMemsetAsync(w->sync1, 0, SKW_SYNC_BYTES, stream));
     SS_HIP_CHECK(hipMemsetAsync(w->sync2, 0, SKW_SYNC_BYTES, stream));
+    SS_HIP_CHECK(hipStreamSynchronize(stream));   // once per context: a later call may arrive on another stream and must see the zeros
   } else if (w->dev != dev) {
     return SS_ERR_ARG;                 // a context belongs to the device it first ran on
   }
