@@ -216,7 +216,10 @@ def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=No
         return tot
 
     kept_ids = None
-    for name, over in (("incremental", {}), ("full_recompute", {"full_recompute_encoder": True, "vocoder_context_units": 0})):
+    # the agent's default: incremental encoder + tail vocoder + the MT decode step as one persistent launch (mt_step.hip);
+    # then the reference's full recompute per call, and the default with the launch-per-op decode step (A/B of mt_step.hip)
+    for name, over in (("incremental", {}), ("full_recompute", {"full_recompute_encoder": True, "vocoder_context_units": 0}),
+                       ("incremental_launch_per_op_mt", {"mt_step_workgroups": 0})):
         agent = StreamSpeechS2STAgent(_agent_args(segment_ms, **over), model=StreamSpeechModel.from_engine(model), vocoder=VocSurface(voc))
         SE.run_utterance(agent, pcms[0], segment_ms)                      # warm-up utterance
         n0 = census_launches()
@@ -237,6 +240,8 @@ def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=No
         summ["actions_first_utterance"] = runs[0]["actions"]
         out[name] = summ
         kept_ids = kept_ids or ids
+    if hasattr(model, "set_persistent_mt_step"):
+        model.set_persistent_mt_step(0)             # the agents switched it on for this (shared) context
     out["value"] = out["incremental"]["rtfx_compute"]
     out["unit"] = "x real-time (audio s / policy() compute s, one utterance at a time)"
     out["higher_is_better"] = True
@@ -450,6 +455,19 @@ def main():
     torch.cuda.synchronize()
     single_ms = 1e3 * (time.perf_counter() - t0) / nlat
     single_rtfx = sum(mine[i].seconds for i in lat_idx) / (single_ms * 1e-3 * nlat)
+    # the same utterances with the MT decode step as one persistent launch (ss_mt_set_persistent: opt-in per context, what the
+    # SimulEval agents switch on; the batched / multi-stream paths of this file never use it)
+    single_ms_pmt = None
+    if not args.no_latency_pass and hasattr(model, "set_persistent_mt_step"):
+        model.set_persistent_mt_step(64)
+        run_utterance(model, voc, pcms[lat_idx[0]], mine[lat_idx[0]])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in lat_idx:
+            run_utterance(model, voc, pcms[i], mine[i])
+        torch.cuda.synchronize()
+        single_ms_pmt = 1e3 * (time.perf_counter() - t0) / nlat
+        model.set_persistent_mt_step(0)
 
     # S concurrent utterance streams: worker threads (ctypes releases the GIL inside the C ABI),
     # each with its own HIP stream and its own scratch/KV-cache context over the shared weights
@@ -794,6 +812,7 @@ def main():
                        "length_bucketed_batches": (not args.no_length_bucketing) and Bsz > 1, "utterances_per_ragged_batch": Bsz, "concurrent_streams_per_gpu": S,
                        "parallelism": f"utterance-dp{world}"},
             "latency_ms_single_stream": round(single_ms, 3), "rtfx_single_stream": round(single_rtfx, 2),
+            "latency_ms_single_stream_persistent_mt_step": None if single_ms_pmt is None else round(single_ms_pmt, 3),
             "batch1_8streams": None if b1_rtfx is None else {"rtfx": round(b1_rtfx, 1), "utterances_per_sec": round(b1_ups, 1),
                                                              "note": "one utterance per call (no ragged packs), 8 concurrent streams, 64 utterances"},
             "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),   # must be 0 (bounded waits of the stream-K fix-up); also asserted for the timed region

@@ -113,6 +113,15 @@ int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d_enc_out, i
                   int32_t* d_raw, int32_t* d_tokens, int32_t* d_index, int32_t* d_count,
                   float* d_logits);
 
+/* Decode-step form of this context (the n = 1 calls of ss_mt_append / the loop inside ss_mt_greedy; reference: one
+ * EnsembleModel.forward_decoder call of agent/sequence_generator.py:592-673 per generated token).  workgroups = 0 (default, or
+ * the SS_MT_PERSISTENT environment variable at context creation): one launch per op, 35 dependent kernels per token.
+ * workgroups = 64 | 128 | 256: the whole step as ONE persistent launch (csrc/mt_step.hip: phases exchange their output vectors
+ * through agent-scope {epoch, value} granules; every wait is bounded and counted by ss_debug_sk_errors).  All workgroups of a
+ * launch must become resident: meant for a context that decodes one utterance at a time on an otherwise lightly loaded
+ * device (the SimulEval agent), at most 8 such contexts concurrently at 64 workgroups. */
+int ss_mt_set_persistent(ss_model* m, int workgroups);
+
 /* ---- a9-a10: first-pass MT decoder with KV cache (the reference re-runs it on the whole prefix
  * every step, agent/sequence_generator.py:313-346; per-position results are identical).
  * ss_mt_begin: bind encoder output, project cross-attention K/V for all layers, reset the cache.

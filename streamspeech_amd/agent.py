@@ -67,6 +67,8 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
 
         eng = self.model.hip if hasattr(self.model, "hip") else self.model
         self.engine = eng
+        if hasattr(eng, "set_persistent_mt_step"):       # HIP engine: the MT decode step as one persistent launch (mt_step.hip)
+            eng.set_persistent_mt_step(int(getattr(args, "mt_step_workgroups", 64)))
         tgt_dict_mt = self.dict[self.model.mt_task_name]
         tgt_dict = self.dict["tgt"]
         uni = getattr(self.model, "uni_encoder", False)
@@ -140,6 +142,9 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
           help="re-encode all received audio at every policy() call like the reference (default: reuse final rows)")
         a("--vocoder-context-units", type=int, default=-1,
           help="left-context units re-synthesised with each new unit tail (-1: receptive field + 8, 0: all units like the reference)")
+        a("--mt-step-workgroups", type=int, default=64,
+          help="first-pass text decoder: one persistent launch per decode step on this many workgroups (64 | 128 | 256; the agent "
+               "decodes one utterance at a time, which is what that form needs); 0: one launch per op")
         a("--extra-output-dir", type=str, default=None, help="extra output dir")
         a("--output-asr-translation", type=bool, default=False, help="extra output dir")
 

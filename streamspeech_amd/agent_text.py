@@ -29,6 +29,8 @@ class _TextAgentBase(SpeechToTextAgent):
         torch.set_grad_enabled(False)
         eng = self.model.hip if hasattr(self.model, "hip") else self.model
         self.engine = eng
+        if hasattr(eng, "set_persistent_mt_step"):       # HIP engine: the MT decode step as one persistent launch (mt_step.hip)
+            eng.set_persistent_mt_step(int(getattr(args, "mt_step_workgroups", 64)))
         self.asr_ctc_generator = CTCDecoder(self.dict["source_unigram"], eng, 0)
         self.st_ctc_generator = CTCDecoder(self.dict["ctc_target_unigram"], eng, 1)
         tgt_dict_mt = self.dict[self.model.mt_task_name]

@@ -12,6 +12,7 @@
 #include "elementwise.hpp"
 #include "fbank.hpp"
 #include "gemm.hpp"
+#include "mt_step.hpp"
 
 using namespace ss;
 
@@ -63,6 +64,7 @@ struct Lin { const float* w = nullptr; const float* b = nullptr; };
 struct LN { const float* g = nullptr; const float* b = nullptr; };
 
 #define RET(x) do { int _r = (x); if (_r != SS_OK) return _r; } while (0)
+static const int g_mt_persistent_default = getenv("SS_MT_PERSISTENT") ? atoi(getenv("SS_MT_PERSISTENT")) : 0;   // default of ss_mt_set_persistent for new contexts (0: launch-per-op decode step)
 static const int g_no_mt_ln_fusion = getenv("SS_NO_MT_LN_FUSION") ? atoi(getenv("SS_NO_MT_LN_FUSION")) : 0;   // A/B knob: separate final LayerNorm launch in the MT decode step
 
 int linear(hipStream_t s, const float* A, int lda, int M, const Lin& l, int N, int K, float* C, int ldc,
@@ -138,6 +140,9 @@ struct ss_model {
   int mt_Tp = 0;
   int mt_len = 0;
   const float* mt_enc = nullptr;
+  DevBuf mt_gran;                // persistent decode step (mt_step.hip): granule region, zeroed once; the epoch grows per launch
+  unsigned mt_epoch = 0;
+  int mt_persistent = g_mt_persistent_default;   // workgroups of the persistent decode step (ss_mt_set_persistent); 0 = launch-per-op
   DevBuf mt_tok;                 // device token chain [max_tgt_pos] (greedy search feeds itself)
   DevBuf seg_buf;                // ragged-batch segment tables / batched token chain
   DevBuf bmt_self;               // batched MT self-attention cache [layer][B][Lcap][3D]
@@ -272,7 +277,7 @@ extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t
 extern "C" void ss_model_destroy(ss_model* m) {
   if (!m) return;
   m->pos_proj.release(); m->ws.release(); m->mt_cross.release(); m->mt_self.release(); m->mt_ws.release();
-  m->mt_tok.release(); m->seg_buf.release(); m->bmt_self.release();
+  m->mt_tok.release(); m->seg_buf.release(); m->bmt_self.release(); m->mt_gran.release();
   m->es_qkv.release(); m->es_glu.release(); m->es_out.release();
   if (m->mt_tok_host) (void)hipHostFree(m->mt_tok_host);
   sk_workspace_free(m->skws);
@@ -601,6 +606,12 @@ extern "C" int ss_mt_begin(ss_model* m, void* stream, const float* d_enc_out, in
   return SS_OK;
 }
 
+extern "C" int ss_mt_set_persistent(ss_model* m, int workgroups) {
+  if (!m || !(workgroups == 0 || workgroups == 64 || workgroups == 128 || workgroups == 256)) return SS_ERR_ARG;
+  m->mt_persistent = workgroups;
+  return SS_OK;
+}
+
 extern "C" int ss_mt_truncate(ss_model* m, int len) {
   if (!m || len < 0 || len > m->mt_len) return SS_ERR_ARG;
   m->mt_len = len;
@@ -622,6 +633,38 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
   float* feats = q2 + (size_t)n * D;
   float* ff = feats + (size_t)n * D;
   float* logits = ff + (size_t)n * F;
+  if (m->mt_persistent > 0 && n == 1 && d_next && n_tail_pad == 0 && c.mt_layers == MT_L && D == MT_D && F == MT_F &&
+      c.dec_heads == MT_H) {
+    // one persistent launch for the whole step (mt_step.hip; opt-in)
+    if (!m->mt_gran.p) {
+      RET(m->mt_gran.ensure(mt_step_granule_bytes()));
+      SS_HIP_CHECK(hipMemsetAsync(m->mt_gran.p, 0, mt_step_granule_bytes(), s));
+      SS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    SkWorkspace* ws = nullptr;
+    RET(sk_workspace_acquire(s, &ws));                    // its time-out counter is the one ss_debug_sk_errors reports
+    MtStepArgs a;
+    for (int l = 0; l < MT_L; ++l) {
+      const DecLayer& L = m->mt[l];
+      if (!L.has_cross) return SS_ERR_ARG;
+      MtLayerW& w = a.L[l];
+      w.ln1_g = L.self_ln.g; w.ln1_b = L.self_ln.b; w.wqkv = L.self_qkv.w; w.bqkv = L.self_qkv.b; w.wo = L.self_out.w; w.bo = L.self_out.b;
+      w.ln2_g = L.cross_ln.g; w.ln2_b = L.cross_ln.b; w.wcq = L.cross_q.w; w.bcq = L.cross_q.b; w.wco = L.cross_out.w; w.bco = L.cross_out.b;
+      w.ln3_g = L.ffn_ln.g; w.ln3_b = L.ffn_ln.b; w.w1 = L.fc1.w; w.b1 = L.fc1.b; w.w2 = L.fc2.w; w.b2 = L.fc2.b;
+      w.selfbuf = m->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
+      w.cross = m->mt_cross.f() + (size_t)l * m->mt_Tp * 2 * D;
+    }
+    a.lnf_g = m->mt_ln.g; a.lnf_b = m->mt_ln.b; a.emb = m->mt_emb; a.pos_table = m->mt_pos;
+    a.tok = d_tokens; a.feats = d_feats ? d_feats : feats; a.next = d_next;
+    a.gran = reinterpret_cast<mt_u64*>(m->mt_gran.p); a.err = ws->sync2 + 8;
+    if (++m->mt_epoch == 0) ++m->mt_epoch;
+    a.epoch = m->mt_epoch;
+    a.Tp = m->mt_Tp; a.pos0 = pos0; a.V = V; a.pad = c.pad; a.eos = c.eos; a.ban_eos = ban_eos; a.force_eos = force_eos;
+    a.emb_scale = sqrtf((float)D);
+    RET(launch_mt_step(a, m->mt_persistent, s));
+    m->mt_len = pos0 + n;
+    return SS_OK;
+  }
   // sqrt(D) * E[tok] + sinusoid(position), positions start at padding_idx + 1 (transformer_decoder.py:297-326)
   RET(launch_embed_tokens(d_tokens, m->mt_emb, m->mt_pos, sqrtf((float)D), pos0 + c.pad + 1, x, n, D, s, 1, c.pad));
   for (int l = 0; l < c.mt_layers; ++l) {

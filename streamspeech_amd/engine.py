@@ -268,6 +268,11 @@ class HipModel(BatchMixin):
                                       min_len, c_out, C.byref(n_out), _ptr(feats), C.byref(n_feats)), "ss_mt_greedy")
         return list(c_out[: n_out.value]), feats[: n_feats.value]
 
+    def set_persistent_mt_step(self, workgroups: int = 64):
+        """One persistent launch per MT decode step (0 restores the launch-per-op form); see ss_mt_set_persistent."""
+        L.check(self.lib.ss_mt_set_persistent(self.h, int(workgroups)), "ss_mt_set_persistent")
+        self.persistent_mt = int(workgroups)
+
     def mt_truncate(self, length: int):
         L.check(self.lib.ss_mt_truncate(self.h, length), "ss_mt_truncate")
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     "ss_encoder_stream_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ss_ctc_greedy": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ss_mt_begin": (_i, [_vp, _vp, _vp, _i]),
+    "ss_mt_set_persistent": (_i, [_vp, _i]),
     "ss_mt_append": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i]),
     "ss_mt_truncate": (_i, [_vp, _i]),
     "ss_mt_greedy": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), _i, _i, _i, C.POINTER(C.c_int32), C.POINTER(_i),

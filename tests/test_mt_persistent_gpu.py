@@ -1,0 +1,104 @@
+"""The persistent MT decode step (csrc/mt_step.hip, ss_mt_set_persistent) against the launch-per-op step it replaces:
+identical greedy token ids, decoder states within float noise, on prefixes / forced eos / min_len, alone and with several
+contexts decoding at once next to a full-chip vocoder batch (the exchange between workgroups must hold under uneven load:
+cdna_hip_programming.md Guideline 16 "test every hand-off under uneven load"); every bounded wait must have been met."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _search(model, enc, prefix, max_new, min_len=1):
+    max_len = len(prefix) + max_new
+    toks, feats = model.mt_greedy(enc, prefix, max_len, min_len)
+    return toks, feats.clone()
+
+
+@pytest.mark.parametrize("wgs", [64, 128, 256])
+def test_persistent_step_equals_launch_per_op_step(hip_model, wgs):
+    from streamspeech_amd import synth
+    lib = hip_model.lib
+    err0 = lib.ss_debug_sk_errors()
+    cases = [(131, [], 12, 1), (435, [17, 4021, 99], 9, 1), (57, [], 30, 5), (23, [5999], 1, 1)]
+    encs = [hip_model.encoder_forward(torch.from_numpy(synth.synth_fbank(60 + i, T)).cuda()) for i, (T, _, _, _) in enumerate(cases)]
+    try:
+        for (T, prefix, max_new, min_len), enc in zip(cases, encs):
+            hip_model.set_persistent_mt_step(0)
+            ref_t, ref_f = _search(hip_model, enc, prefix, max_new, min_len)
+            hip_model.set_persistent_mt_step(wgs)
+            got_t, got_f = _search(hip_model, enc, prefix, max_new, min_len)
+            assert got_t == ref_t, (T, prefix, got_t, ref_t)
+            assert got_f.shape == ref_f.shape and (got_f - ref_f).abs().max().item() < 5e-5
+            # second run of the persistent form: bit-reproducible (fixed summation orders, epoch-tagged exchange)
+            again_t, again_f = _search(hip_model, enc, prefix, max_new, min_len)
+            assert again_t == got_t and torch.equal(again_f, got_f)
+    finally:
+        hip_model.set_persistent_mt_step(0)
+    assert lib.ss_debug_sk_errors() == err0, "a bounded wait of the persistent step timed out"
+
+
+def test_persistent_steps_of_several_contexts_under_load(hip_model, hip_vocoder):
+    """Four contexts decode concurrently with the persistent step (64 workgroups each) while a fifth stream runs batch-scale
+    vocoder passes (full-chip stream-K kernels): tokens equal the serial launch-per-op result, no time-out."""
+    from streamspeech_amd import synth
+    lib = hip_model.lib
+    err0 = lib.ss_debug_sk_errors()
+    dev = hip_model.device
+    Ts = [131, 260, 77, 401]
+    fbs = [torch.from_numpy(synth.synth_fbank(80 + i, T)).to(dev) for i, T in enumerate(Ts)]
+    ctxs = [hip_model.new_context() for _ in Ts]
+    serial = []
+    for m, fb in zip(ctxs, fbs):
+        enc = m.encoder_forward(fb)
+        serial.append((_search(m, enc, [], 24)[0], enc))
+    codes = [[int(c) for c in synth.uniform(21, f"mtp/{i}", (150,), 0, 1000)] for i in range(24)]
+    durs = [[1 + (j % 3 == 1) for j in range(150)] for _ in range(24)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(len(Ts) + 1)]
+    results, errors = [None] * len(Ts), []
+    stop = threading.Event()
+    bar = threading.Barrier(len(Ts) + 1)
+
+    def decoder(i):
+        try:
+            m = ctxs[i]
+            m.set_persistent_mt_step(64)
+            with torch.cuda.stream(streams[i]):
+                bar.wait()
+                out = []
+                for _ in range(6):
+                    out.append(_search(m, serial[i][1], [], 24)[0])
+                streams[i].synchronize()
+            results[i] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            bar.abort()
+        finally:
+            ctxs[i].set_persistent_mt_step(0)
+
+    def load():
+        try:
+            with torch.cuda.stream(streams[-1]):
+                bar.wait()
+                while not stop.is_set():
+                    hip_vocoder.batch_forward(codes, True, forced_dur=durs)
+                    streams[-1].synchronize()
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    th = [threading.Thread(target=decoder, args=(i,)) for i in range(len(Ts))] + [threading.Thread(target=load)]
+    for t in th:
+        t.start()
+    for t in th[:-1]:
+        t.join()
+    stop.set()
+    th[-1].join()
+    torch.cuda.synchronize()
+    if errors:
+        raise errors[0]
+    for i in range(len(Ts)):
+        for out in results[i]:
+            assert out == serial[i][0], f"context {i}"
+    assert lib.ss_debug_sk_errors() == err0, "a bounded wait timed out under load"
