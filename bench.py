@@ -574,10 +574,15 @@ def main():
             kv = pm.get("classes", {}).get(name)
             if kv:
                 traffic = round(kv["hbm_mbytes_per_launch_corrected"] * 1e6)          # HBM-side bytes per launch (counters)
-                from tools.pmc_traffic import csrc_sha16
+                from tools.pmc_traffic import csrc_file_sha16, csrc_sha16
+                then, now = pm.get("csrc_files_sha16") or {}, csrc_file_sha16()
+                changed = sorted(f for f in set(then) | set(now) if then.get(f) != now.get(f)) if then else None
+                dominant = ("conv_sk2.hip", "gemm.hpp", "gemm.hip", "common.hpp")   # kernel, its argument block, dispatch + workspace
                 traffic_detail = {"measured_by": "a separate rocprofv3 --pmc run of an earlier process (NOT this run)",
                                   "pmc_run_kernel_sources_sha16": pm.get("csrc_sha16"), "this_build_kernel_sources_sha16": csrc_sha16(),
                                   "same_kernel_sources": pm.get("csrc_sha16") == csrc_sha16(),
+                                  "files_changed_since_pmc_run": changed,
+                                  "dominant_kernel_sources_unchanged": (None if changed is None else not any(f in changed for f in dominant)),
                                   "mbytes_per_launch": kv["hbm_mbytes_per_launch_corrected"],
                                   "algorithmic_mbytes_per_launch_of_the_pmc_run": kv.get("algo_mbytes_per_launch"),
                                   "traffic_over_algorithmic": kv.get("traffic_over_algorithmic"),

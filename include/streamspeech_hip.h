@@ -121,6 +121,10 @@ int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d_enc_out, i
  * launch must become resident: meant for a context that decodes one utterance at a time on an otherwise lightly loaded
  * device (the SimulEval agent), at most 8 such contexts concurrently at 64 workgroups. */
 int ss_mt_set_persistent(ss_model* m, int workgroups);
+/* The current setting.  It drops to 0 by itself when a launch of the persistent step times out: the kernel then publishes -1
+ * as the next token, ss_mt_greedy (which reads the token chain back anyway) repeats the whole search with one launch per op and
+ * says so on stderr; callers of ss_mt_append that read *d_next < 0 do the same (engine.HipModel.mt_append). */
+int ss_mt_get_persistent(ss_model* m);
 
 /* ---- a9-a10: first-pass MT decoder with KV cache (the reference re-runs it on the whole prefix
  * every step, agent/sequence_generator.py:313-346; per-position results are identical).
@@ -228,6 +232,9 @@ const char* ss_prof_class_name(int cls);
 int ss_debug_force_tile(int bm, int bn, int ks);
 /* Number of bounded-spin time-outs the stream-K kernel has recorded (any value but 0 is a bug). */
 int ss_debug_sk_errors(void);
+/* Test hook: the next launch of the persistent MT decode step behaves as if a bounded wait had timed out (it publishes -1),
+ * without touching the counter above.  tests/test_mt_persistent_gpu.py drives the fall-back with it. */
+int ss_debug_mt_inject_timeout(ss_model* m);
 
 /* ---- op-level entry points (unit tests of single kernels; same launchers the stages use) ---- */
 int ss_op_conv_gemm(void* stream, const float* dA, int lda, const float* dW, const float* dbias,

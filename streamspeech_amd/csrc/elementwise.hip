@@ -123,21 +123,22 @@ int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const floa
 // ---------------------------------------------------------------------------------------------
 __global__ void embed_tokens_kernel(const int* __restrict__ tok, const float* __restrict__ emb,
                                     const float* __restrict__ pos_table, float scale, int pos0, float* out,
-                                    int n, int D, int pos_stride, int pad_id) {
+                                    int n, int D, int pos_stride, int pad_id, int vocab) {
   const int i = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= D) return;
-  const int tk = tok[i];
+  int tk = tok[i];
+  if ((unsigned)tk >= (unsigned)vocab) tk = 0;            // ids come from device memory (the token chain): never index out of the table
   // make_positions (fairseq/utils.py:256-266): a <pad> token takes position padding_idx (the zero row)
   const int pos = (tk == pad_id) ? pad_id : pos0 + i * pos_stride;
   out[(size_t)i * D + c] = scale * emb[(size_t)tk * D + c] + pos_table[(size_t)pos * D + c];
 }
 
 int launch_embed_tokens(const int* tok, const float* emb, const float* pos_table, float scale, int pos0,
-                        float* out, int n, int D, hipStream_t stream, int pos_stride, int pad_id) {
+                        float* out, int n, int D, hipStream_t stream, int pos_stride, int pad_id, int vocab) {
   if (n <= 0) return SS_OK;
   hipLaunchKernelGGL(embed_tokens_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, stream, tok, emb, pos_table,
-                     scale, pos0, out, n, D, pos_stride, pad_id);
+                     scale, pos0, out, n, D, pos_stride, pad_id, vocab);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }
@@ -196,8 +197,9 @@ __global__ __launch_bounds__(256) void masked_argmax_kernel(const float* __restr
   int bi = 0x7fffffff;
   for (int n = t; n < N; n += 256) {
     if (n == mask0 || n == mask1 || n == mask2) continue;
-    const float v = r[n];
-    if (v != v) continue;  // NaN -> -inf (agent/sequence_generator.py:350)
+    float v = r[n];
+    if (v != v) v = -INFINITY;  // NaN -> -inf (agent/sequence_generator.py:350); still a candidate, so a row of NaNs yields the
+                                // first unmasked column like an all -inf row does there, never an out-of-range id
     if (bi == 0x7fffffff || v > best) { best = v; bi = n; }  // n ascends per thread: first max wins
   }
 #pragma unroll

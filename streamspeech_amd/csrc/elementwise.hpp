@@ -23,8 +23,8 @@ int launch_dwconv_bn_silu(const float* x, int ldx, float* y, int ldy, const floa
 // out[i,:] = scale * emb[tok[i],:] + pos_table[pos0 + i, :]     (MT decoder input embedding,
 // reference ctc_unity/modules/transformer_decoder.py:297-326)
 int launch_embed_tokens(const int* tok, const float* emb, const float* pos_table, float scale, int pos0,
-                        float* out, int n, int D, hipStream_t stream, int pos_stride = 1,
-                        int pad_id = -1);  // pos_stride 0: same position for all rows; pad_id: token that takes position pad_id
+                        float* out, int n, int D, hipStream_t stream, int pos_stride, int pad_id, int vocab);
+// pos_stride 0: same position for all rows; pad_id: token that takes position pad_id (-1: none); ids outside [0, vocab) read row 0
 
 // out[u,:] = src[u/up,:] + (src[u/up,0] != pad_value ? pos_row : 0)   (CTC unit decoder input,
 // reference ctc_unity/modules/ctc_transformer_unit_decoder.py:153-181)

@@ -142,6 +142,7 @@ struct ss_model {
   const float* mt_enc = nullptr;
   DevBuf mt_gran;                // persistent decode step (mt_step.hip): granule region, zeroed once; the epoch grows per launch
   unsigned mt_epoch = 0;
+  int mt_inject_timeout = 0;     // ss_debug_mt_inject_timeout: the next persistent launch reports a time-out
   int mt_persistent = g_mt_persistent_default;   // workgroups of the persistent decode step (ss_mt_set_persistent); 0 = launch-per-op
   DevBuf mt_tok;                 // device token chain [max_tgt_pos] (greedy search feeds itself)
   DevBuf seg_buf;                // ragged-batch segment tables / batched token chain
@@ -612,6 +613,14 @@ extern "C" int ss_mt_set_persistent(ss_model* m, int workgroups) {
   return SS_OK;
 }
 
+extern "C" int ss_mt_get_persistent(ss_model* m) { return m ? m->mt_persistent : SS_ERR_ARG; }
+
+extern "C" int ss_debug_mt_inject_timeout(ss_model* m) {
+  if (!m) return SS_ERR_ARG;
+  m->mt_inject_timeout = 1;
+  return SS_OK;
+}
+
 extern "C" int ss_mt_truncate(ss_model* m, int len) {
   if (!m || len < 0 || len > m->mt_len) return SS_ERR_ARG;
   m->mt_len = len;
@@ -637,8 +646,8 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
       c.dec_heads == MT_H) {
     // one persistent launch for the whole step (mt_step.hip; opt-in)
     if (!m->mt_gran.p) {
-      RET(m->mt_gran.ensure(mt_step_granule_bytes()));
-      SS_HIP_CHECK(hipMemsetAsync(m->mt_gran.p, 0, mt_step_granule_bytes(), s));
+      RET(m->mt_gran.ensure(mt_step_granule_bytes() + 64));   // + one spare error word (ss_debug_mt_inject_timeout)
+      SS_HIP_CHECK(hipMemsetAsync(m->mt_gran.p, 0, mt_step_granule_bytes() + 64, s));
       SS_HIP_CHECK(hipStreamSynchronize(s));
     }
     SkWorkspace* ws = nullptr;
@@ -657,6 +666,11 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
     a.lnf_g = m->mt_ln.g; a.lnf_b = m->mt_ln.b; a.emb = m->mt_emb; a.pos_table = m->mt_pos;
     a.tok = d_tokens; a.feats = d_feats ? d_feats : feats; a.next = d_next;
     a.gran = reinterpret_cast<mt_u64*>(m->mt_gran.p); a.err = ws->sync2 + 8;
+    if (m->mt_inject_timeout) {                            // test hook: this one launch sees a time-out that already happened
+      m->mt_inject_timeout = 0;
+      a.err = reinterpret_cast<unsigned*>(static_cast<char*>(m->mt_gran.p) + mt_step_granule_bytes());
+      SS_HIP_CHECK(hipMemsetAsync(a.err, 0x01, sizeof(unsigned), s));
+    }
     if (++m->mt_epoch == 0) ++m->mt_epoch;
     a.epoch = m->mt_epoch;
     a.Tp = m->mt_Tp; a.pos0 = pos0; a.V = V; a.pad = c.pad; a.eos = c.eos; a.ban_eos = ban_eos; a.force_eos = force_eos;
@@ -666,7 +680,7 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
     return SS_OK;
   }
   // sqrt(D) * E[tok] + sinusoid(position), positions start at padding_idx + 1 (transformer_decoder.py:297-326)
-  RET(launch_embed_tokens(d_tokens, m->mt_emb, m->mt_pos, sqrtf((float)D), pos0 + c.pad + 1, x, n, D, s, 1, c.pad));
+  RET(launch_embed_tokens(d_tokens, m->mt_emb, m->mt_pos, sqrtf((float)D), pos0 + c.pad + 1, x, n, D, s, 1, c.pad, V));
   for (int l = 0; l < c.mt_layers; ++l) {
     float* selfbuf = m->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
     const float* cross = m->mt_cross.f() + (size_t)l * m->mt_Tp * 2 * D;
@@ -701,6 +715,8 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
   SkScope sk_scope(m->skws);
   const ss_config& c = m->cfg;
   if (max_len + 3 > c.max_tgt_pos) return SS_ERR_CAPACITY;
+  for (int i = 0; i < n_prefix; ++i)
+    if (h_prefix[i] < 0 || h_prefix[i] >= c.tgt_vocab) return SS_ERR_ARG;   // nn.Embedding's IndexError in the reference
   hipStream_t s = (hipStream_t)stream;
   constexpr int kCheck = 4;
   const int D = c.dec_dim;
@@ -721,7 +737,16 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
       SS_HIP_CHECK(hipMemcpyAsync(host + checked, tok + checked, (size_t)(step + 1 - checked) * sizeof(int32_t),
                                   hipMemcpyDeviceToHost, s));
       SS_HIP_CHECK(hipStreamSynchronize(s));
-      for (int i = checked; i <= step && eos_at < 0; ++i) if (host[i] == c.eos) eos_at = i;
+      for (int i = checked; i <= step && eos_at < 0; ++i) {
+        if (host[i] < 0 && m->mt_persistent > 0) {          // mt_step.hip: a bounded wait of the persistent step timed out
+          fprintf(stderr, "streamspeech_hip: persistent MT decode step timed out (its %d workgroups were not all resident); "
+                          "this context falls back to one launch per op\n", m->mt_persistent);
+          m->mt_persistent = 0;
+          return ss_mt_greedy(m, stream, d_enc_out, Tp, h_prefix, n_prefix, max_len, min_len, h_out_tokens, h_n_out, d_feats,
+                              h_n_feats);
+        }
+        if (host[i] == c.eos) eos_at = i;
+      }
       checked = step + 1;
       if (eos_at >= 0 || last) break;
     }
@@ -1231,7 +1256,7 @@ extern "C" int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float*
   constexpr int kCheck = 4;
   while (true) {
     // feed position `step` of every utterance
-    RET(launch_embed_tokens(tok + (size_t)step * B, m->mt_emb, m->mt_pos, sqrtf((float)D), step + c.pad + 1, x, B, D, s, 0));
+    RET(launch_embed_tokens(tok + (size_t)step * B, m->mt_emb, m->mt_pos, sqrtf((float)D), step + c.pad + 1, x, B, D, s, 0, -1, c.tgt_vocab));
     for (int l = 0; l < c.mt_layers; ++l) {
       float* cache = m->bmt_self.f() + (size_t)l * B * Lcap * 3 * D;
       float* rows = cache + (size_t)step * 3 * D;                    // row b at + b*Lcap*3D

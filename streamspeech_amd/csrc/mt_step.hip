@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
 
   // ---- embedding: x0 = sqrt(D) E[tok] + sinusoid(position); a <pad> token takes position padding_idx (make_positions) ----
   {
-    const int tk = p.tok[0];
+    int tk = p.tok[0];
+    if ((unsigned)tk >= (unsigned)p.V) tk = p.eos;         // the chained token of a step that timed out (phase J: -1): stay in range
     const int pos = (tk == p.pad) ? p.pad : p.pos0 + p.pad + 1;
     xbuf[t] = p.emb_scale * p.emb[(size_t)tk * MT_D + t] + p.pos_table[(size_t)pos * MT_D + t];
     xbuf[t + 256] = p.emb_scale * p.emb[(size_t)tk * MT_D + t + 256] + p.pos_table[(size_t)pos * MT_D + t + 256];
@@ -383,9 +384,10 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
     const int nchunk = (p.V + 8 * nw - 1) / (8 * nw);
     for (int ch = 0; ch < nchunk; ++ch) {
       if (ch > 0) mt_fetch512(wr, p.emb, p.V, gw, nw, lane, ch * 8);
-      const float s = mt_dot512(wr, ybuf, lane);
+      float s = mt_dot512(wr, ybuf, lane);
+      if (s != s) s = -INFINITY;                           // NaN -> -inf, still a candidate (as masked_argmax_kernel)
       const int col = gw + (ch * 8 + lane) * nw;
-      if (lane < 8 && col < p.V && col != p.pad && !(p.ban_eos && col == p.eos) && s == s) {
+      if (lane < 8 && col < p.V && col != p.pad && !(p.ban_eos && col == p.eos)) {
         if (bi == 0x7fffffff || s > bv) { bv = s; bi = col; }      // this lane's columns ascend: first maximum wins
       }
     }
@@ -415,7 +417,10 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
         const float ov = vec[2 * g2]; const int oi = (int)__float_as_uint(vec[2 * g2 + 1]);
         if (oi != 0x7fffffff && (fi == 0x7fffffff || ov > fv || (ov == fv && oi < fi))) { fv = ov; fi = oi; }
       }
-      p.next[0] = p.force_eos ? p.eos : fi;
+      // a bounded wait timed out somewhere in this launch (or an earlier one of this context): the token is not trustworthy.
+      // -1 tells the host, which reads the chain back anyway, to redo the step with the launch-per-op form (model.hip).
+      // The same when no column qualified (all logits NaN): the launch-per-op form then decides what such a step returns.
+      p.next[0] = (__hip_atomic_load(err, MT_RLX) != 0u || fi == 0x7fffffff) ? -1 : (p.force_eos ? p.eos : fi);
     }
   }
 #endif

@@ -248,12 +248,22 @@ class HipModel(BatchMixin):
     def mt_append(self, tokens: List[int], pos0: int, ban_eos: bool, force_eos: bool,
                   want_feats: bool = True, want_next: bool = True, n_tail_pad: int = 0) -> Tuple[Optional[torch.Tensor], Optional[int]]:
         n = len(tokens)
+        if any(not 0 <= int(t) < self.cfg.tgt_vocab for t in tokens):      # nn.Embedding raises the same in the reference
+            raise IndexError(f"token id outside the target dictionary of {self.cfg.tgt_vocab} entries: {tokens}")
         tok = torch.tensor(tokens, dtype=torch.int32).to(self.device)
         feats = torch.empty((n, self.cfg.dec_dim), dtype=torch.float32, device=self.device) if want_feats else None
         nxt = torch.empty((1,), dtype=torch.int32, device=self.device) if want_next else None
         L.check(self.lib.ss_mt_append(self.h, _stream(), _ptr(tok), n, pos0, int(ban_eos), int(force_eos),
                                       _ptr(feats), _ptr(nxt), n_tail_pad), "ss_mt_append")
-        return feats, (int(nxt.item()) if want_next else None)
+        nx = int(nxt.item()) if want_next else None
+        if nx is not None and nx < 0:
+            # csrc/mt_step.hip: a bounded wait of the persistent decode step timed out (its workgroups were not all resident).
+            # Loud, then the same call again with one launch per op -- it rewrites the same cache row and features.
+            import warnings
+            warnings.warn("persistent MT decode step timed out; this context falls back to one launch per op", RuntimeWarning)
+            self.set_persistent_mt_step(0)
+            return self.mt_append(tokens, pos0, ban_eos, force_eos, want_feats, want_next, n_tail_pad)
+        return feats, nx
 
     def mt_greedy(self, enc_out: torch.Tensor, prefix: List[int], max_len: int, min_len: int = 1):
         """Beam-1 search in one C call -> (tokens after the prefix incl. final eos, feats [n_fed, D])."""
@@ -266,6 +276,8 @@ class HipModel(BatchMixin):
         n_out, n_feats = C.c_int(0), C.c_int(0)
         L.check(self.lib.ss_mt_greedy(self.h, _stream(), _ptr(enc_out), enc_out.shape[0], c_pre, n_pre, max_len,
                                       min_len, c_out, C.byref(n_out), _ptr(feats), C.byref(n_feats)), "ss_mt_greedy")
+        if getattr(self, "persistent_mt", 0):                # a time-out inside makes the library fall back (and say so on stderr)
+            self.persistent_mt = int(self.lib.ss_mt_get_persistent(self.h))
         return list(c_out[: n_out.value]), feats[: n_feats.value]
 
     def set_persistent_mt_step(self, workgroups: int = 64):

@@ -48,6 +48,8 @@ SIGNATURES = {
     "ss_ctc_greedy": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ss_mt_begin": (_i, [_vp, _vp, _vp, _i]),
     "ss_mt_set_persistent": (_i, [_vp, _i]),
+    "ss_mt_get_persistent": (_i, [_vp]),
+    "ss_debug_mt_inject_timeout": (_i, [_vp]),
     "ss_mt_append": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i]),
     "ss_mt_truncate": (_i, [_vp, _i]),
     "ss_mt_greedy": (_i, [_vp, _vp, _vp, _i, C.POINTER(C.c_int32), _i, _i, _i, C.POINTER(C.c_int32), C.POINTER(_i),

@@ -105,3 +105,24 @@ def test_missing_weight_slot_is_an_error(synth_weights):
     bad = {k: v for k, v in sd.items() if not k.startswith("encoder.conformer_layers.3.ffn1.w_1")}
     with pytest.raises((L.StreamSpeechHipError, KeyError)):
         HipModel(bad, ModelConfig())
+
+
+@pytest.mark.parametrize("persistent", [0, 64])
+def test_nan_encoder_states_and_bad_ids_never_index_out_of_the_tables(hip_model, persistent):
+    """Broken inputs must not become out-of-range device indices: an encoder output full of NaN turns every logit into NaN ->
+    -inf (agent/sequence_generator.py:350), so each step returns the first unmasked column like an all -inf row; the chained
+    token stays inside the dictionary in both forms of the decode step.  Ids from the host are range-checked like
+    nn.Embedding does."""
+    m = hip_model.new_context()
+    m.set_persistent_mt_step(persistent)
+    enc = torch.full((20, m.cfg.enc_dim), float("nan"), device=m.device)
+    toks, feats = m.mt_greedy(enc, [11], 9, 1)
+    assert len(toks) == 9 and toks[-1] == m.cfg.eos and all(0 <= t < m.cfg.tgt_vocab for t in toks)
+    assert toks[:-1] == [0] * 8                             # first unmasked column
+    good = hip_model.encoder_forward(torch.from_numpy(synth.synth_fbank(2, 80)).to(m.device))
+    with pytest.raises(L.StreamSpeechHipError):
+        m.mt_greedy(good, [m.cfg.tgt_vocab], 6, 1)
+    m.mt_begin(good)
+    with pytest.raises(IndexError):
+        m.mt_append([m.cfg.eos, -3], 0, False, False)
+    assert m.lib.ss_mt_get_persistent(m.h) == persistent    # NaNs are not time-outs: no fall-back was taken

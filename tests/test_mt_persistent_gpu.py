@@ -102,3 +102,44 @@ def test_persistent_steps_of_several_contexts_under_load(hip_model, hip_vocoder)
         for out in results[i]:
             assert out == serial[i][0], f"context {i}"
     assert lib.ss_debug_sk_errors() == err0, "a bounded wait timed out under load"
+
+
+def test_timed_out_persistent_step_falls_back_to_launch_per_op(hip_model):
+    """A launch whose bounded waits timed out publishes -1 instead of a token; ss_mt_greedy (one C call) and the engine's
+    mt_append (the step-by-step form of generators.py) then repeat with one launch per op, loudly, and the context stays on that
+    form.  The time-out is injected (ss_debug_mt_inject_timeout); tokens and states must equal the launch-per-op search."""
+    import warnings
+    from streamspeech_amd import synth
+    lib = hip_model.lib
+    err0 = lib.ss_debug_sk_errors()
+    m = hip_model.new_context()
+    enc = m.encoder_forward(torch.from_numpy(synth.synth_fbank(91, 211)).cuda())
+    ref_t, ref_f = _search(m, enc, [7, 4242], 14)
+    # (1) the search in one C call
+    m.set_persistent_mt_step(64)
+    assert lib.ss_mt_get_persistent(m.h) == 64
+    assert lib.ss_debug_mt_inject_timeout(m.h) == 0
+    got_t, got_f = _search(m, enc, [7, 4242], 14)
+    assert got_t == ref_t and torch.equal(got_f, ref_f)
+    assert lib.ss_mt_get_persistent(m.h) == 0 and m.persistent_mt == 0
+    # (2) step by step through mt_append, time-out on the third generated token
+    m.set_persistent_mt_step(64)
+    m.mt_begin(enc)
+    feats, nxt = m.mt_append([m.cfg.eos, 7, 4242], 0, False, False)
+    toks, rows = [nxt], [feats]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        step = 3                                             # the loop of generators.py (start = 2 prefix tokens, max_len = 16)
+        while nxt != m.cfg.eos and step <= 16:
+            if step == 5:
+                lib.ss_debug_mt_inject_timeout(m.h)
+            feats, nxt = m.mt_append([toks[-1]], step, False, step >= 16)
+            rows.append(feats)
+            toks.append(nxt)
+            step += 1
+    assert any("persistent MT decode step timed out" in str(x.message) for x in w)
+    assert lib.ss_mt_get_persistent(m.h) == 0
+    assert toks == ref_t
+    got = torch.cat(rows)
+    assert got.shape == ref_f.shape and (got - ref_f).abs().max().item() < 5e-5
+    assert lib.ss_debug_sk_errors() == err0            # the injection does not touch the real counter

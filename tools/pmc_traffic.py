@@ -29,6 +29,13 @@ def csrc_sha16():
             h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
+def csrc_file_sha16():
+    """Per-file hashes of the same sources: lets bench.py say WHICH files changed since the counter run."""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "streamspeech_amd", "csrc")
+    return {name: hashlib.sha256(open(os.path.join(d, name), "rb").read()).hexdigest()[:16]
+            for name in sorted(os.listdir(d)) if name.endswith((".hip", ".hpp"))}
+
+
 CLASSES = [("void ss::conv_sk2_kernel", "conv_sk2<256,128,32>"), ("void ss::conv_sk2_kernel", "conv_sk2_bf16x3<256,128,32>"), ("void ss::conv_sk_kernel", "conv_sk<128,BN,32>"), ("void ss::conv_slab_kernel<32", "conv_slab<32>"),
            ("void ss::conv_slab_kernel<16", "conv_slab<16>"),
            ("void ss::resblock_fused_kernel<32", "resblock_fused<32>"), ("void ss::resblock_fused_kernel<16", "resblock_fused<16>"),
@@ -91,7 +98,7 @@ def main():
                 c["traffic_over_algorithmic"] = round(c["hbm_mbytes_per_launch_corrected"] / c["algo_mbytes_per_launch"], 3)
                 c["algo_gflop_per_launch"] = round(z["algo_tflop"] * 1e3 / z["launches"], 3)
     top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_mbytes_per_launch_corrected"] * kv[1]["launches"])[:16])
-    json.dump({"note": sys.argv[4] if len(sys.argv) > 4 else "", "csrc_sha16": csrc_sha16(), "classes": classes, "kernels": top},
+    json.dump({"note": sys.argv[4] if len(sys.argv) > 4 else "", "csrc_sha16": csrc_sha16(), "csrc_files_sha16": csrc_file_sha16(), "classes": classes, "kernels": top},
               open(sys.argv[3], "w"), indent=1)
     print(json.dumps(classes, indent=1))
 
