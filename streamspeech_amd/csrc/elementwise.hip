@@ -163,16 +163,18 @@ int launch_upsample_add_pos(const float* src, int n, int up, const float* pos_ro
 }
 
 __global__ void gather_rows_kernel(const int* __restrict__ idx, const float* __restrict__ table, int D,
-                                   float* out) {
+                                   float* out, int rows) {
   const int i = blockIdx.y;
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= D) return;
-  out[(size_t)i * D + c] = table[(size_t)idx[i] * D + c];
+  int r = idx[i];
+  if ((unsigned)r >= (unsigned)rows) r = 0;                // ids come from device memory: never read outside the table
+  out[(size_t)i * D + c] = table[(size_t)r * D + c];
 }
 
-int launch_gather_rows(const int* idx, const float* table, int D, float* out, int n, hipStream_t stream) {
+int launch_gather_rows(const int* idx, const float* table, int D, float* out, int n, hipStream_t stream, int rows) {
   if (n <= 0) return SS_OK;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, stream, idx, table, D, out);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(D, 256), n), dim3(256), 0, stream, idx, table, D, out, rows);
   SS_LAUNCH_CHECK();
   return SS_OK;
 }

@@ -47,7 +47,7 @@ int launch_ctc_collapse(const int* raw, int T, int blank, int pad, int* tokens, 
                         hipStream_t stream, const int* segs = nullptr, int nseg = 0);  // segs {start,len}: count[s]
 
 // emb_out[k,:] = table[codes[k],:]
-int launch_gather_rows(const int* idx, const float* table, int D, float* out, int n, hipStream_t stream);
+int launch_gather_rows(const int* idx, const float* table, int D, float* out, int n, hipStream_t stream, int rows);  // ids outside [0, rows) read row 0
 
 // dur[k] = clamp(round_half_even(exp(logdur[k]) - 1), min 1)   (reference agent/tts/codehifigan.py:61-64);
 // forced != null overrides the prediction.  cum[0..K] = exclusive prefix sum (cum[K] = total frames).

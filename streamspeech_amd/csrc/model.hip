@@ -1009,7 +1009,7 @@ extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_
   float* logdur = t2 + (size_t)K * Hd;
   int* cum = reinterpret_cast<int*>(logdur + K);
   int* ones = cum + K + 1;
-  RET(launch_gather_rows(d_codes, v->dict, E, emb, K, s));
+  RET(launch_gather_rows(d_codes, v->dict, E, emb, K, s, v->cfg.num_embeddings));
   const int* forced = d_forced_dur;
   if (!forced && dur_prediction) {
     RET(conv1d(s, emb, K, E, v->dur_c1, Hd, c.dur_kernel, 1, t1, ACT_NONE, 0.f, ACT_RELU, nullptr, nullptr, 0.f));
@@ -1390,7 +1390,7 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
   RET(v->segs.ensure((6 * B + 16 * B) * sizeof(int)));
   int* dk = (int*)v->segs.p;
   RET(upload(s, dk, tk));
-  RET(launch_gather_rows(d_codes, v->dict, E, emb, Kt, s));
+  RET(launch_gather_rows(d_codes, v->dict, E, emb, Kt, s, v->cfg.num_embeddings));
   const int* forced = d_forced_dur;
   auto sconv = [&](const float* A, int Cin, const ConvW& cw, int Cout, int k, float* Cc, int act) {
     GemmArgs a;

@@ -365,11 +365,18 @@ class HipVocoder:
         L.check(self.lib.ss_vocoder_set_bf16x3(self.h, int(bool(on))), "ss_vocoder_set_bf16x3")
         self.bf16x3 = bool(on)
 
+    def _check_units(self, ids: torch.Tensor):
+        """nn.Embedding(num_embeddings, ...) of the reference's CodeGenerator raises IndexError on such ids (codehifigan.py:56-70)."""
+        if ids.numel() and (int(ids.min()) < 0 or int(ids.max()) >= self.cfg.num_embeddings):
+            raise IndexError(f"unit id outside the vocoder's {self.cfg.num_embeddings} codes")
+
     def batch_forward(self, codes: List[List[int]], dur_prediction=True, forced_dur: Optional[List[List[int]]] = None):
         """-> (list of wav tensors (views into one packed buffer), list of dur lists)."""
         B = len(codes)
         K = [len(c) for c in codes]
-        flat = torch.tensor([u for c in codes for u in c], dtype=torch.int32).to(self.device)
+        flat = torch.tensor([u for c in codes for u in c], dtype=torch.int32)
+        self._check_units(flat)
+        flat = flat.to(self.device)
         fd = None
         if forced_dur is not None:
             fd = torch.tensor([d for ds in forced_dur for d in ds], dtype=torch.int32).to(self.device)
@@ -394,7 +401,10 @@ class HipVocoder:
 
     def forward(self, codes, dur_prediction: bool = True, forced_dur=None) -> Tuple[torch.Tensor, torch.Tensor]:
         """codes: list/array/tensor of unit ids -> (wav [S] float32 device, dur [K] int32 device)."""
-        codes_t = torch.as_tensor(codes, dtype=torch.int32).reshape(-1).to(self.device)
+        codes_t = torch.as_tensor(codes, dtype=torch.int32).reshape(-1)
+        if not codes_t.is_cuda:
+            self._check_units(codes_t)                      # device-resident ids are guarded by the gather kernel instead
+        codes_t = codes_t.to(self.device)
         K = codes_t.numel()
         fd = None if forced_dur is None else torch.as_tensor(forced_dur, dtype=torch.int32).reshape(-1).to(self.device)
         cap = K * self.max_dur * self.hop

@@ -126,3 +126,17 @@ def test_nan_encoder_states_and_bad_ids_never_index_out_of_the_tables(hip_model,
     with pytest.raises(IndexError):
         m.mt_append([m.cfg.eos, -3], 0, False, False)
     assert m.lib.ss_mt_get_persistent(m.h) == persistent    # NaNs are not time-outs: no fall-back was taken
+
+
+def test_unit_ids_outside_the_vocoder_codebook(hip_vocoder):
+    """Host ids are range-checked like the reference's nn.Embedding (codehifigan.py:56-70); ids already on the device cannot be
+    checked without a sync, so the gather kernel itself never reads outside the table (they take row 0)."""
+    n = hip_vocoder.cfg.num_embeddings
+    with pytest.raises(IndexError):
+        hip_vocoder.forward([5, n, 7])
+    with pytest.raises(IndexError):
+        hip_vocoder.batch_forward([[1, 2], [3, -1]])
+    ok, _ = hip_vocoder.forward([0, 7, 9], forced_dur=[1, 2, 1])
+    dev_ids = torch.tensor([n + 12345, 7, 9], dtype=torch.int32, device=hip_vocoder.device)
+    got, _ = hip_vocoder.forward(dev_ids, forced_dur=[1, 2, 1])
+    assert torch.equal(got, ok)
