@@ -64,7 +64,12 @@ struct Lin { const float* w = nullptr; const float* b = nullptr; };
 struct LN { const float* g = nullptr; const float* b = nullptr; };
 
 #define RET(x) do { int _r = (x); if (_r != SS_OK) return _r; } while (0)
-static const int g_mt_persistent_default = getenv("SS_MT_PERSISTENT") ? atoi(getenv("SS_MT_PERSISTENT")) : 0;   // default of ss_mt_set_persistent for new contexts (0: launch-per-op decode step)
+static int mt_persistent_env() {
+  const char* e = getenv("SS_MT_PERSISTENT");
+  const int v = e ? atoi(e) : 0;
+  return (v == 64 || v == 128 || v == 256) ? v : 0;       // anything else: the launch-per-op form
+}
+static const int g_mt_persistent_default = mt_persistent_env();   // default of ss_mt_set_persistent for new contexts (0: launch-per-op decode step)
 static const int g_no_mt_ln_fusion = getenv("SS_NO_MT_LN_FUSION") ? atoi(getenv("SS_NO_MT_LN_FUSION")) : 0;   // A/B knob: separate final LayerNorm launch in the MT decode step
 
 int linear(hipStream_t s, const float* A, int lda, int M, const Lin& l, int N, int K, float* C, int ldc,
