@@ -1220,7 +1220,10 @@ extern "C" int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float*
   const ss_config& c = m->cfg;
   const int D = c.dec_dim, F = c.dec_ffn, V = c.tgt_vocab, H = c.dec_heads;
   int Lmax = 0;
-  for (int b = 0; b < B; ++b) Lmax = std::max(Lmax, h_max_len[b]);
+  for (int b = 0; b < B; ++b) {
+    if (h_Tp[b] <= 0 || h_max_len[b] < 0) return SS_ERR_ARG;   // an utterance without encoder rows has nothing to attend to
+    Lmax = std::max(Lmax, h_max_len[b]);
+  }
   const int Lcap = Lmax + 2;
   if (Lcap > feat_rows || Lcap + 2 > c.max_tgt_pos || out_stride < Lmax + 1) return SS_ERR_CAPACITY;
   const Offsets oe = prefix(h_Tp, B);
@@ -1312,6 +1315,8 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int D = c.dec_dim, F = c.dec_ffn, V = c.unit_vocab, H = c.dec_heads, up = c.ctc_upsample;
+  for (int b = 0; b < B; ++b)
+    if (h_n[b] <= 0) return SS_ERR_ARG;                    // every utterance feeds at least the leading </s> state
   const Offsets on = prefix(h_n, B);
   const int Nn = on.total, U = Nn * up;
   const size_t nx = (size_t)U * D;
@@ -1377,6 +1382,8 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
   hipStream_t s = (hipStream_t)stream;
   const ss_vocoder_config& c = v->cfg;
   const int E = c.embedding_dim, Hd = c.dur_hidden;
+  for (int b = 0; b < B; ++b)
+    if (h_K[b] <= 0) return SS_ERR_ARG;                    // the single-utterance form refuses K = 0 too; callers drop unit-less utterances
   const Offsets ok = prefix(h_K, B);
   const int Kt = ok.total;
   RET(v->small.ensure(((size_t)Kt * (E + 2 * Hd + 1) + 2 * (Kt + B + 2)) * sizeof(float)));

@@ -140,3 +140,16 @@ def test_unit_ids_outside_the_vocoder_codebook(hip_vocoder):
     dev_ids = torch.tensor([n + 12345, 7, 9], dtype=torch.int32, device=hip_vocoder.device)
     got, _ = hip_vocoder.forward(dev_ids, forced_dur=[1, 2, 1])
     assert torch.equal(got, ok)
+
+
+def test_empty_members_of_a_batch_are_refused(hip_model, hip_vocoder):
+    """The ragged-batch calls take per-utterance lengths from the host: a zero-length member (no encoder rows, no decoder states,
+    no units) is an argument error, like the single-utterance calls (Tp <= 0, K <= 0), not a zero-row segment for the kernels."""
+    enc = hip_model.encoder_forward(torch.from_numpy(synth.synth_fbank(5, 90)).to(hip_model.device))
+    with pytest.raises(L.StreamSpeechHipError):
+        hip_model.batch_mt_greedy(enc, [enc.shape[0], 0], [4, 4])
+    feats = torch.zeros((2, 6, hip_model.cfg.dec_dim), device=hip_model.device)
+    with pytest.raises(L.StreamSpeechHipError):
+        hip_model.batch_t2u_units(feats, [3, 0])
+    with pytest.raises(L.StreamSpeechHipError):
+        hip_vocoder.batch_forward([[1, 2, 3], []], forced_dur=[[1, 1, 1], []])
