@@ -337,8 +337,12 @@ __global__ __launch_bounds__(256) void smallm_gemm_kernel(const GemmArgs p) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int sk = wave / WN, wn = wave % WN;
   const int r = lane & 15, g = lane >> 4;
-  const int m0 = blockIdx.x * 16;
-  const int n0 = blockIdx.y * (16 * WN) + wn * 16;
+  // n-tiles run fastest and their count is a multiple of 8 (launch_smallm): blocks land on XCD (linear id % 8), so the W rows
+  // of an n-tile are fetched by ONE XCD's L2 for all m-tiles instead of by as many XCDs as there are m-tiles (the rows are
+  // the small operand here; MI355X_MICROARCH.md "block b runs on XCD b % 8" -- a speed affinity, nothing depends on it)
+  if ((int)blockIdx.x * (16 * WN) >= p.N) return;
+  const int m0 = blockIdx.y * 16;
+  const int n0 = blockIdx.x * (16 * WN) + wn * 16;
   const int K = p.Cin;
   const int KC = K / 16;                          // 16-wide chunks
   const int c_begin = (KC * sk) / SK, c_end = (KC * (sk + 1)) / SK;
@@ -707,6 +711,11 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream, int cls) {
   if constexpr (kLds > 64 * 1024) SS_MAX_LDS_ONCE((&conv_gemm_kernel<BM, BN, BK, WM, WN, KS, PD>), kLds);
   const int mmax = a.nseg > 0 ? a.max_seg_out : a.M;
   dim3 grid(cdiv(mmax, BM), cdiv(a.N, BN), a.nseg > 0 ? a.nseg : 1);
+  // XCD affinity (speed only): blocks land on XCD (linear id % 8).  With a multiple of 8 m-tiles per grid row every n-tile
+  // column keeps m-tile i on XCD i % 8, so each XCD's L2 fetches 1/8 of the A rows (and all of W) instead of all of both --
+  // the 3.0-3.9x counter-over-algorithmic traffic of the K = 256 encoder GEMMs (profiles/r02_pmc_traffic.json) was exactly
+  // 8 x (A + W) + C.  The padding blocks leave at once (m0 >= out_len); not worth it for a handful of tiles.
+  if (grid.x >= 32 && grid.y * grid.z > 1) grid.x = (grid.x + 7) & ~7u;
   ProfRec rec{}; bool prof = false;
   int rc = prof_begin(a, stream, cls, rec, prof);
   if (rc != SS_OK) return rc;
@@ -728,7 +737,7 @@ static int launch_cfg_ks(const GemmArgs& a, hipStream_t stream, int cls, long ti
 
 template <int SK, int WN>
 static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
-  dim3 grid(cdiv(a.M, 16), cdiv(a.N, 16 * WN));
+  dim3 grid((cdiv(a.N, 16 * WN) + 7) & ~7, cdiv(a.M, 16));   // see the kernel: n-tiles fastest, a multiple of 8 of them
   ProfRec rec{}; bool prof = false;
   int rc = prof_begin(a, stream, cls, rec, prof);
   if (rc != SS_OK) return rc;
