@@ -232,6 +232,9 @@ const char* ss_prof_class_name(int cls);
 int ss_debug_force_tile(int bm, int bn, int ks);
 /* Number of bounded-spin time-outs the stream-K kernel has recorded (any value but 0 is a bug). */
 int ss_debug_sk_errors(void);
+/* Test hook for the key-split form of the single-utterance rel-pos attention (csrc/attention.hip): -1 never split, 0 the
+ * launch heuristic (default), n > 0 force n key tiles (of 64 keys) per split. */
+int ss_debug_attention_split(int v);
 /* Test hook: the next launch of the persistent MT decode step behaves as if a bounded wait had timed out (it publishes -1),
  * without touching the counter above.  tests/test_mt_persistent_gpu.py drives the fall-back with it. */
 int ss_debug_mt_inject_timeout(ss_model* m);

@@ -9,10 +9,15 @@
 // (espnet_multihead_attention.py:186-196) never exist.
 #include "attention.hpp"
 
+#include <algorithm>
+#include <cstdlib>
+
 namespace ss {
 
 static int g_attn_no_mfma = 0;   // test hook: route plain attention to the VALU kernel
 void attention_debug_no_mfma(int v) { g_attn_no_mfma = v; }
+static int g_attn_split = getenv("SS_ATTN_NO_SPLIT") && atoi(getenv("SS_ATTN_NO_SPLIT")) ? -1 : 0;   // test hook (attention_debug_split); SS_ATTN_NO_SPLIT=1: A/B knob
+void attention_debug_split(int v) { g_attn_split = v; }
 
 constexpr int QB = 16;     // query rows per workgroup
 constexpr int KT = 64;     // keys per tile
@@ -388,8 +393,16 @@ constexpr int PWIN = 2 * KT;          // staged table rows (127 used, last one z
 constexpr int LDG = 36;               // per-wave G patch row stride
 constexpr size_t kRelposLds = (size_t)(KT * LDT + DH * LDT + PWIN * LDT + 4 * 16 * LDG) * sizeof(float);
 
+//
+// SPLIT (single utterance, few query tiles): the key tiles are cut into p.ksplit groups of p.ktiles_per_split, one workgroup
+// per (query tile, group, head) -- blockIdx.x = group * query_tiles + query_tile.  Each parks its un-normalised (o, m, l) in
+// its register layout (5 b128 per thread, agent-scope sc1 stores), then bumps the (query tile, head) counter; the workgroup
+// whose bump completes the count merges ALL groups in group order (so the result does not depend on who merges), writes O
+// and zeroes the counter.  Same hand-off rules as conv_sk2: sc1 b128 stores -> vmcnt(0) -> barrier -> relaxed agent-scope
+// atomic; sc1 loads on the other side (MI355X_MICROARCH.md: per-XCD L2s are not coherent).  Nobody waits for anybody.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void attention_relpos_mfma_kernel(AttnArgs p) {
-  if (p.nseg > 0) {
+  if (!SPLIT && p.nseg > 0) {
     const int* sg = p.segs + 4 * blockIdx.z;
     p.Tq = sg[1]; p.Tk = sg[3];
     if ((int)blockIdx.x * MQ >= p.Tq) return;
@@ -406,7 +419,9 @@ __global__ __launch_bounds__(256) void attention_relpos_mfma_kernel(AttnArgs p) 
   float* Gs = Ps + PWIN * LDT + wave * 16 * LDG;
   const int r = lane & 15, g = lane >> 4;
   const int h = blockIdx.y, hoff = h * DH;
-  const int i0 = blockIdx.x * MQ;
+  int qt = blockIdx.x, sp = 0;
+  if (SPLIT) { const int nqt = gridDim.x / p.ksplit; sp = blockIdx.x / nqt; qt = blockIdx.x - sp * nqt; }
+  const int i0 = qt * MQ;
   const int q0 = p.q0;
   const int iq = i0 + wave * 16 + r;                 // this lane's query row (relative to Q); absolute position q0 + iq
   const bool q_ok = iq < p.Tq;
@@ -432,8 +447,16 @@ __global__ __launch_bounds__(256) void attention_relpos_mfma_kernel(AttnArgs p) 
   int lim = p.Tk;
   if (p.chunk > 0) lim = min(lim, ((iq + q0) / p.chunk + 1) * p.chunk);
   if (!q_ok) lim = 0;
+  int jbeg = 0, jend = kmax, s_eff = 1;
+  if (SPLIT) {
+    const int span = p.ktiles_per_split * KT;
+    s_eff = (kmax + span - 1) / span;                // groups that hold a visible key of this query tile (chunk mask)
+    if (sp >= s_eff) return;
+    jbeg = sp * span;
+    jend = min(kmax, jbeg + span);
+  }
 
-  for (int j0 = 0; j0 < kmax; j0 += KT) {
+  for (int j0 = jbeg; j0 < jend; j0 += KT) {
     __syncthreads();
     for (int f = t; f < KT * (DH / 4); f += 256) {
       const int row = f >> 4, c4 = (f & 15) * 4;
@@ -530,6 +553,57 @@ __global__ __launch_bounds__(256) void attention_relpos_mfma_kernel(AttnArgs p) 
         for (int e = 0; e < 4; ++e) o[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[e], s[kt][e], o[dt], 0, 0, 0);
       }
   }
+  if (SPLIT && s_eff > 1) {
+    using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+    const int slot0 = (qt * (int)gridDim.y + h) * p.ksplit;
+    {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.part + (size_t)(slot0 + sp) * ATTN_PART_FLOATS), 0, ATTN_PART_FLOATS * 4, 0x00020000);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        u32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __float_as_uint(o[dt][e]);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, (dt * 256 + t) * 16, 0, 16);      // aux 16 = sc1 (agent scope)
+      }
+      const u32x4 ml = {__float_as_uint(m_run), __float_as_uint(l_run), 0u, 0u};
+      __builtin_amdgcn_raw_buffer_store_b128(ml, rs, (4 * 256 + t) * 16, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ int s_last;
+    unsigned* cnt = p.cnt + qt * (int)gridDim.y + h;
+    if (t == 0) s_last = (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(s_eff - 1)) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last arrival merges every group, in group order ----
+    float mx = -INFINITY;
+    for (int g2 = 0; g2 < s_eff; ++g2) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.part + (size_t)(slot0 + g2) * ATTN_PART_FLOATS), 0, ATTN_PART_FLOATS * 4, 0x00020000);
+      const u32x4 ml = __builtin_amdgcn_raw_buffer_load_b128(rs, (4 * 256 + t) * 16, 0, 16);
+      mx = fmaxf(mx, __uint_as_float(ml[0]));
+    }
+    float lsum = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int g2 = 0; g2 < s_eff; ++g2) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.part + (size_t)(slot0 + g2) * ATTN_PART_FLOATS), 0, ATTN_PART_FLOATS * 4, 0x00020000);
+      u32x4 v[5];
+#pragma unroll
+      for (int dt = 0; dt < 5; ++dt) v[dt] = __builtin_amdgcn_raw_buffer_load_b128(rs, (dt * 256 + t) * 16, 0, 16);
+      const float mg = __uint_as_float(v[4][0]);
+      const float f = (mg > -INFINITY) ? expf(mg - mx) : 0.f;
+      lsum += __uint_as_float(v[4][1]) * f;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[dt][e] += __uint_as_float(v[dt][e]) * f;
+    }
+    l_run = lsum;
+    if (t == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch of this context
+  }
   if (q_ok) {
     const float inv = 1.0f / l_run;
 #pragma unroll
@@ -563,8 +637,23 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     if ((a.nseg == 0 && a.q0 + a.Tq != a.Tk) || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
     if (a.nseg > 0 && a.p_tmax <= 0) return SS_ERR_ARG;
     if (!g_attn_no_mfma && ((a.ldq | a.ldo) & 3) == 0 && a.k_mask_tail == 0 && !a.causal) {
-      SS_MAX_LDS_ONCE(&attention_relpos_mfma_kernel, kRelposLds);
-      hipLaunchKernelGGL(attention_relpos_mfma_kernel, dim3(cdiv(tq, MQ), a.H, gz), dim3(256), kRelposLds, stream, a);
+      const int nqt = cdiv(tq, MQ), nkt = cdiv(a.Tk, KT);
+      // key split: one utterance with few (query tile, head) pairs and more than one key tile
+      if (a.nseg == 0 && a.part && g_attn_split >= 0 && nkt >= 2 && nqt * a.H <= a.cnt_slots && nqt * a.H < 128) {
+        int tps = g_attn_split > 0 ? g_attn_split : cdiv(nkt, std::min(16, std::max(1, 256 / (nqt * a.H))));
+        tps = std::max(tps, cdiv(nkt, 16));
+        const int S = cdiv(nkt, tps);
+        if (S >= 2 && nqt * a.H * S <= a.part_slots) {
+          AttnArgs b = a;
+          b.ksplit = S; b.ktiles_per_split = tps;
+          SS_MAX_LDS_ONCE(&attention_relpos_mfma_kernel<true>, kRelposLds);
+          hipLaunchKernelGGL(attention_relpos_mfma_kernel<true>, dim3(nqt * S, a.H, 1), dim3(256), kRelposLds, stream, b);
+          SS_LAUNCH_CHECK();
+          return SS_OK;
+        }
+      }
+      SS_MAX_LDS_ONCE(&attention_relpos_mfma_kernel<false>, kRelposLds);
+      hipLaunchKernelGGL(attention_relpos_mfma_kernel<false>, dim3(nqt, a.H, gz), dim3(256), kRelposLds, stream, a);
       SS_LAUNCH_CHECK();
       return SS_OK;
     }

@@ -29,7 +29,24 @@ struct AttnArgs {
   // of K/V; Tq/Tk above are ignored except max_q (grid sizing).  For the rel-pos form P must point
   // at row 0 of the FULL table (relative offset p_tmax-1) and the kernel slices it per segment.
   const int* segs = nullptr; int nseg = 0; int max_q = 0; int p_tmax = 0;
+  // Key-split scratch of the calling context (rel-pos form, single utterance only; nullptr = never split): few query tiles
+  // over many keys -- one utterance, or the tail rows of the incremental streaming encoder -- would otherwise run as
+  // (query tiles x heads) workgroups that each walk ALL key tiles one after the other.  See attention_relpos_mfma_kernel.
+  float* part = nullptr;       // [part_slots][ATTN_PART_FLOATS] parked partial (o, m, l) of a (query tile, head, key split)
+  unsigned* cnt = nullptr;     // [cnt_slots] arrivals per (query tile, head); zero between launches
+  int part_slots = 0, cnt_slots = 0;
+  int ksplit = 0, ktiles_per_split = 0;   // filled in by launch_attention
 };
+constexpr int ATTN_PART_FLOATS = 5 * 256 * 4;   // 5 b128 per thread: o[4], {m, l, -, -}
+constexpr int ATTN_PART_SLOTS = 512, ATTN_CNT_SLOTS = 512;
+inline size_t attention_split_bytes() { return (size_t)ATTN_PART_SLOTS * ATTN_PART_FLOATS * sizeof(float) + ATTN_CNT_SLOTS * sizeof(unsigned); }
+// points a.part / a.cnt into a scratch block of attention_split_bytes() bytes whose counter part is zero
+inline void attention_bind_split(AttnArgs& a, void* scratch) {
+  a.part = static_cast<float*>(scratch);
+  a.cnt = reinterpret_cast<unsigned*>(a.part + (size_t)ATTN_PART_SLOTS * ATTN_PART_FLOATS);
+  a.part_slots = ATTN_PART_SLOTS; a.cnt_slots = ATTN_CNT_SLOTS;
+}
+void attention_debug_split(int v);     // test hook: -1 never split, 0 heuristic, n > 0 key tiles per split = n
 
 int launch_attention(const AttnArgs& a, hipStream_t stream);
 void attention_debug_no_mfma(int v);   // test hook: 1 routes plain attention to the VALU kernel

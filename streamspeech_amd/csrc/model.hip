@@ -145,6 +145,7 @@ struct ss_model {
   int mt_Tp = 0;
   int mt_len = 0;
   const float* mt_enc = nullptr;
+  DevBuf attn_split;             // key-split scratch of the single-utterance rel-pos attention (attention.hpp); counters zeroed once
   DevBuf mt_gran;                // persistent decode step (mt_step.hip): granule region, zeroed once; the epoch grows per launch
   unsigned mt_epoch = 0;
   int mt_inject_timeout = 0;     // ss_debug_mt_inject_timeout: the next persistent launch reports a time-out
@@ -161,6 +162,18 @@ struct ss_model {
   int es_cap = 0, es_final = 0, es_achunk = -1, es_cchunk = -1;
   int es_tail = 0;                                  // trailing fbank frames that may still change (resampler edge)
 };
+
+// Key-split scratch of this context for the single-utterance rel-pos attention: allocated and zeroed on first use (the
+// counters must read zero; the stream is synchronised once so that a later call on another stream sees them).
+static int bind_attn_split(ss_model* m, AttnArgs& at, hipStream_t s) {
+  if (!m->attn_split.p) {
+    RET(m->attn_split.ensure(attention_split_bytes()));
+    SS_HIP_CHECK(hipMemsetAsync(m->attn_split.p, 0, attention_split_bytes(), s));
+    SS_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  attention_bind_split(at, m->attn_split.p);
+  return SS_OK;
+}
 
 static int load_dec_layers(ss_model* m, std::vector<DecLayer>& v, const std::string& pfx, int n, int D, int F,
                            int kv_in, bool cross) {
@@ -283,7 +296,7 @@ extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t
 extern "C" void ss_model_destroy(ss_model* m) {
   if (!m) return;
   m->pos_proj.release(); m->ws.release(); m->mt_cross.release(); m->mt_self.release(); m->mt_ws.release();
-  m->mt_tok.release(); m->seg_buf.release(); m->bmt_self.release(); m->mt_gran.release();
+  m->mt_tok.release(); m->seg_buf.release(); m->bmt_self.release(); m->mt_gran.release(); m->attn_split.release();
   m->es_qkv.release(); m->es_glu.release(); m->es_out.release();
   if (m->mt_tok_host) (void)hipHostFree(m->mt_tok_host);
   sk_workspace_free(m->skws);
@@ -372,6 +385,7 @@ extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fban
     at.Q = qkv; at.K = qkv + d; at.V = qkv + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
     at.O = h; at.ldo = d; at.Tq = T2; at.Tk = T2; at.H = c.enc_heads; at.scale = 0.125f;
     at.chunk = achunk; at.P = P + (size_t)l * d; at.ldp = Ld; at.bias_u = e.u; at.bias_v = e.v;
+    RET(bind_attn_split(m, at, s));
     RET(launch_attention(at, s));
     RET(linear(s, h, d, T2, e.out, d, d, x, d, ACT_NONE, 1.f, x, d));
     // x = x + ConvModule(x)
@@ -518,6 +532,7 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
       at.Q = qkv + (size_t)r0 * 3 * d; at.K = qkv + d; at.V = qkv + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
       at.O = h; at.ldo = d; at.Tq = n; at.Tk = T2; at.q0 = r0; at.H = c.enc_heads; at.scale = 0.125f;
       at.chunk = achunk; at.P = P + (size_t)l * d; at.ldp = Ld; at.bias_u = e.u; at.bias_v = e.v;
+      RET(bind_attn_split(m, at, s));
       RET(launch_attention(at, s));
       RET(linear(s, h, d, n, e.out, d, d, x, d, ACT_NONE, 1.f, x, d));
       RET(ln_linear(s, x, n, e.conv_ln, e.pw1, 2 * d, d, glu + (size_t)r0 * d, d, h, ACT_NONE, 1.f, 1));
@@ -1511,8 +1526,18 @@ extern "C" int ss_op_attention(void* stream, const float* dQ, int ldq, const flo
   a.Q = dQ; a.ldq = ldq; a.K = dK; a.ldk = ldk; a.V = dV; a.ldv = ldv; a.O = dO; a.ldo = ldo;
   a.Tq = Tq; a.Tk = Tk; a.H = H; a.scale = scale; a.causal = causal; a.chunk = chunk;
   a.P = dP; a.ldp = ldp; a.bias_u = du; a.bias_v = dv;
+  if (dP) {                                               // test op: one process-wide key-split scratch (callers are serial)
+    static void* scratch = nullptr;
+    if (!scratch) {
+      SS_HIP_CHECK(hipMalloc(&scratch, attention_split_bytes()));
+      SS_HIP_CHECK(hipMemset(scratch, 0, attention_split_bytes()));
+    }
+    attention_bind_split(a, scratch);
+  }
   return launch_attention(a, (hipStream_t)stream);
 }
+
+extern "C" int ss_debug_attention_split(int v) { attention_debug_split(v); return SS_OK; }
 
 extern "C" int ss_op_dwconv_bn_silu(void* stream, const float* dx, int ldx, float* dy, int ldy, const float* dwt,
                                     int K, const float* mean, const float* var, const float* gamma,

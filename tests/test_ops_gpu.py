@@ -182,6 +182,40 @@ def test_relpos_attention(lib, T, chunk):
     assert err < 5e-5, f"{err}"
 
 
+@pytest.mark.parametrize("T,chunk", [(65, 0), (200, 16), (449, 0), (700, 24), (1000, 0)])
+def test_relpos_attention_key_split_equals_the_serial_key_walk(lib, T, chunk):
+    """Single-utterance rel-pos attention: the key-split form (one workgroup per (query tile, key group, head), last arrival
+    merges in group order) against the serial walk over the key tiles, for the launch heuristic and forced group sizes;
+    repeated launches reuse the same counters (they must be back at zero) and reproduce their bits."""
+    from streamspeech_amd import lib as L
+    H = 4
+    qkv = rnd(T, 3 * 256, seed=119)
+    Pt = rnd(2 * T - 1, 256, seed=120)
+    u, vb = rnd(256, seed=121) * 0.3, rnd(256, seed=122) * 0.3
+    dqkv, dP, du, dv = qkv.cuda(), Pt.cuda(), u.cuda(), vb.cuda()
+
+    def run():
+        out = torch.full((T, 256), float("nan"), device="cuda")
+        L.check(lib.ss_op_attention(S(), P(dqkv), 768, C.c_void_p(dqkv.data_ptr() + 256 * 4), 768,
+                                    C.c_void_p(dqkv.data_ptr() + 512 * 4), 768, P(out), 256, T, T, H, 0.125, 0, chunk,
+                                    P(dP), 256, P(du), P(dv)), "attn")
+        return out
+    try:
+        lib.ss_debug_attention_split(-1)
+        serial = run()
+        ref = _attn_ref(qkv[:, :256], qkv[:, 256:512], qkv[:, 512:], H, 0.125, False, chunk, Pt, u, vb)
+        assert (serial.cpu() - ref).abs().max() < 5e-5
+        for mode in (0, 1, 3):
+            lib.ss_debug_attention_split(mode)
+            a = run()
+            b = run()
+            assert torch.equal(a, b), f"split mode {mode}: not reproducible / counters not reset"
+            err = (a - serial).abs().max().item()
+            assert err < 3e-6, f"split mode {mode}: {err}"
+    finally:
+        lib.ss_debug_attention_split(0)
+
+
 @pytest.mark.parametrize("Tq,Tk,causal", [(130, 130, 1), (1, 37, 1), (50, 21, 0), (525, 525, 1), (9, 9, 0), (3, 40, 1)])
 def test_plain_attention(lib, Tq, Tk, causal):
     from streamspeech_amd import lib as L
