@@ -76,10 +76,24 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
   const int tid = threadIdx.x, cl = tid & (DW_TC - 1), rg = tid >> 6;
   const int half = K / 2;
   const int rows = DW_TT + K - 1;                    // slab row s <-> input row t0 - half + s
-  for (int idx = tid; idx < rows * DW_TC; idx += 256) {
-    const int sr = idx / DW_TC, cc = idx - sr * DW_TC;
-    const int tin = t0 - half + sr;
-    slab[idx] = (tin >= 0 && tin < T && c0 + cc < C) ? x[(size_t)tin * ldx + c0 + cc] : 0.f;
+  {
+    // All 16 loads of a thread are issued before the first LDS store: with a run-time trip count the loop was one
+    // load -> wait -> store per iteration, ~1 us each when the launch is a handful of workgroups (a single utterance, the tail
+    // rows of a streaming call): 13-18 us per launch whatever the row count (profiles/r03_streaming_kernel_stats.csv).
+    constexpr int NL = ((DW_TT + DW_KMAX - 1) * DW_TC + 255) / 256;
+    float v[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int idx = tid + i * 256;
+      const int sr = idx / DW_TC, cc = idx - sr * DW_TC;
+      const int tin = t0 - half + sr;
+      v[i] = (sr < rows && tin >= 0 && tin < T && c0 + cc < C) ? x[(size_t)tin * ldx + c0 + cc] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+      const int idx = tid + i * 256;
+      if (idx < (DW_TT + DW_KMAX - 1) * DW_TC) slab[idx] = v[i];
+    }
   }
   const int c = c0 + cl;
   float w[DW_KMAX];
@@ -88,20 +102,28 @@ __global__ __launch_bounds__(256) void dwconv_bn_silu_kernel(
   __syncthreads();
   if (c >= C) return;
   const float mean = bn_mean[c], rstd = 1.0f / sqrtf(bn_var[c] + bn_eps), gam = bn_gamma[c], bet = bn_beta[c];
-#pragma unroll 1
-  for (int u = 0; u < DW_TT / 4; ++u) {
-    const int lt = rg * (DW_TT / 4) + u;             // row inside the tile
-    const int t = t0 + lt;
-    if (t >= T) break;
+  // This thread's 8 consecutive rows share their taps' inputs: slab rows rg*8 .. rg*8 + 37 of channel cl are read ONCE into
+  // registers (38 LDS reads in flight together), then each row slides over them.  Branch-free: the visibility test selects
+  // the result of every tap -- with `if (j < jmax)` around the fma each tap was its own read -> wait -> fma, 13 us per
+  // launch whatever the row count (tools/dwconv_probe.py; 12 such launches per encoder call of a single utterance).
+  constexpr int NR = DW_TT / 4, NV = NR + DW_KMAX - 1;
+  float sv[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) sv[i] = slab[(rg * NR + i) * DW_TC + cl];
+#pragma unroll
+  for (int u = 0; u < NR; ++u) {
+    const int t = t0 + rg * NR + u;
     int lim = T;                                     // first invisible input row
     if (chunk > 0) { const int cl_end = (t / chunk + 1) * chunk; if (cl_end < lim) lim = cl_end; }
     const int jmax = min(K, lim - (t - half));       // taps j < jmax are visible (input row t - half + j < lim)
     float acc = 0.f;
 #pragma unroll
-    for (int j = 0; j < DW_KMAX; ++j)
-      if (j < jmax) acc = fmaf(w[j], slab[(lt + j) * DW_TC + cl], acc);
+    for (int j = 0; j < DW_KMAX; ++j) {
+      const float a2 = fmaf(w[j], sv[u + j], acc);
+      acc = (j < jmax) ? a2 : acc;
+    }
     const float v = (acc - mean) * rstd * gam + bet;
-    y[(size_t)t * ldy + c] = v / (1.0f + expf(-v));
+    if (t < T) y[(size_t)t * ldy + c] = v / (1.0f + expf(-v));
   }
 }
 
