@@ -830,7 +830,11 @@ bool smallm_eligible(const GemmArgs& a) {
                             (a.act == ACT_NONE || a.act == ACT_SILU || a.act == ACT_RELU);
   // row limit of the no-LDS kernel: every 16-row tile re-streams its W columns from L2, so it only pays while the whole
   // problem is latency-bound (SS_SMALLM_MAX_ROWS: tuning knob, tools/latency_breakdown.py)
-  static const int max_rows = getenv("SS_SMALLM_MAX_ROWS") ? atoi(getenv("SS_SMALLM_MAX_ROWS")) : 128;
+  // 192: a single utterance of 5-7.7 s (T' = 129..192 encoder rows, a third of the CVSS-C length distribution) keeps its 12 x 9
+  // linears on this kernel instead of the 32x32-tile kernel, whose k-loop is one global-load round trip per k-step when a
+  // launch is this small: 6.43 -> 6.26 ms per utterance at T' = 131 (tools/b1_profile.py); beyond ~200 rows the re-streaming
+  // costs what the tiles' latency did (8.24 vs 8.18 ms at T' = 201 with 256), and the 500-row unit decoder loses 2x.
+  static const int max_rows = getenv("SS_SMALLM_MAX_ROWS") ? atoi(getenv("SS_SMALLM_MAX_ROWS")) : 192;
   return plain_linear && M <= max_rows && M > 0 && a.Cin % 64 == 0 && (a.lda & 3) == 0;
 }
 

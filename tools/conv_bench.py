@@ -133,7 +133,31 @@ def sweep_slab():
     lib.ss_debug_force_tile(0, 0, 0)
 
 
+def sweep_b1():
+    """single-utterance encoder / decoder linears (M = 131 and 201 rows, just past the small-M kernel's row limit): the
+    32x32 tile kernel with k-split KS and register prefetch depth PD; run once more with SS_SMALLM_MAX_ROWS=256 in the
+    environment to see the small-M kernel ("heur" column) on the same shapes."""
+    shapes = []
+    for M in (131, 201):
+        shapes += [(f"ffn1 M={M}", M, 2048, 256, 1), (f"ffn2 M={M}", M, 256, 2048, 1), (f"qkv M={M}", M, 768, 256, 1),
+                   (f"out M={M}", M, 256, 256, 1)]
+    shapes += [("unit fc1 M=500", 500, 2048, 512, 1), ("unit fc2 M=500", 500, 512, 2048, 1)]
+    cfgs = [("heur", 0, 0, 0), ("32x32/11", 32, 32, 11), ("32x32/14", 32, 32, 14), ("32x32/23", 32, 32, 23), ("32x32/43", 32, 32, 43),
+            ("32x64/11", 32, 64, 11), ("32x64/14", 32, 64, 14), ("32x64/43", 32, 64, 43)]
+    print("%-16s" % "shape" + "".join("%10s" % c[0] for c in cfgs) + "   GFLOP")
+    for name, M, N, Cin, taps in shapes:
+        line = "%-16s" % name
+        for _, bm, bn, ks in cfgs:
+            lib.ss_debug_force_tile(bm, bn, ks)
+            r = bench(name, M, N, Cin, taps, 1, reps=50)
+            line += "%10.1f" % r["us"]
+        print(line + "   %6.3f" % r["gflop"], flush=True)
+    lib.ss_debug_force_tile(0, 0, 0)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "b1":
+        return sweep_b1()
     if len(sys.argv) > 1 and sys.argv[1] == "enc":
         return sweep_enc()
     if len(sys.argv) > 1 and sys.argv[1] == "slab":
