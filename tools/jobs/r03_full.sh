@@ -6,7 +6,7 @@ mkdir -p $O
 export TMPDIR=/tmp
 X="--no-multilingual --no-streaming-line --no-bracket-ab"
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
-# rocprofv3 7.2 sometimes dies (SIGSEGV inside its hipEventRecord interception) under the 8 host threads of this command: up to 3 tries
+# rocprofv3 7.2 often dies (SIGSEGV inside its own HIP-API interception) under the 8 host threads of this command: up to 3 tries
 for try in 1 2 3; do
   rm -rf $O/prof_driver
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_driver -- python bench.py --steps 20 --warmup 5 > $O/bench_under_rocprof.json 2> $O/prof_driver.err && ls $O/prof_driver/*/*_kernel_stats.csv > /dev/null 2>&1 && break
