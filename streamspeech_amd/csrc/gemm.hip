@@ -329,9 +329,10 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
 // of 4 chunks kept in flight.  The SK partial tiles are summed through LDS once at the end.
 // Optional fused LayerNorm over K on the A rows (two-pass statistics per wave, rows stay in L1).
 // =================================================================================================
-template <int SK, int WN, bool LNORM>
+template <int SK, int WN, bool LNORM, bool GLU = false>
 __global__ __launch_bounds__(256) void smallm_gemm_kernel(const GemmArgs p) {
   static_assert(SK * WN == 4, "4 waves");
+  static_assert(!GLU || (SK == 2 && WN == 2), "GLU: wave column 0 = the 16 value columns, 1 = the 16 gate columns of a 32-column block");
   __shared__ f32x4 red[SK > 1 ? (SK - 1) * WN * 64 : 1];
   __shared__ float ln_stat[32];                   // mean[16], rstd[16] of the workgroup's rows
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -437,13 +438,38 @@ __global__ __launch_bounds__(256) void smallm_gemm_kernel(const GemmArgs p) {
   if (SK > 1) {
     if (sk > 0) red[((sk - 1) * WN + wn) * 64 + lane] = acc;
     __syncthreads();
-    if (sk > 0) return;
+    if (!GLU && sk > 0) return;
+    if (sk == 0) {
 #pragma unroll
-    for (int s2 = 1; s2 < SK; ++s2) {
-      const f32x4 o = red[((s2 - 1) * WN + wn) * 64 + lane];
+      for (int s2 = 1; s2 < SK; ++s2) {
+        const f32x4 o = red[((s2 - 1) * WN + wn) * 64 + lane];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) acc[e] += o[e];
+        for (int e = 0; e < 4; ++e) acc[e] += o[e];
+      }
     }
+  }
+  if constexpr (GLU) {
+    // out[m, 16 b + r] = (value + bias) * sigmoid(gate + bias): the gate wave hands its tile to the value wave through LDS
+    // (same formula and packing as the tile kernel's GLU epilogue: [16 value | 16 gate] column blocks)
+    __shared__ f32x4 gate_tile[64];
+    const int ncol = n0 + r;                               // this lane's column of the packed [value | gate] matrix
+    const float bcol = (p.bias && ncol < p.N) ? p.bias[ncol] : 0.f;
+    if (sk == 0 && wn == 1) {
+      f32x4 gt;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) gt[e] = acc[e] + bcol;
+      gate_tile[lane] = gt;
+    }
+    __syncthreads();
+    if (sk != 0 || wn != 0 || ncol + 16 >= p.N) return;
+    const f32x4 gt = gate_tile[lane];
+    const int oc = (int)blockIdx.x * 16 + r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int m = m0 + g * 4 + e;
+      if (m < p.M) p.C[(size_t)m * p.ldc + oc] = (acc[e] + bcol) * (1.0f / (1.0f + expf(-gt[e])));
+    }
+    return;
   }
   const int n = n0 + r;
   if (n >= p.N) return;
@@ -572,7 +598,7 @@ __global__ __launch_bounds__(256) void gemv_kernel(const GemmArgs p) {
 }
 
 bool gemv_eligible(const GemmArgs& a) {
-  return smallm_eligible(a) && a.M <= 4 && a.Cin % 256 == 0 && a.Cin <= 2048;
+  return smallm_eligible(a) && !a.glu && a.M <= 4 && a.Cin % 256 == 0 && a.Cin <= 2048;   // (the GEMV has no GLU epilogue)
 }
 
 template <int KS>
@@ -741,15 +767,15 @@ static int launch_cfg_ks(const GemmArgs& a, hipStream_t stream, int cls, long ti
   return launch_cfg<BM, BN, BK, WM, WN, 1>(a, stream, cls);
 }
 
-template <int SK, int WN>
+template <int SK, int WN, bool GLU = false>
 static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
   dim3 grid((cdiv(a.N, 16 * WN) + 7) & ~7, cdiv(a.M, 16));   // see the kernel: n-tiles fastest, a multiple of 8 of them
   ProfRec rec{}; bool prof = false;
   int rc = prof_begin(a, stream, cls, rec, prof);
   if (rc != SS_OK) return rc;
   if (a.ln_g && a.Cin > 512) return SS_ERR_ARG;   // fused LayerNorm keeps the row in registers (D <= 512)
-  if (a.ln_g) hipLaunchKernelGGL((smallm_gemm_kernel<SK, WN, true>), grid, dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL((smallm_gemm_kernel<SK, WN, false>), grid, dim3(256), 0, stream, a);
+  if (a.ln_g) hipLaunchKernelGGL((smallm_gemm_kernel<SK, WN, true, GLU>), grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((smallm_gemm_kernel<SK, WN, false, GLU>), grid, dim3(256), 0, stream, a);
   SS_LAUNCH_CHECK();
   return prof_end(stream, rec, prof);
 }
@@ -831,7 +857,9 @@ void debug_force_tile(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn
 bool smallm_eligible(const GemmArgs& a) {
   if (g_force_bm > 1) return false;
   const int M = a.nseg > 0 ? a.max_seg_out : a.M;
-  const bool plain_linear = a.taps == 1 && a.stride == 1 && a.pad == 0 && !a.glu && a.nseg == 0 && a.chunk == 0 &&
+  // GLU (the conformer conv module's pointwise conv 1): only in its plain form -- no activation, scale or residual on top
+  const bool glu_ok = !a.glu || (a.N % 32 == 0 && a.act == ACT_NONE && a.alpha == 1.f && !a.R);
+  const bool plain_linear = a.taps == 1 && a.stride == 1 && a.pad == 0 && glu_ok && a.nseg == 0 && a.chunk == 0 &&
                             a.in_act == ACT_NONE && !a.R2 && !a.C2 && a.div == 0.f &&
                             (a.act == ACT_NONE || a.act == ACT_SILU || a.act == ACT_RELU);
   // row limit of the no-LDS kernel: every 16-row tile re-streams its W columns from L2, so it only pays while the whole
@@ -856,6 +884,7 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (!g_force_bm && gemv_eligible(a)) return launch_gemv(a, stream);
   if (a.ln_out) return SS_ERR_ARG;      // only the GEMV form publishes the normalised rows
   if (smallm_eligible(a)) {
+    if (a.glu) return launch_smallm<2, 2, true>(a, stream, 13);   // value / gate tiles side by side in one workgroup
     const long wgs16 = (long)cdiv(M, 16) * cdiv(a.N, 16);
     if (a.Cin >= 1024 || wgs16 <= 1024) return launch_smallm<4, 1>(a, stream, 12);
     if (wgs16 <= 4096) return launch_smallm<2, 2>(a, stream, 13);

@@ -93,6 +93,22 @@ def test_subsampler_conv_glu(lib, cin, cout, T, chunk):
     assert (got - ref).abs().max() < TOL, f"{(got - ref).abs().max()}"
 
 
+@pytest.mark.parametrize("M", [1, 15, 16, 40, 131, 192, 193, 700])
+def test_pointwise_glu_linear(lib, M):
+    """The conformer conv module's pointwise conv 1 + GLU (conformer_layer.py:94-119: 256 -> 512, no bias in the checkpoint; a
+    bias here to cover the epilogue): the small-M kernel's GLU form (M <= 192 rows: single utterances, streaming tail rows)
+    and the tile kernel's (beyond) against torch."""
+    from streamspeech_amd.weights import conv_tap_major, glu_interleave
+    cin, cout = 256, 512
+    x = rnd(M, cin, seed=205)
+    w = rnd(cout, cin, 1, seed=206, scale=cin ** -0.5)
+    b = rnd(cout, seed=207, scale=0.1)
+    ref = F.glu(x @ w[:, :, 0].t() + b, dim=1)
+    got = run_conv_gemm(lib, x, conv_tap_major(glu_interleave(w)), glu_interleave(b), M, cout, cin, taps=1, glu=1)
+    assert got.shape == ref.shape == (M, cout // 2)
+    assert (got - ref).abs().max() < TOL, f"{(got - ref).abs().max()}"
+
+
 @pytest.mark.parametrize("C,k,dil,T", [(256, 11, 5, 300), (128, 7, 3, 1000), (64, 3, 1, 700), (32, 7, 3, 900),
                                        (16, 11, 5, 2000), (16, 3, 1, 257), (512, 7, 1, 50)])
 def test_resblock_conv(lib, C, k, dil, T):
