@@ -2,7 +2,11 @@
 """bench.py -- offline S2ST (BASELINE.json configs[1]) real-time factor on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by torch.distributed.run, one rank per GPU, utterance-level data parallel)
+  (N > 1: one rank per GPU, utterance-level data parallel over RCCL.  Either launched by torch.distributed.run
+   (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment -- what the driver does), or typed as above with no
+   launcher: the command then re-executes itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+   --master-addr 127.0.0.1 --master-port <free>` with the same arguments, rank 0 prints the one JSON line, the exit code
+   is the launcher's.  `--dry-plan` runs the plan + barrier + reductions of that path on CPU over gloo, no GPU.)
 
 A "step" is one pass of the whole HIP hot path over one ragged batch of --batch (32) synthetic
 utterances, each with B = 1 arithmetic (streamspeech_amd/workload.py): PCM already in HBM ->
@@ -349,6 +353,138 @@ def _pmc_file():
 PMC_FILE = _pmc_file()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` typed without a launcher (fairseq's own entry does the same: distributed_utils.call_main
+    spawns one process per device, fairseq/fairseq/distributed/utils.py:344-380): run the same command line under
+    torch.distributed.run, one rank per GPU, and leave with its exit code (non-zero if any rank failed)."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC only on this host driver (RCCL needs it)
+    env["SS_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.call(cmd, env=env)
+
+
+def comm_probe(dist, device, reps=20):
+    """The collectives of the utterance-DP path (one barrier before the timed region, MAX / SUM all-reduce and
+    one all-gather of three doubles after it), timed on an initialised process group -- untimed for `value`."""
+    def sync():
+        if str(device).startswith("cuda"):
+            torch.cuda.synchronize()
+
+    def timed(fn):
+        fn()
+        sync()
+        t = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        sync()
+        return round(1e6 * (time.perf_counter() - t) / reps, 2)
+
+    world = dist.get_world_size()
+    t3 = torch.tensor([1.0 + dist.get_rank(), 2.0, 3.0], dtype=torch.float64, device=device)
+    outs = [torch.zeros_like(t3) for _ in range(world)]
+    res = {"backend": dist.get_backend(), "world": world,
+           "barrier_us": timed(dist.barrier),
+           "all_reduce_max_3xf64_us": timed(lambda: dist.all_reduce(t3.clone(), op=dist.ReduceOp.MAX)),
+           "all_reduce_sum_3xf64_us": timed(lambda: dist.all_reduce(t3.clone(), op=dist.ReduceOp.SUM)),
+           "all_gather_3xf64_us": timed(lambda: dist.all_gather(outs, t3))}
+    mx, sm = t3.clone(), t3.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    dist.all_reduce(sm, op=dist.ReduceOp.SUM)
+    dist.all_gather(outs, t3)
+    sync()
+    res["results_ok"] = bool(float(mx[0]) == float(world) and float(sm[1]) == 2.0 * world
+                             and [float(o[0]) for o in outs] == [1.0 + r for r in range(world)])
+    return res
+
+
+def rccl_probe_main():
+    """`bench.py --rccl-probe`: initialise the nccl (= RCCL) backend on this GPU as a world of one and run the DP path's
+    collectives; printed as one JSON object.  bench.py runs this as a SUBPROCESS with a time-out after its measurement at
+    N = 1 (a communicator that fails or hangs on some box must not cost the bench line), SS_FORCE_DIST=1 runs the same
+    inside the bench process instead, around the timed region."""
+    import datetime
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    t0 = time.perf_counter()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            timeout=datetime.timedelta(seconds=60), device_id=torch.device("cuda", 0))
+    dist.barrier()
+    torch.cuda.synchronize()
+    init_ms = 1e3 * (time.perf_counter() - t0)
+    out = comm_probe(dist, "cuda:0")
+    out["init_plus_first_barrier_ms"] = round(init_ms, 1)
+    try:
+        out["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:  # noqa: BLE001
+        pass
+    dist.destroy_process_group()
+    print(json.dumps(out), flush=True)
+
+
+def rccl_probe_subprocess(timeout_s=120):
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--rccl-probe"], env=env, capture_output=True, text=True,
+                           timeout=timeout_s)
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{"):
+                out = json.loads(line)
+                out["how"] = "subprocess `bench.py --rccl-probe` on the same GPU after the measurement (world of one)"
+                return out
+        return {"error": f"rc {r.returncode}: " + (r.stderr.strip().splitlines() or ["no output"])[-1][:300]}
+    except subprocess.TimeoutExpired:
+        return {"error": f"timed out after {timeout_s} s"}
+    except Exception as e:  # noqa: BLE001
+        return {"error": repr(e)[:300]}
+
+
+def dry_plan(args, rank, world):
+    """`--dry-plan`: the N-rank control path with no GPU -- every rank forms its share of the plan (workload.bench_plan, the
+    function the real run uses), meets the barrier, and the (wall, audio seconds, utterances) statistics go through the same
+    MAX / SUM all-reduce + all-gather over gloo (tests/test_dp_gloo.py runs `bench.py --gpus 2 --dry-plan` as typed)."""
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")
+    Ksteps, Bsz = max(1, args.steps), max(1, args.batch)
+    mine, groups = workload.bench_plan(Ksteps, Bsz, rank, world, bucket=not args.no_length_bucketing, warm=3, strong=args.scaling == "strong")
+    timed_ids = [i for g in groups for i in g]
+    audio = sum(mine[i].seconds for i in timed_ids)
+    if os.environ.get("SS_BENCH_DRY_FAIL_RANK") == str(rank):     # tests: a dying rank must fail the whole command
+        raise SystemExit(3)
+    if dist is not None:
+        dist.barrier()
+    wall = 1.0 + 0.001 * rank          # a stand-in wall time: the MAX must pick the last rank's
+    per_rank = dp.gather_per_rank(dist, wall, audio, float(len(timed_ids)))
+    wall_max, audio_tot, nutt = dp.reduce_stats(dist, wall, audio, float(len(timed_ids)))
+    comm = comm_probe(dist, "cpu", reps=5) if dist is not None else None
+    if rank == 0:
+        print(json.dumps({"metric": "real-time factor (RTFx = audio seconds / wall seconds) + utterances/sec, offline S2ST fr-en",
+                          "dry_plan": True, "value": None, "unit": "x real-time", "n_gpus": world, "steps": Ksteps, "warmup": max(0, args.warmup),
+                          "scaling": args.scaling, "steps_per_gpu": len(groups), "utterances_per_step": Bsz,
+                          "planned_audio_seconds": round(audio_tot, 2), "planned_utterances": int(nutt),
+                          "stand_in_wall_max_s": wall_max, "per_rank": per_rank, "comm": comm,
+                          "self_launched": bool(os.environ.get("SS_BENCH_SELF_LAUNCHED"))}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -375,27 +511,40 @@ def main():
     ap.add_argument("--utterances", type=int, default=12, help="--mode streaming: utterances per configuration")
     ap.add_argument("--no-length-bucketing", action="store_true",
                     help="form ragged batches in arrival order instead of sorted by source length")
+    ap.add_argument("--dry-plan", action="store_true",
+                    help="no GPU: form every rank's plan and run the barrier + statistics reductions over gloo (the N > 1 control path)")
+    ap.add_argument("--rccl-probe", action="store_true", help="internal: world-of-one RCCL initialisation + the DP collectives, one JSON object")
+    ap.add_argument("--no-rccl-probe", action="store_true", help="skip the RCCL probe of the N = 1 line")
     args = ap.parse_args()
+    if args.rccl_probe:
+        return rccl_probe_main()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))        # typed without a launcher: one rank per GPU under torch.distributed.run
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running with the launcher's world size", file=sys.stderr)
+    if args.dry_plan:
+        return dry_plan(args, rank, world)
     # one process per GPU; the modulo only matters for the 2-ranks-on-1-GPU smoke test of this code path
     # (SS_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2)
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = world == 1 and os.environ.get("SS_FORCE_DIST") == "1"   # a world of one still goes through RCCL: init, barrier, reductions
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         backend = os.environ.get("SS_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        kw = {}
+        if "MASTER_ADDR" not in os.environ:                           # SS_FORCE_DIST=1 typed without a launcher
+            kw = {"init_method": f"tcp://127.0.0.1:{_free_port()}", "rank": 0, "world_size": 1}
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, **kw)
 
     cfg, vcfg = ModelConfig(), VocoderConfig()
     sd = synth.make_model_state_dict(0, cfg)
@@ -557,6 +706,11 @@ def main():
     audio = sum(mine[i].seconds for i in timed_ids)
     per_rank = dp.gather_per_rank(dist, wall, audio, float(K), device=dev)
     wall, audio, nutt = dp.reduce_stats(dist, wall, audio, float(K), device=dev)
+    rccl = None
+    if dist is not None:                     # the DP path's collectives on the live communicator (untimed for `value`)
+        rccl = comm_probe(dist, dev if dist.get_backend() == "nccl" else "cpu")
+        rccl["how"] = ("this process group: the barriers around the timed region and the MAX / SUM / all-gather of the statistics above went "
+                       "through it" + ("; SS_FORCE_DIST=1 (world of one)" if force_dist else ""))
 
     def read_class(c):
         ms, fl, n, by = C.c_double(), C.c_double(), C.c_int64(), C.c_double()
@@ -828,6 +982,8 @@ def main():
             "roofline_second_kernel": roofline_conv,
             "process_census": census(lib),
             "per_rank": per_rank,
+            "rccl": rccl if (rccl is not None or args.no_rccl_probe) else rccl_probe_subprocess(),
+            "self_launched": bool(os.environ.get("SS_BENCH_SELF_LAUNCHED")),
             "timed_region_monotonic_ns": [t0_mono_ns, t1_mono_ns],   # tools/trace_gaps.py: window of a rocprofv3 kernel trace
         }
         if world == 1 and not args.no_cpu_baseline:

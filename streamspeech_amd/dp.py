@@ -26,7 +26,7 @@ def balanced_shards(durations: Sequence[float], world: int) -> List[List[int]]:
 
 def reduce_stats(dist, wall: float, audio_s: float, n_utts: float, device="cpu") -> Tuple[float, float, float]:
     """(max wall over ranks, total audio seconds, total utterances)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():       # an initialised world of one still runs the collectives (SS_FORCE_DIST=1)
         return wall, audio_s, n_utts
     t = torch.tensor([wall, audio_s, n_utts], dtype=torch.float64, device=device)
     mx = t.clone()
@@ -38,7 +38,7 @@ def reduce_stats(dist, wall: float, audio_s: float, n_utts: float, device="cpu")
 def gather_per_rank(dist, wall: float, audio_s: float, n_utts: float, device="cpu") -> List[dict]:
     """Per-rank (wall, audio seconds, utterances) on every rank, so that load imbalance is visible in the bench line
     (one more 3-double all-gather after the timed region; the scaling loss of this path is imbalance, not communication)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return [{"rank": 0, "wall_s": round(wall, 5), "audio_s": round(audio_s, 2), "utterances": int(n_utts)}]
     world = dist.get_world_size()
     t = torch.tensor([wall, audio_s, n_utts], dtype=torch.float64, device=device)

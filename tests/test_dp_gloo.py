@@ -84,3 +84,43 @@ def test_strong_scaling_plan_partitions_one_fixed_set():
     # fewer steps than ranks: the 64 utterances still split 8 ways (one short batch per rank)
     assert sum(len(workload.bench_plan(2, 32, r, 8, strong=True)[1]) for r in range(8)) == 8 and \
         all(len(g) == 8 for r in range(8) for g in workload.bench_plan(2, 32, r, 8, strong=True)[1])
+
+
+def test_bench_gpus_2_as_typed_self_launches_its_ranks():
+    """`python bench.py --gpus 2 ...` typed WITHOUT a launcher must start its own ranks (it used to
+    SystemExit).  --dry-plan keeps it on CPU: plan per rank + gloo barrier / MAX / SUM / all-gather, rank 0 prints the
+    one JSON line, every other rank nothing, exit code 0."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--dry-plan"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["self_launched"] and out["dry_plan"]
+    assert [p["rank"] for p in out["per_rank"]] == [0, 1] and all(p["utterances"] == 4 * 32 for p in out["per_rank"])
+    assert out["stand_in_wall_max_s"] == 1.001                    # MAX over ranks picked rank 1's
+    assert out["planned_utterances"] == 256 and out["comm"]["results_ok"] and out["comm"]["world"] == 2
+    # strong scaling: the one fixed set splits over the ranks
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--dry-plan", "--scaling", "strong"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["planned_utterances"] == 128 and out["steps_per_gpu"] == 2
+
+
+def test_bench_failing_rank_gives_nonzero_exit():
+    """A rank that dies must fail the whole command (the launcher's exit code is bench.py's)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["SS_BENCH_DRY_FAIL_RANK"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--dry-plan"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
