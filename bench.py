@@ -353,6 +353,21 @@ def _pmc_file():
 PMC_FILE = _pmc_file()
 
 
+class _stdout_to_stderr:
+    """The bench line is the ONLY thing this command may print on stdout: communicator start-up banners of the libraries
+    underneath ("[Gloo] Rank 0 is connected ...") are sent to stderr (fd-level, so C++ prints are covered)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def _free_port():
     import socket
     with socket.socket() as s:
@@ -460,7 +475,9 @@ def dry_plan(args, rank, world):
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("gloo")
+        with _stdout_to_stderr():
+            dist.init_process_group("gloo")
+            dist.barrier()
     Ksteps, Bsz = max(1, args.steps), max(1, args.batch)
     mine, groups = workload.bench_plan(Ksteps, Bsz, rank, world, bucket=not args.no_length_bucketing, warm=3, strong=args.scaling == "strong")
     timed_ids = [i for g in groups for i in g]
@@ -541,10 +558,12 @@ def main():
         kw = {}
         if "MASTER_ADDR" not in os.environ:                           # SS_FORCE_DIST=1 typed without a launcher
             kw = {"init_method": f"tcp://127.0.0.1:{_free_port()}", "rank": 0, "world_size": 1}
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
-        else:
-            dist.init_process_group(backend, **kw)
+        with _stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank), **kw)
+            else:
+                dist.init_process_group(backend, **kw)
+            dist.barrier()          # the communicator is built lazily: pay for it (and its banners) here, not at the timed barrier
 
     cfg, vcfg = ModelConfig(), VocoderConfig()
     sd = synth.make_model_state_dict(0, cfg)
@@ -589,7 +608,7 @@ def main():
             lib.ss_prof_read(c, C.byref(ms), C.byref(fl), C.byref(n), C.byref(by))
             times.append(ms.value)
         dom = max(range(ncls), key=lambda c: times[c])
-        others = [c for c in range(ncls) if c != dom and times[c] > 0 and lib.ss_prof_class_name(c).decode().startswith("conv_")]
+        others = [c for c in range(ncls) if c != dom and times[c] > 0 and lib.ss_prof_class_name(c).decode().startswith(("conv_", "resblock_fused", "ffn_fused"))]
         dom_conv = max(others, key=lambda c: times[c]) if others else None
         lib.ss_prof_enable(0)
         lib.ss_prof_reset()
@@ -726,6 +745,8 @@ def main():
         try:   # PMC pass is a separate rocprofv3 run (tools/pmc_traffic.py -> profiles/); per-launch bytes with the guide's gfx950 correction
             pm = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE))) if PMC_FILE else {}
             kv = pm.get("classes", {}).get(name)
+            if kv and kv.get("join_ok", True) is False:
+                kv = None                                  # counter pass and census disagree on the launch count: no figure
             if kv:
                 traffic = round(kv["hbm_mbytes_per_launch_corrected"] * 1e6)          # HBM-side bytes per launch (counters)
                 from tools.pmc_traffic import csrc_file_sha16, csrc_sha16

@@ -81,6 +81,14 @@ int ss_resample(void* stream, const float* d_in, int64_t n_in, int up, int down,
 int ss_row_max_logprob(void* stream, const float* d_logits, int rows, int vocab, int mask0, int mask1, int mask2,
                        float* d_out);
 
+/* Normalised (log-)probabilities of dense logit rows [rows, vocab] -> d_out [rows, vocab]: log_softmax (as_probs = 0) or
+ * softmax (as_probs = 1) over the vocabulary, then ids mask0 / mask1 (< 0: none) set to -inf (0 for probabilities) -- what
+ * the reference forms with `model.get_normalized_probs` (researches/ctc_unity/models/streamspeech_model.py via
+ * fairseq_model.py:60-77) and `lprobs[:, :, pad] = lprobs[:, :, unk] = -inf` (agent/ctc_decoder.py:52-60) when a caller
+ * asks the CTC decoder for `lprobs`.  Off the timed path (the greedy searches never form log-probabilities). */
+int ss_log_softmax(void* stream, const float* d_logits, int rows, int vocab, int mask0, int mask1, int as_probs,
+                   float* d_out);
+
 /* ---- a2-a7: model.encoder(src_tokens, src_lengths) for one utterance (agent :433-435 ->
  * chunk_unity/models/s2t_conformer.py:111-163).  d_fbank [T,80] -> d_enc_out [T',256].
  * attn_chunk = encoder.chunk_size, conv_chunk = ChunkCausalConv1d.chunk_size as the agent sets
@@ -225,10 +233,11 @@ int ss_prof_totals(int cls, double* h_flops_total, double* h_bytes_total, int64_
 int ss_prof_num_classes(void);
 const char* ss_prof_class_name(int cls);
 
-/* Tuning hook for tools/conv_bench.py: force the LDS-tiled GEMM tile (bm = 0: heuristic;
- * bm = 1: route every eligible launch to the persistent stream-K kernel with a grid of ks
- * workgroups, ks = 0 -> 2 per CU; bm = 3: run the narrow-stage resblock pairs of the vocoder as two launches
- * instead of the fused kernel). */
+/* Tuning / A-B hook (tools/conv_bench.py, tests): bm = 0 heuristic; 1 route every eligible launch to the first-generation
+ * stream-K kernel with a grid of ks workgroups (ks = 0 -> 2 per CU; bn = 8: XCD tile groups); 2 no slab kernel; 3 the
+ * narrow-stage resblock pairs of the vocoder as two launches; 4 second-generation stream-K with a grid of ks; 5 its split-bf16
+ * form; 6 narrow-stage ResBlocks as separate launches; 32 / 64 / 128 a forced tile of the LDS-tiled kernel (bn, ks = KS*10+PD).
+ * Any other bm: SS_ERR_ARG. */
 int ss_debug_force_tile(int bm, int bn, int ks);
 /* Number of bounded-spin time-outs the stream-K kernel has recorded (any value but 0 is a bug). */
 int ss_debug_sk_errors(void);

@@ -34,6 +34,15 @@ class OracleEngine:
         toks, idx, raw, logits = O.ctc_head(self.sd, enc_out.cpu(), name, self.cfg)
         return toks, idx, torch.tensor(raw, dtype=torch.int32), (logits if want_logits else None)
 
+    def normalized_probs(self, logits, log_probs=True, mask0=-1, mask1=-1):
+        """fairseq_model.py:60-77 get_normalized_probs (+ agent/ctc_decoder.py:58-60 pad / unk masking)."""
+        x = logits.float()
+        out = torch.log_softmax(x, -1) if log_probs else torch.softmax(x, -1)
+        for m in (mask0, mask1):
+            if m >= 0:
+                out[..., m] = float("-inf") if log_probs else 0.0
+        return out
+
     def mt_begin(self, enc_out):
         self._enc, self._tokens = enc_out.cpu(), []
 

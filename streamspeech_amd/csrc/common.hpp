@@ -24,16 +24,21 @@
 
 #define SS_LAUNCH_CHECK() SS_HIP_CHECK(hipGetLastError())
 
-// Raise a kernel's dynamic-LDS limit exactly once per process, from whichever host thread launches it first (bench.py
-// drives the library from 8 threads).  Wrap a template-id in parentheses: SS_MAX_LDS_ONCE((&k<A, B>), bytes).
+// Raise a kernel's dynamic-LDS limit once PER DEVICE, from whichever host thread launches it first there (bench.py drives the
+// library from 8 threads; hipFuncSetAttribute applies to the current device's function object only, so a process that drives
+// several GPUs must repeat it on each -- ADVICE r3).  Wrap a template-id in parentheses: SS_MAX_LDS_ONCE((&k<A, B>), bytes).
 #define SS_MAX_LDS_ONCE(kernel, bytes)                                                                          \
   do {                                                                                                          \
-    static std::once_flag _once;                                                                                \
-    static hipError_t _once_err = hipSuccess;                                                                   \
-    std::call_once(_once, [&] {                                                                                 \
-      _once_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
-    });                                                                                                         \
-    SS_HIP_CHECK(_once_err);                                                                                    \
+    static std::mutex _mu;                                                                                      \
+    static unsigned long long _done[2] = {0ull, 0ull};   /* devices 0..127 */                                   \
+    int _dev = 0;                                                                                               \
+    SS_HIP_CHECK(hipGetDevice(&_dev));                                                                          \
+    if (_dev < 0 || _dev >= 128) return SS_ERR_ARG;                                                             \
+    std::lock_guard<std::mutex> _lk(_mu);                                                                       \
+    if (!((_done[_dev >> 6] >> (_dev & 63)) & 1ull)) {                                                          \
+      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+      _done[_dev >> 6] |= 1ull << (_dev & 63);                                                                  \
+    }                                                                                                           \
   } while (0)
 
 namespace ss {

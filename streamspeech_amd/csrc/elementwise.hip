@@ -277,12 +277,50 @@ __global__ __launch_bounds__(256) void row_max_logprob_kernel(const float* __res
   best = fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3]));
   __syncthreads();
   float sum = 0.f;
-  for (int n = t; n < N; n += 256) sum += __expf(r[n] - mx);
+  for (int n = t; n < N; n += 256) sum += expf(r[n] - mx);     // accurate forms: off the timed path, printed to 4+ decimals
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
   if (lane == 0) sa[wave] = sum;
   __syncthreads();
-  if (t == 0) out[blockIdx.x] = (best - mx) - __logf(sa[0] + sa[1] + sa[2] + sa[3]);
+  if (t == 0) out[blockIdx.x] = (best - mx) - logf(sa[0] + sa[1] + sa[2] + sa[3]);
+}
+
+// Full log-softmax / softmax rows (lprobs the agents hand back with --output-asr-translation style consumers, and
+// model.get_normalized_probs): out[r, n] = x - max - log(sum exp(x - max)), ids mask0 / mask1 set to -inf AFTER the
+// normalisation (agent/ctc_decoder.py:52-60).  Workgroup per row, accurate expf / logf: off the timed path.
+__global__ __launch_bounds__(256) void log_softmax_kernel(const float* __restrict__ logits, int ld, int N, int mask0, int mask1,
+                                                          int as_probs, float* __restrict__ out, int ldo) {
+  __shared__ float sa[4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const float* r = logits + (size_t)blockIdx.x * ld;
+  float* o = out + (size_t)blockIdx.x * ldo;
+  float mx = -INFINITY;
+  for (int n = t; n < N; n += 256) mx = fmaxf(mx, r[n]);
+  mx = wave_max(mx);
+  if (lane == 0) sa[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(sa[0], sa[1]), fmaxf(sa[2], sa[3]));
+  __syncthreads();
+  float sum = 0.f;
+  for (int n = t; n < N; n += 256) sum += expf(r[n] - mx);
+  sum = wave_sum(sum);
+  if (lane == 0) sa[wave] = sum;
+  __syncthreads();
+  const float tot = (sa[0] + sa[1]) + (sa[2] + sa[3]);
+  const float lse = logf(tot);
+  for (int n = t; n < N; n += 256) {
+    float v = as_probs ? expf(r[n] - mx) / tot : (r[n] - mx) - lse;
+    if (n == mask0 || n == mask1) v = as_probs ? 0.f : -INFINITY;
+    o[n] = v;
+  }
+}
+
+int launch_log_softmax(const float* logits, int ld, int M, int N, int mask0, int mask1, int as_probs, float* out, int ldo,
+                       hipStream_t stream) {
+  if (M <= 0) return SS_OK;
+  hipLaunchKernelGGL(log_softmax_kernel, dim3(M), dim3(256), 0, stream, logits, ld, N, mask0, mask1, as_probs, out, ldo);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
 }
 
 int launch_row_max_logprob(const float* logits, int ld, int M, int N, int mask0, int mask1, int mask2, float* out,

@@ -38,6 +38,8 @@ int launch_masked_argmax(const float* logits, int ld, int M, int N, int mask0, i
                          int force_id = -1);  // row_max_len: force `force_id` on rows with step >= row_max_len[row]
 
 // out[m] = max_{n not in masks} log_softmax(logits[m,:])[n]   (researches/ctc_unity/ctc_generator.py:55-63)
+int launch_log_softmax(const float* logits, int ld, int M, int N, int mask0, int mask1, int as_probs, float* out, int ldo,
+                       hipStream_t stream);
 int launch_row_max_logprob(const float* logits, int ld, int M, int N, int mask0, int mask1, int mask2, float* out,
                            hipStream_t stream);
 

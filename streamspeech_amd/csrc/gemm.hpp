@@ -43,6 +43,7 @@ struct GemmArgs {
   int nseg = 0;
   int max_seg_out = 0;        // max out_len over segments (grid sizing)
   double algo_flops = 0.0;    // algorithmic FLOPs of this launch for the profiler (0 -> 2*M*N*taps*Cin)
+  double algo_bytes = 0.0;    // algorithmic bytes of this launch for the profiler (0 -> weights + in + out + residuals once)
   // fused LayerNorm prologue on the A rows (linear layers only: taps == 1, normalised over Cin):
   // A' = (A - mean) * rstd * ln_g + ln_b, eps 1e-5 -- saves the separate LayerNorm launch.
   const float* ln_g = nullptr;
@@ -59,7 +60,7 @@ struct GemmArgs {
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 20;
+constexpr int kNumTileCfg = 23;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises

@@ -2,6 +2,7 @@
 // Host code only queues kernels on the caller's stream; the only device->host syncs are the
 // frame count in the vocoder and whatever the caller does with the returned ids.
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -316,6 +317,12 @@ extern "C" int ss_row_max_logprob(void* stream, const float* d_logits, int rows,
   return launch_row_max_logprob(d_logits, vocab, rows, vocab, mask0, mask1, mask2, d_out, (hipStream_t)stream);
 }
 
+extern "C" int ss_log_softmax(void* stream, const float* d_logits, int rows, int vocab, int mask0, int mask1, int as_probs,
+                              float* d_out) {
+  if (!d_logits || !d_out || rows < 0 || vocab <= 0) return SS_ERR_ARG;
+  return launch_log_softmax(d_logits, vocab, rows, vocab, mask0, mask1, as_probs, d_out, vocab, (hipStream_t)stream);
+}
+
 extern "C" int ss_fbank_num_frames(int n) { return n < 400 ? 0 : 1 + (n - 400) / 160; }
 
 extern "C" int ss_fbank_cmvn(ss_model* m, void* stream, const float* d_pcm, int n_samples, float pcm_scale,
@@ -627,8 +634,28 @@ extern "C" int ss_mt_begin(ss_model* m, void* stream, const float* d_enc_out, in
   return SS_OK;
 }
 
+// Bounded-wait time-outs of persistent MT decode steps, process-wide (reported by ss_debug_sk_errors next to the stream-K
+// counters).  The step has its OWN device error word per context (it used to alias the stream-K time-out counter,
+// so one MT time-out made every later stream-K launch of that workspace bail out); the host collects and clears it whenever
+// the persistent form is switched (which both fall-back paths do).
+static std::atomic<int> g_mt_timeouts{0};
+static unsigned* mt_err_word(ss_model* m) {
+  return reinterpret_cast<unsigned*>(static_cast<char*>(m->mt_gran.p) + mt_step_granule_bytes() + 16);
+}
+static int mt_collect_errors(ss_model* m) {
+  if (!m->mt_gran.p) return SS_OK;
+  unsigned e = 0;
+  SS_HIP_CHECK(hipMemcpy(&e, mt_err_word(m), sizeof(e), hipMemcpyDeviceToHost));     // synchronises with the context's stream work
+  if (e) {
+    g_mt_timeouts.fetch_add((int)e, std::memory_order_relaxed);
+    SS_HIP_CHECK(hipMemset(mt_err_word(m), 0, sizeof(unsigned)));
+  }
+  return SS_OK;
+}
+
 extern "C" int ss_mt_set_persistent(ss_model* m, int workgroups) {
   if (!m || !(workgroups == 0 || workgroups == 64 || workgroups == 128 || workgroups == 256)) return SS_ERR_ARG;
+  if (m->mt_persistent > 0) RET(mt_collect_errors(m));
   m->mt_persistent = workgroups;
   return SS_OK;
 }
@@ -670,8 +697,6 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
       SS_HIP_CHECK(hipMemsetAsync(m->mt_gran.p, 0, mt_step_granule_bytes() + 64, s));
       SS_HIP_CHECK(hipStreamSynchronize(s));
     }
-    SkWorkspace* ws = nullptr;
-    RET(sk_workspace_acquire(s, &ws));                    // its time-out counter is the one ss_debug_sk_errors reports
     MtStepArgs a;
     for (int l = 0; l < MT_L; ++l) {
       const DecLayer& L = m->mt[l];
@@ -685,7 +710,7 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
     }
     a.lnf_g = m->mt_ln.g; a.lnf_b = m->mt_ln.b; a.emb = m->mt_emb; a.pos_table = m->mt_pos;
     a.tok = d_tokens; a.feats = d_feats ? d_feats : feats; a.next = d_next;
-    a.gran = reinterpret_cast<mt_u64*>(m->mt_gran.p); a.err = ws->sync2 + 8;
+    a.gran = reinterpret_cast<mt_u64*>(m->mt_gran.p); a.err = mt_err_word(m);
     if (m->mt_inject_timeout) {                            // test hook: this one launch sees a time-out that already happened
       m->mt_inject_timeout = 0;
       a.err = reinterpret_cast<unsigned*>(static_cast<char*>(m->mt_gran.p) + mt_step_granule_bytes());
@@ -761,6 +786,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
         if (host[i] < 0 && m->mt_persistent > 0) {          // mt_step.hip: a bounded wait of the persistent step timed out
           fprintf(stderr, "streamspeech_hip: persistent MT decode step timed out (its %d workgroups were not all resident); "
                           "this context falls back to one launch per op\n", m->mt_persistent);
+          RET(mt_collect_errors(m));
           m->mt_persistent = 0;
           return ss_mt_greedy(m, stream, d_enc_out, Tp, h_prefix, n_prefix, max_len, min_len, h_out_tokens, h_n_out, d_feats,
                               h_n_feats);
@@ -908,7 +934,7 @@ extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
 // HBM-bound late stages (C < 64) the extra write would cost more than the VALU, so the activation
 // stays on the consumer's A-fragment path there.
 // -------------------------------------------------------------------------------------------------
-static int g_no_resblock_fusion = getenv("SS_NO_RESBLOCK_FUSION") ? atoi(getenv("SS_NO_RESBLOCK_FUSION")) : 0;   // test hook / env knob (ss_debug_force_tile(4, ...)): narrow-stage ResBlocks as separate pair / conv launches
+static int g_no_resblock_fusion = getenv("SS_NO_RESBLOCK_FUSION") ? atoi(getenv("SS_NO_RESBLOCK_FUSION")) : 0;   // test hook / env knob (ss_debug_force_tile(6, ...)): narrow-stage ResBlocks as separate pair / conv launches
 static int g_no_pair_fusion = getenv("SS_NO_PAIR_FUSION") ? atoi(getenv("SS_NO_PAIR_FUSION")) : 0;   // test hook / env knob (ss_debug_force_tile(3, ...)): run the narrow-stage pairs as two launches
 struct GenBufs { float *bx, *bt, *br, *bs, *bxa, *bra, *bsa, *br2; };
 
@@ -1563,9 +1589,14 @@ extern "C" int ss_prof_num_classes(void) { return kNumTileCfg; }
 extern "C" const char* ss_prof_class_name(int cls) { return prof_cfg_name(cls); }
 
 extern "C" int ss_debug_force_tile(int bm, int bn, int ks) {
-  if (bm == 4 || bm == 0) g_no_resblock_fusion = (bm == 4);        // bm = 4: narrow-stage ResBlocks as separate launches (A/B of resblock.hip)
+  // 0 heuristic | 1 first-generation stream-K (bn = 8: XCD groups, ks = grid) | 2 no slab kernel | 3 narrow-stage pairs as two
+  // launches | 4 second-generation stream-K (ks = grid) | 5 its split-bf16 form | 6 narrow-stage ResBlocks as separate launches |
+  // 32 / 64 / 128 a forced tile of the LDS-tiled kernel (tools/conv_bench.py); anything else is a caller's mistake.
+  // (Round 3 had booked BOTH the conv_sk2 hook and the ResBlock A/B on 4, so (4, 0, G) never reached the stream-K launcher.)
+  if (!(bm >= 0 && bm <= 6) && bm != 32 && bm != 64 && bm != 128) return SS_ERR_ARG;
+  if (bm == 6 || bm == 0) g_no_resblock_fusion = (bm == 6);        // bm = 6: narrow-stage ResBlocks as separate launches (A/B of resblock.hip)
   if (bm == 3 || bm == 0) g_no_pair_fusion = (bm == 3);            // bm = 3: narrow-stage resblock pairs as two launches (A/B of the fused kernel)
-  debug_force_tile((bm == 3 || bm == 4) ? 0 : bm, bn, ks);
+  debug_force_tile((bm == 3 || bm == 6) ? 0 : bm, bn, ks);
   return SS_OK;
 }
-extern "C" int ss_debug_sk_errors(void) { return conv_sk_error_count() + conv_sk2_error_count(); }
+extern "C" int ss_debug_sk_errors(void) { return conv_sk_error_count() + conv_sk2_error_count() + g_mt_timeouts.load(std::memory_order_relaxed); }

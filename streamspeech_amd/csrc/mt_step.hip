@@ -19,10 +19,10 @@
 //               H  x = x2 + W2 h                                                              (512)
 //   then        I  feats = LN_f(x) (workgroup 0 writes the row), logits = E feats, masked arg-max per workgroup   (2 G)
 //               J  workgroup 0 reduces the candidates (first maximum wins, as torch.max) and writes the next token.
-// Every spin is bounded: a time-out bumps the context's bounded-wait counter (ss_debug_sk_errors) and the launch runs to its
+// Every spin is bounded: a time-out bumps the context's own error word (collected into ss_debug_sk_errors by the host) and the launch runs to its
 // end on whatever it has -- results are then wrong and the counter says so; nothing hangs.  The granule region is zeroed once
 // at allocation and the epoch grows with every launch of the context, so no per-launch memset is needed.
-// Opt-in (SS_MT_PERSISTENT=G, ss_debug_force_tile(6, G, 0)): all G workgroups of a launch must become resident, which is certain
+// Opt-in per context (ss_mt_set_persistent(m, G), or SS_MT_PERSISTENT=G in the environment): all G workgroups of a launch must become resident, which is certain
 // for one decoding stream and not when many contexts decode at once next to full-chip kernels (each would hold CUs while
 // waiting for its missing workgroups); the default path stays the launch-per-op one.
 #include "mt_step.hpp"

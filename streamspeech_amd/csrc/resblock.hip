@@ -376,18 +376,19 @@ bool resblock_fused_eligible(int C, int taps, const int* dil, int ldx, int ldy, 
          ((size_t)(M + 1024) * C) * 4 < 0x7ff00000ull;
 }
 
-static int rb_cus(int& cus) {             // CU count of the current device, read once (thread-safe)
-  static std::once_flag once;
-  static int n = 0;
-  static hipError_t err = hipSuccess;
-  std::call_once(once, [&] {
-    int dev = 0;
-    err = hipGetDevice(&dev);
-    if (err == hipSuccess) err = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n <= 0) n = 256;
-  });
-  SS_HIP_CHECK(err);
-  cus = n;
+static int rb_cus(int& cus) {             // CU count of the CURRENT device, read once per device (thread-safe)
+  static std::mutex mu;
+  static int n[128] = {0};
+  int dev = 0;
+  SS_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 128) return SS_ERR_ARG;
+  std::lock_guard<std::mutex> lk(mu);
+  if (n[dev] == 0) {
+    int v = 0;
+    SS_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    n[dev] = v > 0 ? v : 256;
+  }
+  cus = n[dev];
   return SS_OK;
 }
 
@@ -403,12 +404,14 @@ static int launch_rb_t(const ResblockArgs& a, hipStream_t stream) {
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   const long long max_blocks = (long long)cdiv(a.M, BM) + nseg;            // upper bound (per-utterance round-up)
   const int grid = (int)std::min<long long>(cus, std::max<long long>(1, max_blocks));   // one workgroup per CU (LDS)
-  // profiler class of the narrow-stage kernels (C = 32 -> 16, C = 16 -> 17); algorithmic work of the six convs
+  // profiler classes resblock_fused<32> / <16> (20 / 21); algorithmic work of the six convs: 12 M C^2 k FLOP; bytes: x read
+  // once, y written once, the MRF accumulator read once when present, the six weight matrices + biases once
   GemmArgs ga;
   ga.M = a.M; ga.N = C; ga.Cin = C; ga.taps = TAPS; ga.in_len = a.M; ga.R2 = a.R2;
   ga.algo_flops = 12.0 * (double)a.M * C * C * TAPS;
+  ga.algo_bytes = 4.0 * ((double)a.M * C * (2 + (a.R2 ? 1 : 0)) + 6.0 * C * (C * TAPS + 1));
   ProfRec rec{}; bool prof = false;
-  int rc = prof_begin(ga, stream, C == 32 ? 16 : 17, rec, prof);
+  int rc = prof_begin(ga, stream, C == 32 ? 20 : 21, rec, prof);
   if (rc != SS_OK) return rc;
   hipLaunchKernelGGL((resblock_fused_kernel<C, TAPS>), dim3(grid), dim3(RB_NW * 64), G::LDS_BYTES, stream, a);
   SS_LAUNCH_CHECK();

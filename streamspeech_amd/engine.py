@@ -304,6 +304,16 @@ class HipModel(BatchMixin):
         return host[U:U + k].tolist(), host[:U], logits
 
 
+    def normalized_probs(self, logits: torch.Tensor, log_probs: bool = True, mask0: int = -1, mask1: int = -1) -> torch.Tensor:
+        """model.get_normalized_probs on the device (ss_log_softmax): (log-)softmax over the last axis of dense logits, then ids
+        mask0 / mask1 set to -inf (0).  Glue for callers that ask for `lprobs`; the greedy searches never need it."""
+        x = logits.to(self.device, torch.float32).contiguous()
+        V = x.shape[-1]
+        rows = x.numel() // V
+        out = torch.empty_like(x)
+        L.check(self.lib.ss_log_softmax(_stream(), _ptr(x), rows, V, int(mask0), int(mask1), int(not log_probs), _ptr(out)), "ss_log_softmax")
+        return out
+
     def unit_scores(self, mt_feats: torch.Tensor, t2u_causal: bool = False):
         """Per-position maximum log-probability (natural log, pad / unk / eos masked after the softmax) of the unit
         decoder over the 25 n positions -- the offline search's positional scores (researches/ctc_unity/ctc_generator.py:

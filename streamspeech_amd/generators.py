@@ -28,10 +28,8 @@ class CTCDecoder:
             raw = torch.tensor(merged, dtype=torch.int32)
         lprobs = None
         if logits is not None:
-            lprobs = torch.log_softmax(logits, -1)
-            lprobs[:, self.pad] = float("-inf")
-            lprobs[:, self.unk] = float("-inf")
-            lprobs = lprobs.unsqueeze(0)
+            # model.get_normalized_probs + "never select pad, unk" (agent/ctc_decoder.py:52-60), on the engine (ss_log_softmax)
+            lprobs = self.engine.normalized_probs(logits, True, self.pad, self.unk).unsqueeze(0)
         return [[{"tokens": torch.tensor(toks, dtype=torch.long), "org_tokens": raw, "lprobs": lprobs,
                   "index": index, "attn": None, "alignment": None}]]
 

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ss_encoder_out_len": (_i, [_i]),
     "ss_resample": (_i, [_vp, _vp, _i64, _i, _i, _vp, _i, _vp, _i64]),
     "ss_row_max_logprob": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "ss_log_softmax": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ss_encoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ss_encoder_stream_reset": (_i, [_vp]),
     "ss_encoder_stream_set_tail": (_i, [_vp, _i]),

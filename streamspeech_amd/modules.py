@@ -193,8 +193,7 @@ class StreamSpeechModel:
         return self.cfg.max_target_positions
 
     def get_normalized_probs(self, net_output, log_probs, sample=None):
-        logits = net_output[0]
-        return torch.log_softmax(logits.float(), -1) if log_probs else torch.softmax(logits.float(), -1)
+        return self.hip.normalized_probs(net_output[0], log_probs)       # ss_log_softmax: no model math in torch
 
 
 @register_model_architecture("streamspeech", "streamspeech")

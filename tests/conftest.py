@@ -3,6 +3,13 @@ import sys
 
 import pytest
 
+# The CPU suite runs tiny torch ops (oracle agents, reference modules): torch's default of one thread per core
+# oversubscribes the box (51 min / 335 CPU-minutes on 8 cores).  Cap BEFORE torch spins up its pools;
+# SS_TEST_THREADS overrides.
+_NT = os.environ.get("SS_TEST_THREADS", "4")
+for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+    os.environ.setdefault(_k, _NT)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -10,6 +17,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun / at round end)")
+    config.addinivalue_line("markers", "slow: long CPU cases (live reference-agent re-runs); deselect with -m 'not gpu and not slow'")
+    try:
+        import torch
+        torch.set_num_threads(int(_NT))
+    except Exception:  # noqa: BLE001
+        pass
+    if not config.option.durations:
+        config.option.durations = 10          # always print the ten slowest tests
 
 
 @pytest.fixture(scope="session")

@@ -292,7 +292,7 @@ def test_fused_narrow_resblocks_equal_the_multi_launch_form_bitwise(hip_vocoder)
                                         forced_dur=torch.tensor(durs[i], dtype=torch.int32, device="cuda:0"))[0].clone()
     fused = [w.clone() for w in hip_vocoder.batch_forward(codes, True, forced_dur=durs)[0]]
     f_single = [one(i) for i in (1, 4)]
-    lib.ss_debug_force_tile(4, 0, 0)           # narrow-stage ResBlocks as pair / two-launch kernels
+    lib.ss_debug_force_tile(6, 0, 0)           # narrow-stage ResBlocks as pair / two-launch kernels
     try:
         plain = [w.clone() for w in hip_vocoder.batch_forward(codes, True, forced_dur=durs)[0]]
         p_single = [one(i) for i in (1, 4)]

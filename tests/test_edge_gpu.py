@@ -153,3 +153,35 @@ def test_empty_members_of_a_batch_are_refused(hip_model, hip_vocoder):
         hip_model.batch_t2u_units(feats, [3, 0])
     with pytest.raises(L.StreamSpeechHipError):
         hip_vocoder.batch_forward([[1, 2, 3], []], forced_dur=[[1, 1, 1], []])
+
+
+@pytest.mark.gpu
+def test_log_softmax_kernel_and_lprobs_glue(hip_model):
+    """no model math in torch on a product path -- `lprobs` / get_normalized_probs go through ss_log_softmax.
+    Checked against torch's float64 log_softmax; pad / unk are -inf AFTER the normalisation (agent/ctc_decoder.py:52-60)."""
+    import torch
+    from streamspeech_amd.generators import CTCDecoder
+    from streamspeech_amd.modules import StreamSpeechModel
+    from tests import ref_fixtures as RF
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(37, 6000, generator=g) * 4).cuda()
+    ref = torch.log_softmax(x.double().cpu(), -1)
+    got = hip_model.normalized_probs(x, True, 1, 3).cpu()
+    assert torch.isinf(got[:, 1]).all() and torch.isinf(got[:, 3]).all() and (got[:, 1] < 0).all()
+    keep = [i for i in range(6000) if i not in (1, 3)]
+    assert (got[:, keep].double() - ref[:, keep]).abs().max() < 1e-5          # f32 on values down to -30: 1 ulp = 2e-6
+    p = hip_model.normalized_probs(x, False).cpu()
+    assert (p.double() - ref.exp()).abs().max() < 1e-6 and (p.sum(-1) - 1).abs().max() < 1e-5
+    # the agent-facing glue: CTCDecoder.generate(..., want_lprobs=True) and model.get_normalized_probs
+    cfg = hip_model.cfg
+    enc = hip_model.encoder_forward(torch.randn(83, 80, generator=g).cuda())
+    d = RF.dictionaries(cfg)["source_unigram"]
+    hyp = CTCDecoder(d, hip_model, 0).generate({"encoder_out": [enc[:, None]]}, aux_task_name="source_unigram", want_lprobs=True)[0][0]
+    _, _, _, logits = hip_model.ctc_greedy(0, enc, want_logits=True)
+    want = torch.log_softmax(logits.double().cpu(), -1)
+    want[:, [d.pad(), d.unk()]] = float("-inf")
+    lp = hyp["lprobs"][0].cpu().double()
+    fin = torch.isfinite(want)
+    assert torch.equal(torch.isfinite(lp), fin) and (lp[fin] - want[fin]).abs().max() < 1e-5
+    m = StreamSpeechModel.from_engine(hip_model)
+    assert (m.get_normalized_probs([logits], True).cpu().double() - torch.log_softmax(logits.double().cpu(), -1)).abs().max() < 1e-5

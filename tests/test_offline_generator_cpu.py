@@ -19,9 +19,11 @@ def oracle_model(synth_weights, golden_dir):
     return OracleEngine(sd, cfg, cmvn_mean=g["mean"], cmvn_std=g["std"])
 
 
+# score_rel 5e-6: the H-/D- score is a float64 sum over 25 n positions of float32 log-probabilities whose GEMM reduction order
+# depends on torch's CPU thread count (conftest caps it at 4; the fixture was written with 8): observed 2e-6 relative.
 def test_offline_driver_lines_equal_reference_generator_output(oracle_model, synth_weights, tmp_path):
     cfg, vcfg, sd, vsd = synth_weights
-    r = OF.run_and_compare(oracle_model, OracleVocoder(vsd, vcfg), cfg, "short_search", tmp_path, score_rel=1e-6, pos_abs=1.5e-4)
+    r = OF.run_and_compare(oracle_model, OracleVocoder(vsd, vcfg), cfg, "short_search", tmp_path, score_rel=5e-6, pos_abs=1.5e-4)
     # the files pred.offline-s2st.sh cuts out of the two generate files
     units = open(tmp_path / "generate-test.unit").read().splitlines()
     assert units == [" ".join(str(u) for u in r["hyps"][i]["units"]) for i in sorted(r["ids"])]
@@ -32,7 +34,7 @@ def test_offline_driver_default_search_length(oracle_model, synth_weights, tmp_p
     """max_len_a_mt / max_len_b_mt = 0 / 200, the task's defaults: the random model never emits </s>, so the first pass runs
     to 200 tokens in the reference (with incremental states) and here."""
     cfg, vcfg, sd, vsd = synth_weights
-    OF.run_and_compare(oracle_model, None, cfg, "default_search", tmp_path, score_rel=1e-6, pos_abs=1.5e-4)
+    OF.run_and_compare(oracle_model, None, cfg, "default_search", tmp_path, score_rel=5e-6, pos_abs=1.5e-4)
 
 
 def test_fixture_is_what_the_reference_generator_prints_now():

@@ -125,3 +125,16 @@ def test_product_path_fails_loudly_without_gpu():
     from streamspeech_amd.engine import HipModel
     with pytest.raises(L.StreamSpeechHipError):
         HipModel({}, ModelConfig())
+
+
+def test_debug_force_tile_rejects_unknown_codes():
+    """an unrecognised `bm` used to be stored as a forced tile and silently disabled the small-M / GEMV kernels."""
+    from streamspeech_amd import lib as L
+    lib = L.load()
+    try:
+        for bad in (7, 6000, -1, 16):
+            assert lib.ss_debug_force_tile(bad, 0, 0) == 2          # SS_ERR_ARG
+        for ok in (1, 2, 3, 4, 5, 6, 32, 64, 128, 0):
+            assert lib.ss_debug_force_tile(ok, 0, 0) == 0
+    finally:
+        lib.ss_debug_force_tile(0, 0, 0)

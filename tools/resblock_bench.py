@@ -1,5 +1,5 @@
 """A/B of the narrow-stage ResBlock kernels on the batch-32 vocoder workload of bench.py: fused per-ResBlock launches
-(resblock.hip, default) vs the pair / two-launch form (ss_debug_force_tile(4)).  Prints whole-vocoder time per batch, the
+(resblock.hip, default) vs the pair / two-launch form (ss_debug_force_tile(6)).  Prints whole-vocoder time per batch, the
 narrow-stage kernel classes' event time / launches / TFLOP/s, and checks the waveforms are bit-identical.
     python tools/resblock_bench.py [n_utterances]"""
 import ctypes as C
@@ -25,7 +25,7 @@ def main():
     frames = sum(sum(d) for d in durs)
     print(f"{n} utterances, {sum(u.seconds for u in utts):.1f} s of audio, {frames} frames")
     outs = {}
-    for name, mode in (("fused resblocks", 0), ("pair / two-launch", 4), ("fused resblocks (again)", 0)):
+    for name, mode in (("fused resblocks", 0), ("pair / two-launch", 6), ("fused resblocks (again)", 0)):
         lib.ss_debug_force_tile(mode, 0, 0)
         for _ in range(2):
             w = voc.batch_forward(codes, True, forced_dur=durs)[0]
