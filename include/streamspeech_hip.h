@@ -233,6 +233,18 @@ int ss_prof_totals(int cls, double* h_flops_total, double* h_bytes_total, int64_
 int ss_prof_num_classes(void);
 const char* ss_prof_class_name(int cls);
 
+/* Unit-test entry of the fused Conformer feed-forward kernel (csrc/ffn.hip; what ss_batch_encoder_forward launches twice per
+ * layer on packed batches): dY = dX + alpha * (W2 . SiLU(W1 . LayerNorm(dX; ln_g, ln_b) + b1) + b2), then LayerNorm(ln2_g, ln2_b)
+ * over the result rows when ln2_g != NULL -- FeedForwardModule.forward + the 0.5-residual wiring and final_layer_norm of
+ * ChunkConformerEncoderLayer.forward (researches/chunk_unity/modules/conformer_layer.py:152-164, 254-312).  D must be 256,
+ * F % 64 == 0; W1 [F, D], W2 [D, F] row-major; dY may alias dX. */
+int ss_op_ffn_fused(void* stream, const float* dX, int ldx, float* dY, int ldy, const float* ln_g, const float* ln_b,
+                    const float* dW1, const float* db1, const float* dW2, const float* db2, float alpha,
+                    const float* ln2_g, const float* ln2_b, int M, int D, int F);
+/* A/B + test hook of the same kernel: grid > 0 fixes its workgroup count (0: heuristic); row_tiles_per_wave 3 | 4 picks 48- or
+ * 64-row tiles (0: keep); enable 0 / 1 switches its use by ss_batch_encoder_forward off / on (-1: keep). */
+int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable);
+
 /* Tuning / A-B hook (tools/conv_bench.py, tests): bm = 0 heuristic; 1 route every eligible launch to the first-generation
  * stream-K kernel with a grid of ks workgroups (ks = 0 -> 2 per CU; bn = 8: XCD tile groups); 2 no slab kernel; 3 the
  * narrow-stage resblock pairs of the vocoder as two launches; 4 second-generation stream-K with a grid of ks; 5 its split-bf16

@@ -809,6 +809,7 @@ void sk_workspace_free(SkWorkspace* w) {
   if (w->ws) (void)hipFree(w->ws);
   if (w->sync1) (void)hipFree(w->sync1);
   if (w->sync2) (void)hipFree(w->sync2);
+  if (w->sync3) (void)hipFree(w->sync3);
   if (w->dbg) (void)hipFree(w->dbg);
   delete w;
 }
@@ -837,6 +838,8 @@ int sk_workspace_acquire(hipStream_t stream, SkWorkspace** out) {
     SS_HIP_CHECK(hipMalloc(&w->sync2, SKW_SYNC_BYTES));
     SS_HIP_CHECK(hipMemsetAsync(w->sync1, 0, SKW_SYNC_BYTES, stream));
     SS_HIP_CHECK(hipMemsetAsync(w->sync2, 0, SKW_SYNC_BYTES, stream));
+    SS_HIP_CHECK(hipMalloc(&w->sync3, 4096 * sizeof(unsigned)));
+    SS_HIP_CHECK(hipMemsetAsync(w->sync3, 0, 4096 * sizeof(unsigned), stream));
     SS_HIP_CHECK(hipStreamSynchronize(stream));   // once per context: a later call may arrive on another stream and must see the zeros
   } else if (w->dev != dev) {
     return SS_ERR_ARG;                 // a context belongs to the device it first ran on

@@ -82,6 +82,7 @@ struct SkWorkspace {
   float* ws = nullptr;                 // [cus] parked partial tiles of 128 KB (conv_sk2: 256 x 128, conv_sk: 2 x 128 x 128 per CU)
   unsigned* sync1 = nullptr;           // conv_sk: ticket counters, time-out counter, flags
   unsigned* sync2 = nullptr;           // conv_sk2
+  unsigned* sync3 = nullptr;           // ffn_fused: per-tile arrival counters (zero between launches)
   unsigned base1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, epoch1 = 0;
   unsigned base2 = 0, epoch2 = 0;
   unsigned long long* dbg = nullptr;   // diagnostic builds only
@@ -129,6 +130,16 @@ bool resblock_fused_eligible(int C, int taps, const int* dil, int ldx, int ldy, 
 int launch_resblock_fused(const float* X, int ldx, const float* const* W1, const float* const* B1, const float* const* W2,
                           const float* const* B2, const int* dil, float* Y, int ldy, const float* R2, int ldr2, float div, int C,
                           int taps, int M, float slope, const int* segs, int nseg, hipStream_t stream);
+
+// Fused Conformer feed-forward module (ffn.hip): Y = X + alpha * (W2 . SiLU(W1 . LayerNorm(X) + b1) + b2), optionally followed by
+// LayerNorm(ln2) over the result rows; one persistent launch, hidden activations stay in registers.  D = 256, F % 64 == 0.
+// Y may alias X (in place).
+bool ffn_fused_eligible(int D, int F, int act, int M, int ldx, int ldy);
+int launch_ffn_fused(const float* X, int ldx, float* Y, int ldy, const float* ln_g, const float* ln_b, const float* W1,
+                     const float* b1, const float* W2, const float* b2, float alpha, const float* ln2_g, const float* ln2_b,
+                     int M, int D, int F, hipStream_t stream);
+void ffn_fused_debug_grid(int g);    // tests / tuning: fixed workgroup count (0 = heuristic)
+void ffn_fused_debug_rows(int wm);   // tests / tuning: 16-row MFMA tiles per wave (3: 48-row tiles, 4: 64-row tiles)
 
 // True when launch_conv_gemm would route `a` to the decode GEMV (M <= 4 rows; the only form that honours ln_out).
 bool gemv_eligible(const GemmArgs& a);

@@ -106,6 +106,9 @@ int ln_linear(hipStream_t s, const float* x, int M, const LN& ln, const Lin& l, 
 
 }  // namespace
 
+static int g_ffn_fusion = getenv("SS_NO_FFN_FUSION") && atoi(getenv("SS_NO_FFN_FUSION")) ? 0 : 1;   // A/B knob: encoder FFNs of packed batches as one launch each (ffn.hip)
+static int g_ffn_min_rows = getenv("SS_FFN_MIN_ROWS") ? atoi(getenv("SS_FFN_MIN_ROWS")) : 768;       // below: the two-launch form (too few row tiles to fill the chip)
+
 // =================================================================================================
 // model
 // =================================================================================================
@@ -1209,8 +1212,16 @@ extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const 
   RET(linear(s, g, d, M2, m->enc_linear, d, d, x, d));
   for (int l = 0; l < c.enc_layers; ++l) {
     const EncLayer& e = m->enc[l];
-    RET(ln_linear(s, x, M2, e.ffn1_ln, e.ffn1_w1, f, d, ff, f, h, ACT_SILU));
-    RET(linear(s, ff, f, M2, e.ffn1_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
+    // macaron FFN: x += 0.5 * W2 SiLU(W1 LN(x)); packed batches: ONE launch (ffn.hip), the [rows, 2048] hidden tile stays on chip
+    const bool fuse_ffn = g_ffn_fusion && M2 >= g_ffn_min_rows && ffn_fused_eligible(d, f, ACT_SILU, M2, d, d) && e.ffn1_w1.b &&
+                          e.ffn1_w2.b && e.ffn2_w1.b && e.ffn2_w2.b;
+    if (fuse_ffn) {
+      RET(launch_ffn_fused(x, d, x, d, e.ffn1_ln.g, e.ffn1_ln.b, e.ffn1_w1.w, e.ffn1_w1.b, e.ffn1_w2.w, e.ffn1_w2.b, 0.5f, nullptr,
+                           nullptr, M2, d, f, s));
+    } else {
+      RET(ln_linear(s, x, M2, e.ffn1_ln, e.ffn1_w1, f, d, ff, f, h, ACT_SILU));
+      RET(linear(s, ff, f, M2, e.ffn1_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
+    }
     RET(ln_linear(s, x, M2, e.attn_ln, e.qkv, 3 * d, d, qkv, 3 * d, h));
     AttnArgs at;
     at.Q = qkv; at.K = qkv + d; at.V = qkv + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
@@ -1223,9 +1234,14 @@ extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const 
     RET(launch_dwconv_bn_silu(g, d, g2, d, e.dw_wt, c.dw_kernel, e.bn_mean, e.bn_var, e.bn_g, e.bn_b, 1e-5f,
                               o2.mx, d, cchunk, s, dr, B));
     RET(linear(s, g2, d, M2, e.pw2, d, d, x, d, ACT_NONE, 1.f, x, d));
-    RET(ln_linear(s, x, M2, e.ffn2_ln, e.ffn2_w1, f, d, ff, f, h, ACT_SILU));
-    RET(linear(s, ff, f, M2, e.ffn2_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
-    RET(layernorm(s, x, x, e.final_ln, M2, d));
+    if (fuse_ffn) {                          // second FFN + the layer's final LayerNorm in the same launch
+      RET(launch_ffn_fused(x, d, x, d, e.ffn2_ln.g, e.ffn2_ln.b, e.ffn2_w1.w, e.ffn2_w1.b, e.ffn2_w2.w, e.ffn2_w2.b, 0.5f,
+                           e.final_ln.g, e.final_ln.b, M2, d, f, s));
+    } else {
+      RET(ln_linear(s, x, M2, e.ffn2_ln, e.ffn2_w1, f, d, ff, f, h, ACT_SILU));
+      RET(linear(s, ff, f, M2, e.ffn2_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
+      RET(layernorm(s, x, x, e.final_ln, M2, d));
+    }
   }
   return SS_OK;
 }
@@ -1538,6 +1554,19 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
   a.chunk = chunk; a.in_act = in_act; a.in_slope = in_slope; a.act = act; a.alpha = alpha; a.div = div; a.glu = glu;
   a.same_rows = (stride == 1 && M == in_len) ? 1 : 0;
   return launch_conv_gemm(a, (hipStream_t)stream);
+}
+
+extern "C" int ss_op_ffn_fused(void* stream, const float* dX, int ldx, float* dY, int ldy, const float* ln_g, const float* ln_b,
+                               const float* dW1, const float* db1, const float* dW2, const float* db2, float alpha,
+                               const float* ln2_g, const float* ln2_b, int M, int D, int F) {
+  return launch_ffn_fused(dX, ldx, dY, ldy, ln_g, ln_b, dW1, db1, dW2, db2, alpha, ln2_g, ln2_b, M, D, F, (hipStream_t)stream);
+}
+extern "C" int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable) {
+  if (grid < 0 || !(row_tiles_per_wave == 0 || row_tiles_per_wave == 3 || row_tiles_per_wave == 4)) return SS_ERR_ARG;
+  ffn_fused_debug_grid(grid);
+  if (row_tiles_per_wave) ffn_fused_debug_rows(row_tiles_per_wave);
+  if (enable >= 0) g_ffn_fusion = enable ? 1 : 0;
+  return SS_OK;
 }
 
 extern "C" int ss_op_layernorm(void* stream, const float* dx, int ldx, float* dy, int ldy, const float* dg,

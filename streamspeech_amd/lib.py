@@ -76,6 +76,8 @@ SIGNATURES = {
     "ss_prof_num_classes": (_i, []),
     "ss_prof_class_name": (C.c_char_p, [_i]),
     "ss_debug_force_tile": (_i, [_i, _i, _i]),
+    "ss_op_ffn_fused": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _i, _i]),
+    "ss_debug_ffn": (_i, [_i, _i, _i]),
     "ss_debug_sk_errors": (_i, []),
     "ss_debug_attention_split": (_i, [_i]),
     "ss_op_conv_gemm": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
