@@ -233,6 +233,11 @@ int ss_prof_totals(int cls, double* h_flops_total, double* h_bytes_total, int64_
 int ss_prof_num_classes(void);
 const char* ss_prof_class_name(int cls);
 
+/* Test hook (tests/test_margin_gpu.py): the dense logits [rows, cols] the LAST ss_batch_ctc_greedy / ss_batch_t2u_units call of
+ * this context took its arg-max over (they live in the context's scratch until the next call that reuses it).  d_out == NULL:
+ * size query only.  Lets a test measure top-1 / top-2 margins of the packed-batch path against the single-utterance path. */
+int ss_debug_last_logits(ss_model* m, void* stream, float* d_out, int64_t cap_floats, int* h_rows, int* h_cols);
+
 /* Unit-test entry of the fused Conformer feed-forward kernel (csrc/ffn.hip; what ss_batch_encoder_forward launches twice per
  * layer on packed batches): dY = dX + alpha * (W2 . SiLU(W1 . LayerNorm(dX; ln_g, ln_b) + b1) + b2), then LayerNorm(ln2_g, ln2_b)
  * over the result rows when ln2_g != NULL -- FeedForwardModule.forward + the 0.5-residual wiring and final_layer_norm of

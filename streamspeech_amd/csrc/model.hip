@@ -165,6 +165,10 @@ struct ss_model {
   DevBuf es_out;        // [es_cap][d]
   int es_cap = 0, es_final = 0, es_achunk = -1, es_cchunk = -1;
   int es_tail = 0;                                  // trailing fbank frames that may still change (resampler edge)
+  // ss_debug_last_logits: where the last batched argmax stage of this context left its dense logits (scratch, valid until the
+  // next call that uses the same scratch buffer)
+  const float* dbg_logits = nullptr;
+  int dbg_rows = 0, dbg_cols = 0;
 };
 
 // Key-split scratch of this context for the single-utterance rel-pos attention: allocated and zeroed on first use (the
@@ -1262,6 +1266,7 @@ extern "C" int ss_batch_ctc_greedy(ss_model* m, void* stream, int head, int B, c
   RET(m->seg_buf.ensure(tr.size() * sizeof(int)));
   RET(upload(s, (int*)m->seg_buf.p, tr));
   RET(linear(s, d_enc_out, c.enc_dim, o.total, head == 0 ? m->ctc_asr : m->ctc_st, V, c.enc_dim, logits, V));
+  m->dbg_logits = logits; m->dbg_rows = o.total; m->dbg_cols = V;
   RET(launch_masked_argmax(logits, V, o.total, V, c.pad, c.unk, -1, -1, d_raw, s));
   return launch_ctc_collapse(d_raw, 0, 0, c.pad, d_tokens, d_index, d_counts, s, (const int*)m->seg_buf.p, B);
 }
@@ -1426,6 +1431,7 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
   }
   RET(launch_layernorm(x, D, h, D, m->unit_ln.g, m->unit_ln.b, U, D, 1e-5f, s));
   RET(linear(s, h, D, U, m->unit_out, V, D, logits, V));
+  m->dbg_logits = logits; m->dbg_rows = U; m->dbg_cols = V;
   RET(launch_masked_argmax(logits, V, U, V, c.pad, c.unk, mask_eos ? c.eos : -1, -1, d_raw, s));
   return launch_ctc_collapse(d_raw, 0, V - 1, c.pad, d_tokens, idx_scratch, d_counts, s, dt + 12 * B, B);
 }
@@ -1554,6 +1560,16 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
   a.chunk = chunk; a.in_act = in_act; a.in_slope = in_slope; a.act = act; a.alpha = alpha; a.div = div; a.glu = glu;
   a.same_rows = (stride == 1 && M == in_len) ? 1 : 0;
   return launch_conv_gemm(a, (hipStream_t)stream);
+}
+
+extern "C" int ss_debug_last_logits(ss_model* m, void* stream, float* d_out, int64_t cap_floats, int* h_rows, int* h_cols) {
+  if (!m || !h_rows || !h_cols) return SS_ERR_ARG;
+  *h_rows = m->dbg_rows; *h_cols = m->dbg_cols;
+  if (!d_out) return SS_OK;                                   // size query
+  if (!m->dbg_logits || cap_floats < (int64_t)m->dbg_rows * m->dbg_cols) return SS_ERR_CAPACITY;
+  SS_HIP_CHECK(hipMemcpyAsync(d_out, m->dbg_logits, (size_t)m->dbg_rows * m->dbg_cols * sizeof(float), hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream));
+  return SS_OK;
 }
 
 extern "C" int ss_op_ffn_fused(void* stream, const float* dX, int ldx, float* dY, int ldy, const float* ln_g, const float* ln_b,

@@ -93,6 +93,14 @@ class BatchMixin:
         toks = [list(out[b * stride: b * stride + n_out[b]]) for b in range(B)]
         return toks, feats, list(n_out)
 
+    def last_logits(self) -> torch.Tensor:
+        """Dense logits [rows, cols] of this context's last batch_ctc_greedy / batch_t2u_units call (test hook: arg-max margins)."""
+        rows, cols = C.c_int(0), C.c_int(0)
+        L.check(self.lib.ss_debug_last_logits(self.h, _stream(), None, 0, C.byref(rows), C.byref(cols)), "ss_debug_last_logits")
+        out = torch.empty((rows.value, cols.value), dtype=torch.float32, device=self.device)
+        L.check(self.lib.ss_debug_last_logits(self.h, _stream(), _ptr(out), out.numel(), C.byref(rows), C.byref(cols)), "ss_debug_last_logits")
+        return out
+
     def batch_t2u_units(self, feats: torch.Tensor, n_rows: List[int], t2u_causal=False, mask_eos=False,
                         return_raw: bool = False):
         """feats [B, rows, D] (rows of utterance b used: n_rows[b]) -> list of collapsed unit-vocab token lists

@@ -1,0 +1,79 @@
+"""how close to an arg-max flip does the packed-batch path run?  The same 32 utterances go once through the
+single-utterance entry points and once through the ragged pack of 32 the bench times (workload.run_batch's calls).  A GEMM routed
+to a stream-K kernel (conv_sk2, the fused FFN) associates a row's partial sums differently in a pack than alone, so logits differ
+at the 1e-6 level; an id can only flip where the top-1 / top-2 margin is smaller than that difference.  Per arg-max stage (ASR CTC,
+ST CTC, MT greedy, unit CTC) the test holds the ids identical, measures the maximum packed-vs-single logit difference and the
+minimum margin, requires difference < margin / 2 on EVERY row (no flip possible), and reports how many rows have a margin below
+100x the difference (the "1 %" reading of the verdict: with seeded random weights thousands of 6000-way rows include near-ties
+that no trained model would have, so that count is printed rather than asserted)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _margins(logits, masked):
+    x = logits.double().clone()
+    x[:, masked] = float("-inf")
+    top = torch.topk(x, 2, dim=1).values
+    return (top[:, 0] - top[:, 1]), x.argmax(1)
+
+
+def _stage(name, single, packed, masked, report):
+    assert single.shape == packed.shape, name
+    diff = (single.double() - packed.double()).abs().max(dim=1).values
+    mg, am_s = _margins(single, masked)
+    _, am_p = _margins(packed, masked)
+    assert torch.equal(am_s, am_p), f"{name}: arg-max differs between the single-utterance and the packed path"
+    risk = mg < 2.0 * diff
+    at_1pct = int((mg < 100.0 * diff.max()).sum())
+    report[name] = {"rows": int(single.shape[0]), "max_logit_diff": float(diff.max()), "min_margin": float(mg.min()),
+                    "median_margin": float(mg.median()), "rows_with_margin_below_100x_max_diff": at_1pct}
+    assert not bool(risk.any()), f"{name}: {int(risk.sum())} rows have a margin below twice the packed-vs-single difference: {report[name]}"
+
+
+def test_pack_of_32_vs_single_utterance_argmax_margins(hip_model, synth_weights):
+    from streamspeech_amd import synth, workload
+    from streamspeech_amd.pipeline import mt_greedy
+    cfg, vcfg, sd, vsd = synth_weights
+    m = hip_model
+    utts = sorted(workload.make_utterances(96), key=lambda u: -u.seconds)[32:64]       # a middle-of-the-distribution bucket of the bench plan
+    pcms = [torch.from_numpy(synth.synth_pcm(1234 + u.idx, u.n_samples)).cuda() for u in utts]
+    emb = torch.from_numpy(np.asarray(sd["target_unigram_decoder.embed_tokens.weight"])).double()
+
+    # ---- single-utterance entry points ----
+    s_asr, s_st, s_mt, s_unit, s_tok = [], [], [], [], []
+    for u, pcm in zip(utts, pcms):
+        enc = m.encoder_forward(m.fbank_cmvn(pcm))
+        s_asr.append(m.ctc_greedy(0, enc, want_logits=True)[3].cpu())
+        s_st.append(m.ctc_greedy(1, enc, want_logits=True)[3].cpu())
+        toks, feats = mt_greedy(m, enc, max_new_tokens=u.n_mt)
+        assert len(toks) == u.n_mt + 1 and toks[-1] == cfg.eos
+        s_tok.append(toks)
+        s_mt.append(feats[: u.n_mt + 1].cpu())
+        s_unit.append(m.t2u_units(feats[: u.n_mt + 1], want_logits=True)[2].cpu())
+
+    # ---- the ragged pack of 32 (the calls of workload.run_batch) ----
+    feat, T = m.batch_fbank_cmvn(torch.cat(pcms), [u.n_samples for u in utts])
+    enc, Tp = m.batch_encoder_forward(feat, T)
+    m.batch_ctc_greedy(0, enc, Tp)
+    p_asr = m.last_logits().cpu()
+    m.batch_ctc_greedy(1, enc, Tp)
+    p_st = m.last_logits().cpu()
+    toks, feats, n = m.batch_mt_greedy(enc, Tp, [u.n_mt for u in utts])
+    assert [list(t) for t in toks] == s_tok
+    m.batch_t2u_units(feats, n)
+    p_unit = m.last_logits().cpu()
+    p_mt = torch.cat([feats[b, : utts[b].n_mt + 1].cpu() for b in range(len(utts))])
+
+    report = {}
+    _stage("asr_ctc", torch.cat(s_asr), p_asr, [cfg.pad, cfg.unk], report)
+    _stage("st_ctc", torch.cat(s_st), p_st, [cfg.pad, cfg.unk], report)
+    _stage("unit_ctc", torch.cat(s_unit), p_unit, [cfg.pad, cfg.unk], report)
+    # MT greedy: next-token logits = decoder state . E^T (tied projection); the last row of every utterance is the forced </s>
+    keep = torch.cat([torch.arange(u.n_mt + 1) < u.n_mt for u in utts])
+    lm_s = (torch.cat(s_mt).double() @ emb.T)[keep]
+    lm_p = (p_mt.double() @ emb.T)[keep]
+    _stage("mt_greedy", lm_s.float(), lm_p.float(), [cfg.pad, cfg.eos], report)
+    print("packed-vs-single arg-max margins:", report)
