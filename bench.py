@@ -613,7 +613,10 @@ def main():
         lib.ss_prof_enable(0)
         lib.ss_prof_reset()
 
-    # single-stream latency pass (untimed for `value`; reported as latency_ms_single_stream)
+    # single-stream latency pass (untimed for `value`; reported as latency_ms_single_stream): one utterance at a time on the
+    # primary context, whose MT decode step is the persistent one-launch form by default (engine.HipModel; the batched /
+    # multi-stream paths of this file never use it) -- and the same utterances with the launch-per-op step for comparison
+    pmt_default = int(getattr(model, "persistent_mt", 0))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nlat = 1 if args.no_latency_pass else min(Kpool, 8)
@@ -623,19 +626,19 @@ def main():
     torch.cuda.synchronize()
     single_ms = 1e3 * (time.perf_counter() - t0) / nlat
     single_rtfx = sum(mine[i].seconds for i in lat_idx) / (single_ms * 1e-3 * nlat)
-    # the same utterances with the MT decode step as one persistent launch (ss_mt_set_persistent: opt-in per context, what the
-    # SimulEval agents switch on; the batched / multi-stream paths of this file never use it)
-    single_ms_pmt = None
+    pmt_after = int(getattr(model, "persistent_mt", 0))      # 0 if the persistent step timed out and the context fell back
+    single_ms_lpo = None
     if not args.no_latency_pass and hasattr(model, "set_persistent_mt_step"):
-        model.set_persistent_mt_step(64)
+        model.set_persistent_mt_step(0)
         run_utterance(model, voc, pcms[lat_idx[0]], mine[lat_idx[0]])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in lat_idx:
             run_utterance(model, voc, pcms[i], mine[i])
         torch.cuda.synchronize()
-        single_ms_pmt = 1e3 * (time.perf_counter() - t0) / nlat
-        model.set_persistent_mt_step(0)
+        single_ms_lpo = 1e3 * (time.perf_counter() - t0) / nlat
+    if hasattr(model, "set_persistent_mt_step"):
+        model.set_persistent_mt_step(0)       # from here on this context runs next to seven others: launch-per-op (see HipModel.new_context)
 
     # S concurrent utterance streams: worker threads (ctypes releases the GIL inside the C ABI),
     # each with its own HIP stream and its own scratch/KV-cache context over the shared weights
@@ -992,7 +995,8 @@ def main():
                        "length_bucketed_batches": (not args.no_length_bucketing) and Bsz > 1, "utterances_per_ragged_batch": Bsz, "concurrent_streams_per_gpu": S,
                        "parallelism": f"utterance-dp{world}"},
             "latency_ms_single_stream": round(single_ms, 3), "rtfx_single_stream": round(single_rtfx, 2),
-            "latency_ms_single_stream_persistent_mt_step": None if single_ms_pmt is None else round(single_ms_pmt, 3),
+            "latency_ms_single_stream_launch_per_op_mt_step": None if single_ms_lpo is None else round(single_ms_lpo, 3),
+            "single_stream_mt_step": {"persistent_workgroups_default": pmt_default, "after_the_pass": pmt_after},
             "batch1_8streams": None if b1_rtfx is None else {"rtfx": round(b1_rtfx, 1), "utterances_per_sec": round(b1_ups, 1),
                                                              "note": "one utterance per call (no ragged packs), 8 concurrent streams, 64 utterances"},
             "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),   # must be 0 (bounded waits of the stream-K fix-up); also asserted for the timed region

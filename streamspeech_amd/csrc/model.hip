@@ -107,7 +107,7 @@ int ln_linear(hipStream_t s, const float* x, int M, const LN& ln, const Lin& l, 
 }  // namespace
 
 static int g_ffn_fusion = getenv("SS_NO_FFN_FUSION") && atoi(getenv("SS_NO_FFN_FUSION")) ? 0 : 1;   // A/B knob: encoder FFNs of packed batches as one launch each (ffn.hip)
-static int g_ffn_min_rows = getenv("SS_FFN_MIN_ROWS") ? atoi(getenv("SS_FFN_MIN_ROWS")) : 768;       // below: the two-launch form (too few row tiles to fill the chip)
+static int g_ffn_min_rows = getenv("SS_FFN_MIN_ROWS") ? atoi(getenv("SS_FFN_MIN_ROWS")) : 1000;      // below: the two-launch form (too few row tiles to fill the chip)
 
 // =================================================================================================
 // model

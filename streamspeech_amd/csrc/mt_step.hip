@@ -53,7 +53,7 @@ namespace {
 // All 256 threads sweep N granules (N <= 2304) into dst until every tag carries `epoch`; bounded.
 [[maybe_unused]] __device__ __forceinline__ void mt_gather(const mt_u64* g, int N, float* dst, unsigned epoch, unsigned* err, int t, int lane) {
   constexpr int MAXL = 9;
-  unsigned spins = 0;
+  unsigned long long t_first = 0ull;     // wall clock (100 MHz) of the first sweep that found a granule missing
   __syncthreads();                       // every wave is done reading what dst held before
   for (;;) {
     mt_u64 x[MAXL];
@@ -71,8 +71,13 @@ namespace {
       if (idx < N) dst[idx] = __uint_as_float((unsigned)x[k]);
     }
     if (__all(ok)) break;
-    if (++spins > MT_SPIN_LIMIT || __hip_atomic_load(err, MT_RLX) != 0u) {
-      if (lane == 0 && spins > MT_SPIN_LIMIT) atomicAdd(err, 1u);
+    // bounded by TIME (2^18 sweeps were hundreds of ms per wave): a granule that has not arrived MT_WAIT_TICKS after
+    // it was first missed means a workgroup of this launch is not resident -- count it, let the launch run out, the host falls back
+    const unsigned long long now = wall_clock64();
+    if (t_first == 0ull) t_first = now;
+    const bool late = now - t_first > MT_WAIT_TICKS;
+    if (late || __hip_atomic_load(err, MT_RLX) != 0u) {
+      if (lane == 0 && late) atomicAdd(err, 1u);
       break;
     }
     __builtin_amdgcn_s_sleep(1);

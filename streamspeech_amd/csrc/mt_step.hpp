@@ -15,7 +15,8 @@ constexpr int MG_QKV = 0, MG_ATT = MG_QKV + 3 * MT_D, MG_X1 = MG_ATT + MT_D, MG_
 constexpr int MG_ARG = MT_L * MG_LAYER;                        // 2 granules per workgroup: value bits, index
 constexpr int MT_MAXG = 256;
 constexpr int MG_TOTAL = MG_ARG + 2 * MT_MAXG;
-constexpr unsigned MT_SPIN_LIMIT = 1u << 18;
+constexpr unsigned long long MT_WAIT_TICKS = 1000000ull;  // bounded wait of an exchange: 10 ms of the 100 MHz wall clock (a healthy exchange takes 2-4 us;
+                                                         // a workgroup kept off the chip by another stream's full-chip kernel arrives within ~1 ms)
 
 inline size_t mt_step_granule_bytes() { return (size_t)MG_TOTAL * sizeof(mt_u64); }
 

@@ -3,6 +3,7 @@ to the C ABI.  Torch is plumbing here (allocation, streams, H2D/D2H copies) -- e
 S2ST path runs in libstreamspeech_hip.so.
 """
 import ctypes as C
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -149,10 +150,19 @@ class HipModel(BatchMixin):
                                              C.byref(h)), "ss_model_create")
         self.h = h
         self.max_tgt_pos = max_tgt_pos
+        # MT decode step of single-utterance searches (ss_mt_greedy / ss_mt_append with one token): the C ABI's default is the
+        # launch-per-op form (SS_MT_PERSISTENT overrides it); a PRIMARY context -- the one an agent / the offline driver / a
+        # one-utterance-at-a-time caller decodes on, alone on its device -- uses the persistent one-launch step (mt_step.hip:
+        # 125 vs 189 us per token).  Contexts made by new_context() exist for concurrency and keep the launch-per-op form; a
+        # time-out of the persistent step (its workgroups were not all resident) falls back to it for good and says so.
+        self.persistent_mt = int(self.lib.ss_mt_get_persistent(self.h))
+        if _share is None and "SS_MT_PERSISTENT" not in os.environ:
+            self.set_persistent_mt_step(64)
 
     def new_context(self) -> "HipModel":
         """A second ss_model handle (own scratch / KV caches) borrowing the same weights: one per
-        concurrent utterance stream."""
+        concurrent utterance stream.  (Concurrent contexts start with the launch-per-op MT decode step: the persistent step's
+        workgroups must all be resident, which only a context that decodes alone on the device can count on.)"""
         return HipModel(None, self.cfg, device=str(self.device), max_rel_pos=self._dims[0],
                         max_tgt_pos=self._dims[1], _share=self._packed)
 

@@ -361,7 +361,7 @@ def test_incremental_encoder_equals_full_recompute_on_a_30_second_source(hip_mod
         if prev is not None and prev_final > 0:
             assert torch.equal(inc[:prev_final], prev[:prev_final]), "final rows must be served unchanged"
         assert nc <= 8 + 8 + 8 + 16, f"T={T}: {nc} rows recomputed"       # bounded, not growing with the prefix
-        if k % 6 == 5 or T == 3000:
+        if k % 6 == 5 or T in (1568, 3000):
             full = hip_model.encoder_forward(fb, 8, 8)
             err = (inc - full).abs().max().item()
             worst = max(worst, err)
