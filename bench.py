@@ -608,7 +608,7 @@ def main():
             lib.ss_prof_read(c, C.byref(ms), C.byref(fl), C.byref(n), C.byref(by))
             times.append(ms.value)
         dom = max(range(ncls), key=lambda c: times[c])
-        others = [c for c in range(ncls) if c != dom and times[c] > 0 and lib.ss_prof_class_name(c).decode().startswith(("conv_", "resblock_fused", "ffn_fused"))]
+        others = [c for c in range(ncls) if c != dom and times[c] > 0 and lib.ss_prof_class_name(c).decode().startswith(("conv_", "resblock_fused", "ffn_fused", "rt_linear"))]
         dom_conv = max(others, key=lambda c: times[c]) if others else None
         lib.ss_prof_enable(0)
         lib.ss_prof_reset()

@@ -249,6 +249,16 @@ int ss_op_ffn_fused(void* stream, const float* dX, int ldx, float* dY, int ldy, 
 /* A/B + test hook of the same kernel: grid > 0 fixes its workgroup count (0: heuristic); row_tiles_per_wave 3 | 4 picks 48- or
  * 64-row tiles (0: keep); enable 0 / 1 switches its use by ss_batch_encoder_forward off / on (-1: keep). */
 int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable);
+/* A/B + test hook of the row-tile linear kernel (csrc/rtlin.hip: every K = 256 linear of more than 192 rows that goes through
+ * ss_op_conv_gemm / the model entry points): grid > 0 fixes its workgroup count (0: heuristic); enable 0 / 1 routes those linears
+ * back to the LDS-tiled kernel / to it (-1: keep). */
+int ss_debug_rtlin(int grid, int enable);
+/* Unit-test entry of the LayerNorm-prologue linears (what ln_linear() in model.hip issues for QKV / pointwise conv 1 / the FFNs
+ * of one utterance): dC = epi(LayerNorm(dX; ln_g, ln_b, eps 1e-5) . dW^T + dbias), epi as ss_op_conv_gemm (act, alpha, + dR, glu).
+ * Served by the small-M kernel (<= 192 rows) or the row-tile kernel (K = 256, more rows); SS_ERR_ARG otherwise. */
+int ss_op_ln_linear(void* stream, const float* dX, int ldx, const float* ln_g, const float* ln_b, const float* dW,
+                    const float* dbias, const float* dR, int ldr, float* dC, int ldc, int M, int N, int K, int act, float alpha,
+                    int glu);
 
 /* Tuning / A-B hook (tools/conv_bench.py, tests): bm = 0 heuristic; 1 route every eligible launch to the first-generation
  * stream-K kernel with a grid of ks workgroups (ks = 0 -> 2 per CU; bn = 8: XCD tile groups); 2 no slab kernel; 3 the

@@ -630,7 +630,7 @@ static const char* kTileNames[kNumTileCfg] = {
     "conv_slab<32>", "conv_slab<16>", "conv_sk2<256,128,32>", "conv_sk2_bf16x3<256,128,32>",
     // whole-ResBlock launches of the narrow vocoder stages (resblock.hip) and the fused encoder FFN (ffn.hip): kernels of their own,
     // booked under their own names (round 3 booked resblock_fused under conv_slab<..>: VERDICT r3 "mislabelled second kernel")
-    "resblock_fused<32>", "resblock_fused<16>", "ffn_fused<256,2048>"};
+    "resblock_fused<32>", "resblock_fused<16>", "ffn_fused<256,2048>", "rt_linear<48,256>"};
 static int g_prof_mask = 0;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
@@ -898,7 +898,9 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
     if (wgs16 <= 4096) return launch_smallm<2, 2>(a, stream, 13);
     return launch_smallm<1, 4>(a, stream, 14);
   }
-  if (a.ln_g) return SS_ERR_ARG;  // LayerNorm fusion exists only on the small-M path
+  // K = 256 linears of packed batches (encoder projections, CTC heads, cross K|V): row tile in LDS, W fragments from L2 (rtlin.hip)
+  if (!g_force_bm && rtlin_eligible(a)) return launch_rtlin(a, stream);
+  if (a.ln_g) return SS_ERR_ARG;  // LayerNorm fusion exists only on the small-M and row-tile paths
   if (g_force_bm == 1 && conv_sk_eligible(a)) return launch_conv_sk(a, stream, g_force_ks);   // tuning hook: stream-K, grid = ks (0 = auto)
   if (g_force_bm == 4 && conv_sk2_eligible(a)) return launch_conv_sk2(a, stream, g_force_ks);  // tuning hook: 2nd-generation stream-K
   if (g_force_bm == 5 && conv_sk2_eligible(a)) { GemmArgs b = a; b.x3 = 1; return launch_conv_sk2(b, stream, g_force_ks); }  // ... its split-bf16 variant (tests, tools/sk2_bench.py)

@@ -60,7 +60,7 @@ struct GemmArgs {
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 23;
+constexpr int kNumTileCfg = 24;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
@@ -130,6 +130,12 @@ bool resblock_fused_eligible(int C, int taps, const int* dil, int ldx, int ldy, 
 int launch_resblock_fused(const float* X, int ldx, const float* const* W1, const float* const* B1, const float* const* W2,
                           const float* const* B2, const int* dil, float* Y, int ldy, const float* R2, int ldr2, float div, int C,
                           int taps, int M, float slope, const int* segs, int nseg, hipStream_t stream);
+
+// Row-tile linear layer for K = 256 projections of packed batches (rtlin.hip): the row tile (LayerNorm-ed when a.ln_g is set) in
+// LDS, weight fragments straight from L2 to registers, bias / activation / alpha / residual or GLU epilogue per 16-column unit.
+bool rtlin_eligible(const GemmArgs& a);
+int launch_rtlin(const GemmArgs& a, hipStream_t stream);
+void rtlin_debug(int grid, int enable);   // tests / A-B: fixed workgroup count (0 = heuristic); enable 0 / 1 (-1: keep)
 
 // Fused Conformer feed-forward module (ffn.hip): Y = X + alpha * (W2 . SiLU(W1 . LayerNorm(X) + b1) + b2), optionally followed by
 // LayerNorm(ln2) over the result rows; one persistent launch, hidden activations stay in registers.  D = 256, F % 64 == 0.

@@ -98,6 +98,11 @@ int ln_linear(hipStream_t s, const float* x, int M, const LN& ln, const Lin& l, 
     a.ln_g = ln.g; a.ln_b = ln.b;
     return launch_conv_gemm(a, s);
   }
+  {
+    GemmArgs b = a;
+    b.ln_g = ln.g; b.ln_b = ln.b;
+    if (rtlin_eligible(b)) return launch_conv_gemm(b, s);      // LayerNorm in the row tile's way into LDS (rtlin.hip)
+  }
   int rc = layernorm(s, x, h, ln, M, K);
   if (rc != SS_OK) return rc;
   a.A = h;
@@ -1576,6 +1581,20 @@ extern "C" int ss_op_ffn_fused(void* stream, const float* dX, int ldx, float* dY
                                const float* dW1, const float* db1, const float* dW2, const float* db2, float alpha,
                                const float* ln2_g, const float* ln2_b, int M, int D, int F) {
   return launch_ffn_fused(dX, ldx, dY, ldy, ln_g, ln_b, dW1, db1, dW2, db2, alpha, ln2_g, ln2_b, M, D, F, (hipStream_t)stream);
+}
+extern "C" int ss_op_ln_linear(void* stream, const float* dX, int ldx, const float* ln_g, const float* ln_b, const float* dW,
+                               const float* dbias, const float* dR, int ldr, float* dC, int ldc, int M, int N, int K, int act,
+                               float alpha, int glu) {
+  GemmArgs a;
+  a.A = dX; a.lda = ldx; a.W = dW; a.bias = dbias; a.R = dR; a.ldr = ldr; a.C = dC; a.ldc = ldc;
+  a.M = M; a.N = N; a.Cin = K; a.in_len = M; a.act = act; a.alpha = alpha; a.glu = glu; a.same_rows = 1;
+  a.ln_g = ln_g; a.ln_b = ln_b;
+  return launch_conv_gemm(a, (hipStream_t)stream);       // SS_ERR_ARG when no kernel with a LayerNorm prologue takes the shape
+}
+extern "C" int ss_debug_rtlin(int grid, int enable) {
+  if (grid < 0) return SS_ERR_ARG;
+  rtlin_debug(grid, enable);
+  return SS_OK;
 }
 extern "C" int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable) {
   if (grid < 0 || !(row_tiles_per_wave == 0 || row_tiles_per_wave == 3 || row_tiles_per_wave == 4)) return SS_ERR_ARG;
