@@ -60,7 +60,7 @@ struct GemmArgs {
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 24;
+constexpr int kNumTileCfg = 25;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
@@ -130,6 +130,13 @@ bool resblock_fused_eligible(int C, int taps, const int* dil, int ldx, int ldy, 
 int launch_resblock_fused(const float* X, int ldx, const float* const* W1, const float* const* B1, const float* const* W2,
                           const float* const* B2, const int* dil, float* Y, int ldy, const float* R2, int ldr2, float div, int C,
                           int taps, int M, float slope, const int* segs, int nseg, hipStream_t stream);
+
+// Slab conv with streamed weights for the 64-channel vocoder stage of a packed batch (conv_c64.hip): Cin = N = 64, "same" rows,
+// input leaky-ReLU applied while the slab is staged, W fragments straight from L2.
+bool conv_c64_eligible(const GemmArgs& a);
+bool conv_c64_enabled();
+int launch_conv_c64(const GemmArgs& a, hipStream_t stream);
+void conv_c64_debug(int enable);          // A/B: 0 routes the stage back to conv_sk2<64> (pre-activated twins), 1 on, -1 keep
 
 // Row-tile linear layer for K = 256 projections of packed batches (rtlin.hip): the row tile (LayerNorm-ed when a.ln_g is set) in
 // LDS, weight fragments straight from L2 to registers, bias / activation / alpha / residual or GLU epilogue per 16-column unit.

@@ -954,7 +954,19 @@ template <class ConvFn, class StageFn, class GeomFn>
 static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, StageFn&& on_stage, GeomFn&& geom,
                          const float* frames, int Ft, const GenBufs& b, int* out_scale, int* out_C) {
   const ss_vocoder_config& c = v->cfg;
-  auto preact = [](int channels) { return channels >= 64; };
+  // Stages with >= 64 channels get their input leaky-ReLU from the PRODUCER (a second, pre-activated output: VALU work inside a
+  // stream-K MFMA loop costs matrix-core time) -- except the 64-channel stage of a packed batch, whose convs run on conv_c64.hip:
+  // that kernel applies the activation once per element while it stages its input slab, so no twin tensor is written or read.
+  bool c64 = conv_c64_enabled() && !v->x3;
+  if (c64) {
+    long long rows = Ft; int ch = c.upsample_initial_channel; bool found = false;
+    for (int i = 0; i < c.n_up && !found; ++i) { rows *= c.upsample_rates[i]; ch /= 2; found = ch == 64; }
+    GemmArgs probe;
+    probe.same_rows = 1; probe.Cin = probe.N = probe.lda = probe.ldc = 64; probe.taps = 3; probe.dil = 1; probe.pad = 1; probe.M = (int)rows;
+    probe.in_len = (int)rows; probe.in_act = ACT_LRELU;
+    c64 = found && rows < (1ll << 30) && conv_c64_eligible(probe);
+  }
+  auto preact = [c64](int channels) { return channels >= 64 && !(c64 && channels == 64); };
   auto mk = [v](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
     GemmArgs a;
     a.A = A; a.lda = Cin; a.W = cw.w; a.bias = cw.b; a.C = Cc; a.ldc = ldc; a.ldr = ldc; a.ldr2 = ldc; a.ldc2 = ldc;
@@ -1591,6 +1603,7 @@ extern "C" int ss_op_ln_linear(void* stream, const float* dX, int ldx, const flo
   a.ln_g = ln_g; a.ln_b = ln_b;
   return launch_conv_gemm(a, (hipStream_t)stream);       // SS_ERR_ARG when no kernel with a LayerNorm prologue takes the shape
 }
+extern "C" int ss_debug_conv_c64(int enable) { conv_c64_debug(enable); return SS_OK; }
 extern "C" int ss_debug_rtlin(int grid, int enable) {
   if (grid < 0) return SS_ERR_ARG;
   rtlin_debug(grid, enable);
