@@ -955,22 +955,18 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
                          const float* frames, int Ft, const GenBufs& b, int* out_scale, int* out_C) {
   const ss_vocoder_config& c = v->cfg;
   // Stages with >= 64 channels get their input leaky-ReLU from the PRODUCER (a second, pre-activated output: VALU work inside a
-  // stream-K MFMA loop costs matrix-core time) -- except the 64- and 128-channel stages of a packed batch, whose ResBlock convs
-  // run on conv_c64.hip / conv_c128.hip: those kernels apply the activation once per element while they stage their input slab,
-  // so no twin tensor is written or read.  Up-convs out of a >= 128-channel stage stay on stream-K and keep a pre-activated input.
-  auto slab_stage = [&](int channels) {
-    if (v->x3 || !(channels == 64 ? conv_c64_enabled() : channels == 128 ? conv_c128_enabled() : false)) return false;
+  // stream-K MFMA loop costs matrix-core time) -- except the 64-channel stage of a packed batch, whose convs run on conv_c64.hip:
+  // that kernel applies the activation once per element while it stages its input slab, so no twin tensor is written or read.
+  bool c64 = conv_c64_enabled() && !v->x3;
+  if (c64) {
     long long rows = Ft; int ch = c.upsample_initial_channel; bool found = false;
-    for (int i = 0; i < c.n_up && !found; ++i) { rows *= c.upsample_rates[i]; ch /= 2; found = ch == channels; }
-    if (!found || rows >= (1ll << 30)) return false;
+    for (int i = 0; i < c.n_up && !found; ++i) { rows *= c.upsample_rates[i]; ch /= 2; found = ch == 64; }
     GemmArgs probe;
-    probe.same_rows = 1; probe.Cin = probe.N = probe.lda = probe.ldc = channels; probe.taps = 3; probe.dil = 1; probe.pad = 1;
-    probe.M = probe.in_len = (int)rows; probe.in_act = ACT_LRELU;
-    return channels == 64 ? conv_c64_eligible(probe) : conv_c128_eligible(probe);
-  };
-  const bool c64 = slab_stage(64), c128 = slab_stage(128);
-  auto preact = [c64, c128](int channels) { return channels >= 64 && !(c64 && channels == 64) && !(c128 && channels == 128); };
-  auto upconv_preact = [c64](int cin) { return cin >= 64 && !(c64 && cin == 64); };   // up-conv out of a `cin`-channel stage reads lrelu(x) from the producer
+    probe.same_rows = 1; probe.Cin = probe.N = probe.lda = probe.ldc = 64; probe.taps = 3; probe.dil = 1; probe.pad = 1; probe.M = (int)rows;
+    probe.in_len = (int)rows; probe.in_act = ACT_LRELU;
+    c64 = found && rows < (1ll << 30) && conv_c64_eligible(probe);
+  }
+  auto preact = [c64](int channels) { return channels >= 64 && !(c64 && channels == 64); };
   auto mk = [v](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
     GemmArgs a;
     a.A = A; a.lda = Cin; a.W = cw.w; a.bias = cw.b; a.C = Cc; a.ldc = ldc; a.ldr = ldc; a.ldr2 = ldc; a.ldc2 = ldc;
@@ -987,7 +983,7 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
   }
   for (int i = 0; i < c.n_up; ++i) {
     const int st = c.upsample_rates[i], Co = C / 2;
-    const bool pa_in = i == 0 ? preact(C) : upconv_preact(C), pa = preact(Co);
+    const bool pa_in = preact(C), pa = preact(Co);
     {
       // leaky_relu(0.1) -> ConvTranspose1d as a 3-tap polyphase conv with N = st*Co: row q of the
       // [T, st*Co] result is rows q*st .. q*st+st-1 of the [T*st, Co] signal.
@@ -999,7 +995,7 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
     }
     scale *= st; C = Co;
     RET(on_stage(scale));
-    const bool pa_next = (i + 1 < c.n_up) && upconv_preact(C);     // the next up-conv reads leaky_relu(x)
+    const bool pa_next = (i + 1 < c.n_up) && preact(C);     // the next up-conv reads leaky_relu(x)
     for (int j = 0; j < c.n_res; ++j) {
       const int kr = c.resblock_kernel_sizes[j];
       // narrow stages: each (dilated conv, plain conv, residual) pair as ONE launch with the intermediate in LDS
@@ -1608,7 +1604,6 @@ extern "C" int ss_op_ln_linear(void* stream, const float* dX, int ldx, const flo
   return launch_conv_gemm(a, (hipStream_t)stream);       // SS_ERR_ARG when no kernel with a LayerNorm prologue takes the shape
 }
 extern "C" int ss_debug_conv_c64(int enable) { conv_c64_debug(enable); return SS_OK; }
-extern "C" int ss_debug_conv_c128(int enable) { conv_c128_debug(enable); return SS_OK; }
 extern "C" int ss_debug_rtlin(int grid, int enable) {
   if (grid < 0) return SS_ERR_ARG;
   rtlin_debug(grid, enable);
