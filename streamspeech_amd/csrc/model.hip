@@ -957,15 +957,18 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
   // Stages with >= 64 channels get their input leaky-ReLU from the PRODUCER (a second, pre-activated output: VALU work inside a
   // stream-K MFMA loop costs matrix-core time) -- except the 64-channel stage of a packed batch, whose convs run on conv_c64.hip:
   // that kernel applies the activation once per element while it stages its input slab, so no twin tensor is written or read.
-  bool c64 = conv_c64_enabled() && !v->x3;
-  if (c64) {
+  // The 32-channel stage of a packed batch runs its convs one by one on conv_c32.hip instead of one fused launch per ResBlock.
+  auto slab_stage = [&](int channels) {
+    if (v->x3 || !(channels == 64 ? conv_c64_enabled() : channels == 32 ? conv_c32_enabled() : false)) return false;
     long long rows = Ft; int ch = c.upsample_initial_channel; bool found = false;
-    for (int i = 0; i < c.n_up && !found; ++i) { rows *= c.upsample_rates[i]; ch /= 2; found = ch == 64; }
+    for (int i = 0; i < c.n_up && !found; ++i) { rows *= c.upsample_rates[i]; ch /= 2; found = ch == channels; }
+    if (!found || rows >= (1ll << 30)) return false;
     GemmArgs probe;
-    probe.same_rows = 1; probe.Cin = probe.N = probe.lda = probe.ldc = 64; probe.taps = 3; probe.dil = 1; probe.pad = 1; probe.M = (int)rows;
-    probe.in_len = (int)rows; probe.in_act = ACT_LRELU;
-    c64 = found && rows < (1ll << 30) && conv_c64_eligible(probe);
-  }
+    probe.same_rows = 1; probe.Cin = probe.N = probe.lda = probe.ldc = channels; probe.taps = 3; probe.dil = 1; probe.pad = 1;
+    probe.M = probe.in_len = (int)rows; probe.in_act = ACT_LRELU;
+    return channels == 64 ? conv_c64_eligible(probe) : conv_c32_eligible(probe);
+  };
+  const bool c64 = slab_stage(64), c32 = slab_stage(32);
   auto preact = [c64](int channels) { return channels >= 64 && !(c64 && channels == 64); };
   auto mk = [v](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
     GemmArgs a;
@@ -1005,7 +1008,11 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
       // 10-30 % at k = 11 (MFMA-bound: halo rows of conv1 are extra work and the 54-KB footprint halves the occupancy)
       // narrow stages: the whole ResBlock (three pairs) as ONE persistent launch (resblock.hip); bit-identical to the
       // pair / two-launch forms below, which stay as the A/B and fallback path
-      if (!pa && !g_no_resblock_fusion && resblock_fused_eligible(C, kr, c.resblock_dilations[j], C, C, gnseg, gM)) {
+      // conv_c32.hip: at k = 11 (MFMA-bound) six separate convs beat the fused ResBlock launch -- no halo recompute: 107 vs 86
+      // TFLOP/s in the pipeline; at k = 3 / 7 the fused launch wins (92-98 vs 56-93: the separate convs are HBM-bound there)
+      static const int c32_min_k = getenv("SS_CONV_C32_MIN_K") ? atoi(getenv("SS_CONV_C32_MIN_K")) : 11;
+      const bool per_conv = c32 && C == 32 && kr >= c32_min_k;
+      if (!pa && !per_conv && !g_no_resblock_fusion && resblock_fused_eligible(C, kr, c.resblock_dilations[j], C, C, gnseg, gM)) {
         const float *W1[3], *B1[3], *W2[3], *B2[3];
         for (int dd = 0; dd < 3; ++dd) {
           const int idx = (i * c.n_res + j) * 3 + dd;
@@ -1015,7 +1022,7 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
                                   j == c.n_res - 1 ? (float)c.n_res : 0.f, C, kr, gM, 0.1f, gsegs, gnseg, s));
         continue;
       }
-      const bool fuse = !pa && !g_no_pair_fusion && kr == 3 &&
+      const bool fuse = !pa && !per_conv && !g_no_pair_fusion && kr == 3 &&
                         conv_pair_eligible(C, kr, c.resblock_dilations[j][2], C, C, gnseg, gM);
       const float* cur = b.bs;
       for (int dd = 0; dd < 3; ++dd) {
@@ -1604,6 +1611,7 @@ extern "C" int ss_op_ln_linear(void* stream, const float* dX, int ldx, const flo
   return launch_conv_gemm(a, (hipStream_t)stream);       // SS_ERR_ARG when no kernel with a LayerNorm prologue takes the shape
 }
 extern "C" int ss_debug_conv_c64(int enable) { conv_c64_debug(enable); return SS_OK; }
+extern "C" int ss_debug_conv_c32(int enable) { conv_c32_debug(enable); return SS_OK; }
 extern "C" int ss_debug_rtlin(int grid, int enable) {
   if (grid < 0) return SS_ERR_ARG;
   rtlin_debug(grid, enable);

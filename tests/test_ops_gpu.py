@@ -450,34 +450,39 @@ def test_stream_k_fixup_never_reads_stale_partials(lib):
     assert (first[0].cpu() - ref).abs().max() < TOL
 
 
-@pytest.mark.parametrize("taps,dil,M,lrelu,extras", [(3, 1, 40000, True, True), (3, 5, 33000, True, False), (7, 3, 40077, True, True),
-                                                      (11, 5, 36001, True, True), (11, 1, 40000, False, False), (3, 1, 32768, False, True)])
-def test_conv_c64_slab_kernel(lib, taps, dil, M, lrelu, extras):
+@pytest.mark.parametrize("C_", [64, 32])
+@pytest.mark.parametrize("taps,dil,M,lrelu,extras", [(3, 1, 70000, True, True), (3, 5, 66000, True, False), (7, 3, 70077, True, True),
+                                                      (11, 5, 66001, True, True), (11, 1, 70000, False, False), (3, 1, 65536, False, True),
+                                                      (2, 1, 66000, True, False)])
+def test_conv_c64_slab_kernel(lib, C_, taps, dil, M, lrelu, extras):
     """csrc/conv_c64.hip (the 64-channel vocoder stage of a packed batch: input slab once into LDS with the leaky-ReLU applied on
     the way, weight fragments streamed from L2): dilated "same" convs with bias / residual / MRF accumulate / mean against torch,
     and against the stream-K kernel it replaces (ss_debug_conv_c64(0)); both block heights (k = 11 at dilation 5 -> 192 rows)."""
     from streamspeech_amd.weights import conv_tap_major
-    C = 64
+    C = C_
+    cls = "conv_c64<256,64>" if C == 64 else "conv_c32<256,32>"
+    dbg = lib.ss_debug_conv_c64 if C == 64 else lib.ss_debug_conv_c32
     x = rnd(M, C, seed=31)
     w = rnd(C, C, taps, seed=32, scale=(C * taps) ** -0.5)
     b = rnd(C, seed=33, scale=0.1)
     R, R2 = (rnd(M, C, seed=34), rnd(M, C, seed=35)) if extras else (None, None)
     pad = dil * (taps - 1) // 2
     xin = F.leaky_relu(x, 0.1) if lrelu else x
-    y = F.conv1d(xin.t()[None].double(), w.double(), b.double(), dilation=dil, padding=pad)[0].t()
+    xin_p = F.pad(xin.t()[None].double(), (pad, dil * (taps - 1) - pad))          # even tap counts: the extra row goes to the right
+    y = F.conv1d(xin_p, w.double(), b.double(), dilation=dil)[0].t()
     ref = ((R2.double() + (y + R.double())) / 3.0) if extras else y
     kw = dict(taps=taps, dil=dil, pad=pad, in_act=3 if lrelu else 0, slope=0.1, R=R, R2=R2, div=3.0 if extras else 0.0)
-    n0 = _class_launches_ops(lib, "conv_c64<256,64>")
+    n0 = _class_launches_ops(lib, cls)
     got = run_conv_gemm(lib, x, conv_tap_major(w), b, M, C, C, **kw)
-    assert _class_launches_ops(lib, "conv_c64<256,64>") == n0 + 1, "the slab kernel must have taken the launch"
+    assert _class_launches_ops(lib, cls) == n0 + 1, "the slab kernel must have taken the launch"
     assert torch.isfinite(got).all()
     assert (got.double() - ref).abs().max() < TOL, f"max err {(got.double() - ref).abs().max()}"
-    lib.ss_debug_conv_c64(0)
+    dbg(0)
     try:
         old = run_conv_gemm(lib, x, conv_tap_major(w), b, M, C, C, **kw)
     finally:
-        lib.ss_debug_conv_c64(1)
-    assert _class_launches_ops(lib, "conv_c64<256,64>") == n0 + 1
+        dbg(1)
+    assert _class_launches_ops(lib, cls) == n0 + 1
     assert (got - old).abs().max() < 2e-5
 
 

@@ -11,7 +11,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from streamspeech_amd import lib as L          # noqa: E402
 
-CH = 64
+CH = int(os.environ.get("C64_BENCH_CHANNELS", "64"))      # 64 (conv_c64.hip) or 32 (conv_c32.hip)
 
 
 def P(t):
@@ -19,8 +19,9 @@ def P(t):
 
 
 def main():
-    M = int(sys.argv[1]) if len(sys.argv) > 1 else 576000
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else (576000 if CH == 64 else 1152000)
     lib = L.load()
+    dbg = lib.ss_debug_conv_c64 if CH == 64 else lib.ss_debug_conv_c32
     g = torch.Generator(device="cuda").manual_seed(0)
     rn = lambda *s, sc=1.0: torch.randn(*s, device="cuda", generator=g) * sc     # noqa: E731
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -38,7 +39,7 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) * 1e3 / reps
 
-    print(f"{M} rows x 64 channels; conv1 = dilated conv of lrelu(x) + bias; conv2 = conv of lrelu(h) + bias + residual")
+    print(f"{M} rows x {CH} channels; conv1 = dilated conv of lrelu(x) + bias; conv2 = conv of lrelu(h) + bias + residual")
     print("taps dil | conv1: stream-K (pre-activated in, LRELU epilogue) | slab | conv2: stream-K (+ twin out) | slab   [us (TF/s)]")
     for taps in (3, 7, 11):
         for dil in (1, 5):
@@ -48,7 +49,7 @@ def main():
             cols = []
             for conv2 in (False, True):
                 for slab in (False, True):
-                    lib.ss_debug_conv_c64(1 if slab else 0)
+                    dbg(1 if slab else 0)
                     # stream-K form: input already activated by the producer (in_act 0), conv1 applies the LRELU epilogue; the slab
                     # form reads raw rows (in_act 3) and writes raw rows
                     in_act = 3 if slab else 0
@@ -63,7 +64,7 @@ def main():
                     t = timed(run)
                     cols.append(f"{t:7.1f} ({fl / t * 1e-6:5.1f})")
             print(f"{taps:4d} {dil:3d} | " + " | ".join(cols), flush=True)
-    lib.ss_debug_conv_c64(1)
+    dbg(1)
     print("(the stream-K conv2 of the pipeline additionally writes the pre-activated twin of its output: +1 tensor pass not timed here)")
 
 

@@ -9,8 +9,14 @@ import sys
 # profiler class (bench.py process_census key) -> kernel-name prefixes of the profile
 CLASSES = [("conv_sk2<256,128,32>", ["void ss::conv_sk2_kernel"]),
            ("conv_sk<128,BN,32>", ["void ss::conv_sk_kernel"]),
-           ("conv_slab<32>", ["void ss::conv_slab_kernel<32", "void ss::conv_pair_kernel<32", "void ss::resblock_fused_kernel<32"]),
-           ("conv_slab<16>", ["void ss::conv_slab_kernel<16", "void ss::conv_pair_kernel<16", "void ss::resblock_fused_kernel<16"]),
+           ("conv_c64<256,64>", ["void ss::conv_c64_kernel"]),
+           ("conv_c32<256,32>", ["void ss::conv_c32_kernel"]),
+           ("resblock_fused<32>", ["void ss::resblock_fused_kernel<32"]),
+           ("resblock_fused<16>", ["void ss::resblock_fused_kernel<16"]),
+           ("conv_slab<32>", ["void ss::conv_slab_kernel<32", "void ss::conv_pair_kernel<32"]),
+           ("conv_slab<16>", ["void ss::conv_slab_kernel<16", "void ss::conv_pair_kernel<16"]),
+           ("ffn_fused<256,2048>", ["void ss::ffn_fused_kernel"]),
+           ("rt_linear<48,256>", ["void ss::rt_linear_kernel"]),
            ("conv_gemm<32,64,32,2,2>", ["void ss::conv_gemm_kernel<32, 64, 32"]),
            ("conv_gemm<32,32,32,2,2>", ["void ss::conv_gemm_kernel<32, 32, 32"]),
            ("conv_gemm<32,64,16,2,2>", ["void ss::conv_gemm_kernel<32, 64, 16"]),
