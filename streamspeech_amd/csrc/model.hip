@@ -71,6 +71,7 @@ static int mt_persistent_env() {
   return (v == 64 || v == 128 || v == 256) ? v : 0;       // anything else: the launch-per-op form
 }
 static const int g_mt_persistent_default = mt_persistent_env();   // default of ss_mt_set_persistent for new contexts (0: launch-per-op decode step)
+static const int g_no_mt_device_loop = getenv("SS_NO_MT_DEVICE_LOOP") ? atoi(getenv("SS_NO_MT_DEVICE_LOOP")) : 0;   // A/B knob: one persistent launch per TOKEN (round 3) instead of one per search
 static const int g_no_mt_ln_fusion = getenv("SS_NO_MT_LN_FUSION") ? atoi(getenv("SS_NO_MT_LN_FUSION")) : 0;   // A/B knob: separate final LayerNorm launch in the MT decode step
 
 int linear(hipStream_t s, const float* A, int lda, int M, const Lin& l, int N, int K, float* C, int ldc,
@@ -686,6 +687,54 @@ extern "C" int ss_mt_truncate(ss_model* m, int len) {
   return SS_OK;
 }
 
+// Argument block of the persistent decode kernel (mt_step.hip) for context `m`: weights, caches, granules, error word.
+static int mt_step_args(ss_model* m, MtStepArgs& a, float* scratch_feats) {
+  const ss_config& c = m->cfg;
+  const int D = c.dec_dim;
+  for (int l = 0; l < MT_L; ++l) {
+    const DecLayer& L = m->mt[l];
+    if (!L.has_cross) return SS_ERR_ARG;
+    MtLayerW& w = a.L[l];
+    w.ln1_g = L.self_ln.g; w.ln1_b = L.self_ln.b; w.wqkv = L.self_qkv.w; w.bqkv = L.self_qkv.b; w.wo = L.self_out.w; w.bo = L.self_out.b;
+    w.ln2_g = L.cross_ln.g; w.ln2_b = L.cross_ln.b; w.wcq = L.cross_q.w; w.bcq = L.cross_q.b; w.wco = L.cross_out.w; w.bco = L.cross_out.b;
+    w.ln3_g = L.ffn_ln.g; w.ln3_b = L.ffn_ln.b; w.w1 = L.fc1.w; w.b1 = L.fc1.b; w.w2 = L.fc2.w; w.b2 = L.fc2.b;
+    w.selfbuf = m->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
+    w.cross = m->mt_cross.f() + (size_t)l * m->mt_Tp * 2 * D;
+  }
+  a.lnf_g = m->mt_ln.g; a.lnf_b = m->mt_ln.b; a.emb = m->mt_emb; a.pos_table = m->mt_pos;
+  a.feats = scratch_feats;
+  a.gran = reinterpret_cast<mt_u64*>(m->mt_gran.p); a.err = mt_err_word(m);
+  a.Tp = m->mt_Tp; a.V = c.tgt_vocab; a.pad = c.pad; a.eos = c.eos;
+  a.emb_scale = sqrtf((float)D);
+  return SS_OK;
+}
+// n consecutive epochs for a launch of n steps (0 is what a fresh granule holds: skipped)
+static unsigned mt_next_epochs(ss_model* m, int n) {
+  if (m->mt_epoch + (unsigned)n + 1u < m->mt_epoch || m->mt_epoch == 0u) m->mt_epoch = 0u;      // wrap: start over above 0
+  const unsigned first = m->mt_epoch + 1u;
+  m->mt_epoch += (unsigned)n;
+  return first;
+}
+static int mt_inject(ss_model* m, MtStepArgs& a, hipStream_t s) {      // test hook: this one launch sees a time-out that already happened
+  if (!m->mt_inject_timeout) return SS_OK;
+  m->mt_inject_timeout = 0;
+  a.err = reinterpret_cast<unsigned*>(static_cast<char*>(m->mt_gran.p) + mt_step_granule_bytes());
+  SS_HIP_CHECK(hipMemsetAsync(a.err, 0x01, sizeof(unsigned), s));
+  return SS_OK;
+}
+static bool mt_persistent_ok(const ss_model* m) {
+  const ss_config& c = m->cfg;
+  return m->mt_persistent > 0 && c.mt_layers == MT_L && c.dec_dim == MT_D && c.dec_ffn == MT_F && c.dec_heads == MT_H;
+}
+static int mt_gran_ensure(ss_model* m, hipStream_t s) {
+  if (!m->mt_gran.p) {
+    RET(m->mt_gran.ensure(mt_step_granule_bytes() + 64));   // + one spare error word (ss_debug_mt_inject_timeout) + the step's own
+    SS_HIP_CHECK(hipMemsetAsync(m->mt_gran.p, 0, mt_step_granule_bytes() + 64, s));
+    SS_HIP_CHECK(hipStreamSynchronize(s));
+  }
+  return SS_OK;
+}
+
 extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, int n, int pos0, int ban_eos,
                             int force_eos, float* d_feats, int32_t* d_next, int n_tail_pad) {
   if (!m || n <= 0 || pos0 < 0 || pos0 > m->mt_len || m->mt_Tp <= 0) return SS_ERR_ARG;
@@ -701,37 +750,17 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
   float* feats = q2 + (size_t)n * D;
   float* ff = feats + (size_t)n * D;
   float* logits = ff + (size_t)n * F;
-  if (m->mt_persistent > 0 && n == 1 && d_next && n_tail_pad == 0 && c.mt_layers == MT_L && D == MT_D && F == MT_F &&
-      c.dec_heads == MT_H) {
+  if (mt_persistent_ok(m) && n == 1 && d_next && n_tail_pad == 0) {
     // one persistent launch for the whole step (mt_step.hip; opt-in)
-    if (!m->mt_gran.p) {
-      RET(m->mt_gran.ensure(mt_step_granule_bytes() + 64));   // + one spare error word (ss_debug_mt_inject_timeout)
-      SS_HIP_CHECK(hipMemsetAsync(m->mt_gran.p, 0, mt_step_granule_bytes() + 64, s));
-      SS_HIP_CHECK(hipStreamSynchronize(s));
-    }
+    RET(mt_gran_ensure(m, s));
     MtStepArgs a;
-    for (int l = 0; l < MT_L; ++l) {
-      const DecLayer& L = m->mt[l];
-      if (!L.has_cross) return SS_ERR_ARG;
-      MtLayerW& w = a.L[l];
-      w.ln1_g = L.self_ln.g; w.ln1_b = L.self_ln.b; w.wqkv = L.self_qkv.w; w.bqkv = L.self_qkv.b; w.wo = L.self_out.w; w.bo = L.self_out.b;
-      w.ln2_g = L.cross_ln.g; w.ln2_b = L.cross_ln.b; w.wcq = L.cross_q.w; w.bcq = L.cross_q.b; w.wco = L.cross_out.w; w.bco = L.cross_out.b;
-      w.ln3_g = L.ffn_ln.g; w.ln3_b = L.ffn_ln.b; w.w1 = L.fc1.w; w.b1 = L.fc1.b; w.w2 = L.fc2.w; w.b2 = L.fc2.b;
-      w.selfbuf = m->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
-      w.cross = m->mt_cross.f() + (size_t)l * m->mt_Tp * 2 * D;
-    }
-    a.lnf_g = m->mt_ln.g; a.lnf_b = m->mt_ln.b; a.emb = m->mt_emb; a.pos_table = m->mt_pos;
+    RET(mt_step_args(m, a, feats));
     a.tok = d_tokens; a.feats = d_feats ? d_feats : feats; a.next = d_next;
-    a.gran = reinterpret_cast<mt_u64*>(m->mt_gran.p); a.err = mt_err_word(m);
-    if (m->mt_inject_timeout) {                            // test hook: this one launch sees a time-out that already happened
-      m->mt_inject_timeout = 0;
-      a.err = reinterpret_cast<unsigned*>(static_cast<char*>(m->mt_gran.p) + mt_step_granule_bytes());
-      SS_HIP_CHECK(hipMemsetAsync(a.err, 0x01, sizeof(unsigned), s));
-    }
-    if (++m->mt_epoch == 0) ++m->mt_epoch;
-    a.epoch = m->mt_epoch;
-    a.Tp = m->mt_Tp; a.pos0 = pos0; a.V = V; a.pad = c.pad; a.eos = c.eos; a.ban_eos = ban_eos; a.force_eos = force_eos;
-    a.emb_scale = sqrtf((float)D);
+    a.pos0 = pos0; a.n_steps = 1;
+    a.min_len = ban_eos ? pos0 + 1 : 0;                   // </s> banned at positions < min_len, forced at positions >= max_len
+    a.max_len = force_eos ? pos0 : 0x7fffffff;
+    RET(mt_inject(m, a, s));
+    a.epoch = mt_next_epochs(m, 1);
     RET(launch_mt_step(a, m->mt_persistent, s));
     m->mt_len = pos0 + n;
     return SS_OK;
@@ -784,6 +813,47 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
   for (int i = 0; i < n_prefix; ++i) host[1 + i] = h_prefix[i];
   const int start = n_prefix;
   SS_HIP_CHECK(hipMemcpyAsync(tok, host, (size_t)(start + 1) * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  if (mt_persistent_ok(m) && !g_no_mt_device_loop) {
+    // ---- the whole search as ONE persistent launch (device-side token loop, mt_step.hip): positions `first` .. max_len, the loop
+    // ends at </s>; with a prefix its tokens are fed first in one launch-per-op pass ----
+    int first = 0;
+    if (start > 0) {
+      RET(ss_mt_append(m, stream, tok, start + 1, 0, start < min_len, start >= max_len, d_feats, tok + start + 1, 0));
+      first = start + 1;
+    }
+    const int n_steps = max_len + 1 - first;
+    if (n_steps > 0) {
+      RET(mt_gran_ensure(m, s));
+      MtStepArgs a;
+      RET(mt_step_args(m, a, d_feats));
+      a.tok = tok + first; a.feats = d_feats + (size_t)first * D; a.next = tok + first + 1;
+      a.pos0 = first; a.n_steps = n_steps; a.min_len = min_len; a.max_len = max_len;
+      RET(mt_inject(m, a, s));
+      a.epoch = mt_next_epochs(m, n_steps);
+      RET(launch_mt_step(a, m->mt_persistent, s));
+    }
+    const int lo = start + 1, hi = max_len + 1;             // generated tokens live at chain indices lo .. hi
+    SS_HIP_CHECK(hipMemcpyAsync(host + lo, tok + lo, (size_t)(hi - lo + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+    SS_HIP_CHECK(hipStreamSynchronize(s));
+    int eos_at = -1;
+    for (int i = lo; i <= hi && eos_at < 0; ++i) {
+      if (host[i] < 0) {                                    // a bounded wait of the persistent kernel timed out
+        fprintf(stderr, "streamspeech_hip: persistent MT decode step timed out (its %d workgroups were not all resident); "
+                        "this context falls back to one launch per op\n", m->mt_persistent);
+        RET(mt_collect_errors(m));
+        m->mt_persistent = 0;
+        return ss_mt_greedy(m, stream, d_enc_out, Tp, h_prefix, n_prefix, max_len, min_len, h_out_tokens, h_n_out, d_feats, h_n_feats);
+      }
+      if (host[i] == c.eos) eos_at = i;
+    }
+    const int end = eos_at >= 0 ? eos_at : hi;              // (position max_len forces </s>: eos_at is always found)
+    const int n_out = end - start;
+    for (int i = 0; i < n_out; ++i) h_out_tokens[i] = host[start + 1 + i];
+    *h_n_out = n_out;
+    if (h_n_feats) *h_n_feats = end;
+    m->mt_len = end;
+    return SS_OK;
+  }
   // step `start`: feed [eos, prefix...] in one pass
   RET(ss_mt_append(m, stream, tok, start + 1, 0, start < min_len, start >= max_len, d_feats, tok + start + 1, 0));
   int step = start + 1;      // next position to feed == index of the newest generated token

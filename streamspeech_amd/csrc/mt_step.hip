@@ -30,6 +30,7 @@
 namespace ss {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 #define MT_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 namespace {
@@ -147,14 +148,24 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int G = gridDim.x, wg = blockIdx.x, nw = G * 4, gw = wg * 4 + wave;
-  const unsigned epoch = p.epoch;
   unsigned* err = p.err;
+  __shared__ int s_tok;
+  // Device-side token loop (round 4): one launch runs up to n_steps decode steps -- the token a step decides is the next step's
+  // input, every workgroup works it out for itself from the exchanged arg-max candidates (no hop through workgroup 0, no host in
+  // between) and the loop ends for all of them at </s>.  Step `it` uses epoch p.epoch + it; a phase's granules are reused every step:
+  // a workgroup can only overwrite them after it has gathered the previous step's candidates, which every other workgroup publishes
+  // after its last read of that step -- the all-to-all exchanges are the barrier.
+  int tk = p.tok[0];
+#pragma unroll 1
+  for (int it = 0; it < p.n_steps; ++it) {
+  const unsigned epoch = p.epoch + (unsigned)it;
+  const int pos0 = p.pos0 + it;
+  const bool ban_eos = pos0 < p.min_len, force_eos = pos0 >= p.max_len;
 
   // ---- embedding: x0 = sqrt(D) E[tok] + sinusoid(position); a <pad> token takes position padding_idx (make_positions) ----
   {
-    int tk = p.tok[0];
     if ((unsigned)tk >= (unsigned)p.V) tk = p.eos;         // the chained token of a step that timed out (phase J: -1): stay in range
-    const int pos = (tk == p.pad) ? p.pad : p.pos0 + p.pad + 1;
+    const int pos = (tk == p.pad) ? p.pad : pos0 + p.pad + 1;
     xbuf[t] = p.emb_scale * p.emb[(size_t)tk * MT_D + t] + p.pos_table[(size_t)pos * MT_D + t];
     xbuf[t + 256] = p.emb_scale * p.emb[(size_t)tk * MT_D + t + 256] + p.pos_table[(size_t)pos * MT_D + t + 256];
   }
@@ -177,7 +188,8 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
       if (lane < 8 && col < 3 * MT_D) {
         const float v = s + Lw.bqkv[col];
         mt_publish(gl + MG_QKV + col, epoch, v);
-        Lw.selfbuf[(size_t)p.pos0 * 3 * MT_D + col] = v;   // cache row of this position (read by later launches)
+        // cache row of this position: read by later launches AND by later steps of this one (other CUs): write-through store
+        __hip_atomic_store(Lw.selfbuf + (size_t)pos0 * 3 * MT_D + col, v, MT_RLX);
       }
     }
     // ================= B: causal self-attention over the cache rows 0 .. pos0-1 and the new key =================
@@ -185,7 +197,7 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
     mt_gather(gl + MG_QKV, 3 * MT_D, vec, epoch, err, t, lane);
     if (wg < MT_H) {
       const int h = wg, hoff = h * MT_DH;
-      const int kmax = p.pos0 + 1;
+      const int kmax = pos0 + 1;
       const float* q = vec + hoff;                         // LDS
       const float* Kc = Lw.selfbuf + MT_D + hoff;          // rows j < pos0 (written by earlier launches)
       const float* Vc = Lw.selfbuf + 2 * MT_D + hoff;
@@ -197,17 +209,18 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
 #pragma unroll
         for (int u = 0; u < 64; ++u) {
           const int jj = min(j0 + u, kmax - 1);
-          vv[u] = jj < p.pos0 ? Vc[(size_t)jj * 3 * MT_D + lane] : vec[2 * MT_D + hoff + lane];
+          vv[u] = jj < pos0 ? __hip_atomic_load(Vc + (size_t)jj * 3 * MT_D + lane, MT_RLX) : vec[2 * MT_D + hoff + lane];   // (L1-bypassing: rows of earlier steps of this launch)
         }
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (vis) {
-          if (j < p.pos0) {
-            const float4* kr = reinterpret_cast<const float4*>(Kc + (size_t)j * 3 * MT_D);
+          if (j < pos0) {
+            const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(Kc + (size_t)j * 3 * MT_D), 0, MT_DH * 4, 0x00020000);
 #pragma unroll
             for (int d4 = 0; d4 < MT_DH / 4; ++d4) {
-              const float4 kv = kr[d4];
-              s0 = fmaf(q[4 * d4 + 0], kv.x, s0); s1 = fmaf(q[4 * d4 + 1], kv.y, s1);
-              s2 = fmaf(q[4 * d4 + 2], kv.z, s2); s3 = fmaf(q[4 * d4 + 3], kv.w, s3);
+              const u32x4 kb = __builtin_amdgcn_raw_buffer_load_b128(rsK, d4 * 16, 0, 16);      // sc1: the row may come from an earlier step of this launch
+              const float kx = __uint_as_float(kb[0]), ky = __uint_as_float(kb[1]), kz = __uint_as_float(kb[2]), kw = __uint_as_float(kb[3]);
+              s0 = fmaf(q[4 * d4 + 0], kx, s0); s1 = fmaf(q[4 * d4 + 1], ky, s1);
+              s2 = fmaf(q[4 * d4 + 2], kz, s2); s3 = fmaf(q[4 * d4 + 3], kw, s3);
             }
           } else {
             const float* kn = vec + MT_D + hoff;
@@ -382,7 +395,7 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
   mt_fetch512(wr, p.emb, p.V, gw, nw, lane, 0);
   mt_gather(p.gran + (size_t)(MT_L - 1) * MG_LAYER + MG_X, MT_D, xbuf, epoch, err, t, lane);
   mt_layernorm(xbuf, p.lnf_g, p.lnf_b, ybuf, red, t, lane, wave);
-  if (wg == 0) { p.feats[t] = ybuf[t]; p.feats[t + 256] = ybuf[t + 256]; }
+  if (wg == 0) { p.feats[(size_t)it * MT_D + t] = ybuf[t]; p.feats[(size_t)it * MT_D + t + 256] = ybuf[t + 256]; }
   float bv = -INFINITY;
   int bi = 0x7fffffff;
   {
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
       float s = mt_dot512(wr, ybuf, lane);
       if (s != s) s = -INFINITY;                           // NaN -> -inf, still a candidate (as masked_argmax_kernel)
       const int col = gw + (ch * 8 + lane) * nw;
-      if (lane < 8 && col < p.V && col != p.pad && !(p.ban_eos && col == p.eos)) {
+      if (lane < 8 && col < p.V && col != p.pad && !(ban_eos && col == p.eos)) {
         if (bi == 0x7fffffff || s > bv) { bv = s; bi = col; }      // this lane's columns ascend: first maximum wins
       }
     }
@@ -413,8 +426,8 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
       __hip_atomic_store(p.gran + MG_ARG + 2 * wg + 1, ((mt_u64)epoch << 32) | (unsigned)bi, MT_RLX);
     }
   }
-  // ================= J: workgroup 0 picks the winner =================
-  if (wg == 0) {
+  // ================= J: every workgroup picks the winner (workgroup 0 records it) =================
+  {
     mt_gather(p.gran + MG_ARG, 2 * G, vec, epoch, err, t, lane);
     if (t == 0) {
       float fv = -INFINITY; int fi = 0x7fffffff;
@@ -423,11 +436,18 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
         if (oi != 0x7fffffff && (fi == 0x7fffffff || ov > fv || (ov == fv && oi < fi))) { fv = ov; fi = oi; }
       }
       // a bounded wait timed out somewhere in this launch (or an earlier one of this context): the token is not trustworthy.
-      // -1 tells the host, which reads the chain back anyway, to redo the step with the launch-per-op form (model.hip).
+      // -1 tells the host, which reads the chain back anyway, to redo the search with the launch-per-op form (model.hip).
       // The same when no column qualified (all logits NaN): the launch-per-op form then decides what such a step returns.
-      p.next[0] = (__hip_atomic_load(err, MT_RLX) != 0u || fi == 0x7fffffff) ? -1 : (p.force_eos ? p.eos : fi);
+      const int nx = (__hip_atomic_load(err, MT_RLX) != 0u || fi == 0x7fffffff) ? -1 : (force_eos ? p.eos : fi);
+      if (wg == 0) p.next[it] = nx;
+      s_tok = nx;
     }
+    __syncthreads();
+    tk = s_tok;
+    __syncthreads();
   }
+  if (tk < 0 || tk == p.eos) break;              // the search is over (</s>), or broken (time-out): same decision in every workgroup
+  }   // token loop
 #endif
 }
 

@@ -30,18 +30,20 @@ struct MtLayerW {
 struct MtStepArgs {
   MtLayerW L[MT_L];
   const float *lnf_g, *lnf_b, *emb, *pos_table;
-  const int* tok;          // the token fed at this position (device; written by the previous step)
-  float* feats;            // [512] out: LN_f(x), the decoder state of this position
-  int* next;               // out: the next token
+  const int* tok;          // the token fed at position pos0 (device; written by the previous step / launch)
+  float* feats;            // [n_steps][512] out: LN_f(x), the decoder state of every fed position
+  int* next;               // [n_steps] out: the token decided at position pos0 + it (-1: a bounded wait timed out)
   mt_u64* gran;
   unsigned* err;
   unsigned epoch;
-  int Tp, pos0, V, pad, eos, ban_eos, force_eos;
+  int Tp, pos0, V, pad, eos;
+  int n_steps;             // decode steps of this launch (the loop ends early at </s>)
+  int min_len, max_len;    // </s> is banned at positions < min_len and forced at positions >= max_len
   float emb_scale;
 };
 
 
-// One decode step on G resident workgroups (64, 128 or 256); the step's outputs are a.feats and a.next.
+// Up to a.n_steps decode steps on G resident workgroups (64, 128 or 256); outputs a.feats rows and a.next tokens.
 int launch_mt_step(const MtStepArgs& a, int G, hipStream_t stream);
 
 }  // namespace ss
