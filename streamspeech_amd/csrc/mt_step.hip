@@ -214,10 +214,13 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         if (vis) {
           if (j < pos0) {
-            const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)(Kc + (size_t)j * 3 * MT_D), 0, MT_DH * 4, 0x00020000);
+            // (ONE wave-uniform resource over the cache, the key row in the per-lane offset: a per-lane base pointer in the resource
+            //  would make every load a 64-trip waterfall loop)
+            const __amdgpu_buffer_rsrc_t rsK = __builtin_amdgcn_make_buffer_rsrc((void*)Kc, 0, 0x7ffffff0, 0x00020000);
+            const int kofs = j * 3 * MT_D * 4;
 #pragma unroll
             for (int d4 = 0; d4 < MT_DH / 4; ++d4) {
-              const u32x4 kb = __builtin_amdgcn_raw_buffer_load_b128(rsK, d4 * 16, 0, 16);      // sc1: the row may come from an earlier step of this launch
+              const u32x4 kb = __builtin_amdgcn_raw_buffer_load_b128(rsK, kofs + d4 * 16, 0, 16);      // sc1: the row may come from an earlier step of this launch
               const float kx = __uint_as_float(kb[0]), ky = __uint_as_float(kb[1]), kz = __uint_as_float(kb[2]), kw = __uint_as_float(kb[3]);
               s0 = fmaf(q[4 * d4 + 0], kx, s0); s1 = fmaf(q[4 * d4 + 1], ky, s1);
               s2 = fmaf(q[4 * d4 + 2], kz, s2); s3 = fmaf(q[4 * d4 + 3], kw, s3);
