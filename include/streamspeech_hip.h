@@ -258,6 +258,7 @@ int ss_debug_rtlin(int grid, int enable);
 int ss_debug_conv_c64(int enable);
 /* The same for the 32-channel stage (csrc/conv_c32.hip): 0 = one fused launch per ResBlock (round 3), 1 = one launch per conv. */
 int ss_debug_conv_c32(int enable);
+int ss_debug_conv_c16(int enable);       /* ... and for the 16-channel stage (csrc/conv_c16.hip) */
 /* Unit-test entry of the LayerNorm-prologue linears (what ln_linear() in model.hip issues for QKV / pointwise conv 1 / the FFNs
  * of one utterance): dC = epi(LayerNorm(dX; ln_g, ln_b, eps 1e-5) . dW^T + dbias), epi as ss_op_conv_gemm (act, alpha, + dR, glu).
  * Served by the small-M kernel (<= 192 rows) or the row-tile kernel (K = 256, more rows); SS_ERR_ARG otherwise. */

@@ -60,7 +60,7 @@ struct GemmArgs {
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 26;
+constexpr int kNumTileCfg = 27;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
@@ -143,6 +143,12 @@ bool conv_c32_eligible(const GemmArgs& a);
 bool conv_c32_enabled();
 int launch_conv_c32(const GemmArgs& a, hipStream_t stream);
 void conv_c32_debug(int enable);
+
+// ... and for the 16-channel stage (conv_c16.hip): the whole 16 x 16k weight matrix in registers.
+bool conv_c16_eligible(const GemmArgs& a);
+bool conv_c16_enabled();
+int launch_conv_c16(const GemmArgs& a, hipStream_t stream);
+void conv_c16_debug(int enable);
 
 // Row-tile linear layer for K = 256 projections of packed batches (rtlin.hip): the row tile (LayerNorm-ed when a.ln_g is set) in
 // LDS, weight fragments straight from L2 to registers, bias / activation / alpha / residual or GLU epilogue per 16-column unit.

@@ -1029,16 +1029,16 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
   // that kernel applies the activation once per element while it stages its input slab, so no twin tensor is written or read.
   // The 32-channel stage of a packed batch runs its convs one by one on conv_c32.hip instead of one fused launch per ResBlock.
   auto slab_stage = [&](int channels) {
-    if (v->x3 || !(channels == 64 ? conv_c64_enabled() : channels == 32 ? conv_c32_enabled() : false)) return false;
+    if (v->x3 || !(channels == 64 ? conv_c64_enabled() : channels == 32 ? conv_c32_enabled() : channels == 16 ? conv_c16_enabled() : false)) return false;
     long long rows = Ft; int ch = c.upsample_initial_channel; bool found = false;
     for (int i = 0; i < c.n_up && !found; ++i) { rows *= c.upsample_rates[i]; ch /= 2; found = ch == channels; }
     if (!found || rows >= (1ll << 30)) return false;
     GemmArgs probe;
     probe.same_rows = 1; probe.Cin = probe.N = probe.lda = probe.ldc = channels; probe.taps = 3; probe.dil = 1; probe.pad = 1;
     probe.M = probe.in_len = (int)rows; probe.in_act = ACT_LRELU;
-    return channels == 64 ? conv_c64_eligible(probe) : conv_c32_eligible(probe);
+    return channels == 64 ? conv_c64_eligible(probe) : channels == 32 ? conv_c32_eligible(probe) : conv_c16_eligible(probe);
   };
-  const bool c64 = slab_stage(64), c32 = slab_stage(32);
+  const bool c64 = slab_stage(64), c32 = slab_stage(32), c16 = slab_stage(16);
   auto preact = [c64](int channels) { return channels >= 64 && !(c64 && channels == 64); };
   auto mk = [v](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
     GemmArgs a;
@@ -1081,7 +1081,10 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
       // conv_c32.hip: at k = 11 (MFMA-bound) six separate convs beat the fused ResBlock launch -- no halo recompute: 107 vs 86
       // TFLOP/s in the pipeline; at k = 3 / 7 the fused launch wins (92-98 vs 56-93: the separate convs are HBM-bound there)
       static const int c32_min_k = getenv("SS_CONV_C32_MIN_K") ? atoi(getenv("SS_CONV_C32_MIN_K")) : 11;
-      const bool per_conv = c32 && C == 32 && kr >= c32_min_k;
+      // conv_c16.hip: the same split at 16 channels (weight matrix in registers): +0.5 %; the round-1 slab kernel (weights in LDS) conv by
+      // conv measures -0.3 % against the fused launch, profiles/r04_c16_bench.txt + tools/jobs/r04_o.sh / r04_p.sh
+      static const int c16_min_k = getenv("SS_CONV_C16_MIN_K") ? atoi(getenv("SS_CONV_C16_MIN_K")) : 11;
+      const bool per_conv = (c32 && C == 32 && kr >= c32_min_k) || (c16 && C == 16 && kr >= c16_min_k);
       if (!pa && !per_conv && !g_no_resblock_fusion && resblock_fused_eligible(C, kr, c.resblock_dilations[j], C, C, gnseg, gM)) {
         const float *W1[3], *B1[3], *W2[3], *B2[3];
         for (int dd = 0; dd < 3; ++dd) {
@@ -1682,6 +1685,7 @@ extern "C" int ss_op_ln_linear(void* stream, const float* dX, int ldx, const flo
 }
 extern "C" int ss_debug_conv_c64(int enable) { conv_c64_debug(enable); return SS_OK; }
 extern "C" int ss_debug_conv_c32(int enable) { conv_c32_debug(enable); return SS_OK; }
+extern "C" int ss_debug_conv_c16(int enable) { conv_c16_debug(enable); return SS_OK; }
 extern "C" int ss_debug_rtlin(int grid, int enable) {
   if (grid < 0) return SS_ERR_ARG;
   rtlin_debug(grid, enable);

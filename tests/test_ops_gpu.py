@@ -450,7 +450,7 @@ def test_stream_k_fixup_never_reads_stale_partials(lib):
     assert (first[0].cpu() - ref).abs().max() < TOL
 
 
-@pytest.mark.parametrize("C_", [64, 32])
+@pytest.mark.parametrize("C_", [64, 32, 16])
 @pytest.mark.parametrize("taps,dil,M,lrelu,extras", [(3, 1, 70000, True, True), (3, 5, 66000, True, False), (7, 3, 70077, True, True),
                                                       (11, 5, 66001, True, True), (11, 1, 70000, False, False), (3, 1, 65536, False, True),
                                                       (2, 1, 66000, True, False)])
@@ -460,8 +460,12 @@ def test_conv_c64_slab_kernel(lib, C_, taps, dil, M, lrelu, extras):
     and against the stream-K kernel it replaces (ss_debug_conv_c64(0)); both block heights (k = 11 at dilation 5 -> 192 rows)."""
     from streamspeech_amd.weights import conv_tap_major
     C = C_
-    cls = "conv_c64<256,64>" if C == 64 else "conv_c32<256,32>"
-    dbg = lib.ss_debug_conv_c64 if C == 64 else lib.ss_debug_conv_c32
+    if C == 16:
+        if taps == 2:
+            pytest.skip("conv_c16 keeps the weight matrix in registers: k = 3 / 7 / 11 only")
+        M = 2 * M                # its dispatch threshold is 131072 rows
+    cls = {64: "conv_c64<256,64>", 32: "conv_c32<256,32>", 16: "conv_c16<256,16>"}[C]
+    dbg = {64: lib.ss_debug_conv_c64, 32: lib.ss_debug_conv_c32, 16: lib.ss_debug_conv_c16}[C]
     x = rnd(M, C, seed=31)
     w = rnd(C, C, taps, seed=32, scale=(C * taps) ** -0.5)
     b = rnd(C, seed=33, scale=0.1)

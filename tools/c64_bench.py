@@ -19,9 +19,9 @@ def P(t):
 
 
 def main():
-    M = int(sys.argv[1]) if len(sys.argv) > 1 else (576000 if CH == 64 else 1152000)
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else {64: 576000, 32: 1152000, 16: 2304000}[CH]
     lib = L.load()
-    dbg = lib.ss_debug_conv_c64 if CH == 64 else lib.ss_debug_conv_c32
+    dbg = {64: lib.ss_debug_conv_c64, 32: lib.ss_debug_conv_c32, 16: lib.ss_debug_conv_c16}[CH]
     g = torch.Generator(device="cuda").manual_seed(0)
     rn = lambda *s, sc=1.0: torch.randn(*s, device="cuda", generator=g) * sc     # noqa: E731
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
