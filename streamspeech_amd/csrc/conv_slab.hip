@@ -201,18 +201,19 @@ bool conv_slab_eligible(const GemmArgs& a) {
          (a.in_act == ACT_NONE || a.in_act == ACT_LRELU);
 }
 
-static int slab_cus(int& cus) {           // CU count of the current device, read once (thread-safe)
-  static std::once_flag once;
-  static int n = 0;
-  static hipError_t err = hipSuccess;
-  std::call_once(once, [&] {
-    int dev = 0;
-    err = hipGetDevice(&dev);
-    if (err == hipSuccess) err = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n <= 0) n = 256;
-  });
-  SS_HIP_CHECK(err);
-  cus = n;
+static int slab_cus(int& cus) {           // CU count of the CURRENT device, read once per device (thread-safe)
+  static std::mutex mu;
+  static int n[128] = {0};
+  int dev = 0;
+  SS_HIP_CHECK(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 128) return SS_ERR_ARG;
+  std::lock_guard<std::mutex> lk(mu);
+  if (n[dev] == 0) {
+    int v = 0;
+    SS_HIP_CHECK(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+    n[dev] = v > 0 ? v : 256;
+  }
+  cus = n[dev];
   return SS_OK;
 }
 
