@@ -8,11 +8,11 @@
    --master-addr 127.0.0.1 --master-port <free>` with the same arguments, rank 0 prints the one JSON line, the exit code
    is the launcher's.  `--dry-plan` runs the plan + barrier + reductions of that path on CPU over gloo, no GPU.)
 
-A "step" is one pass of the whole HIP hot path over one ragged batch of --batch (32) synthetic
+A "step" is one pass of the whole HIP hot path over one ragged batch of --batch (64) synthetic
 utterances, each with B = 1 arithmetic (streamspeech_amd/workload.py): PCM already in HBM ->
 fbank+CMVN -> chunk-Conformer -> CTC x2 -> AR MT greedy decode -> T2U + NAR unit decoder -> CTC
-collapse -> unit HiFi-GAN -> waveform in HBM.  The default K = 32 steps is BASELINE.json's
-1024-utterance set; with --batch 1 a step is one utterance through the single-utterance entry points.
+collapse -> unit HiFi-GAN -> waveform in HBM.  The default K = 16 steps is BASELINE.json's
+1024-utterance set (rounds 1-3 packed 32 per batch; 64 measured +4 % on the same utterances, profiles/r04_batch_sweep.txt); with --batch 1 a step is one utterance through the single-utterance entry points.
 value = total audio seconds / wall seconds over all ranks (RTFx; higher is better); the line also
 carries utterances/sec, the roofline of the dominant kernel (HIP events recorded on the launch
 stream inside the timed region) and the CPU oracle timed on this box's host cores (rank 0, N=1).
@@ -505,7 +505,7 @@ def dry_plan(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32, help="timed steps per GPU (one step = one ragged batch of --batch utterances)")
+    ap.add_argument("--steps", type=int, default=16, help="timed steps per GPU (one step = one ragged batch of --batch utterances)")
     ap.add_argument("--warmup", type=int, default=3, help="untimed warm-up steps per GPU before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the optional second line (same batches, split-bf16 vocoder convs)")
@@ -519,7 +519,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8,
                     help="concurrent HIP streams per GPU (own scratch context each)")
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the single-stream latency measurement")
-    ap.add_argument("--batch", type=int, default=32,
+    ap.add_argument("--batch", type=int, default=64,
                     help="utterances packed per ragged batch (1 = the one-utterance-at-a-time entry points)")
     ap.add_argument("--mode", choices=("offline", "streaming"), default="offline",
                     help="offline: the headline metric (default, what the driver runs); streaming: BASELINE.json configs[2] -- the "

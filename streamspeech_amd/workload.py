@@ -62,7 +62,7 @@ def run_batch(model, voc, pcm_packed, utts, detail: bool = False):
     B = 1 arithmetic (streamspeech_amd/csrc/model.hip ss_batch_*) -- per element the same operands in the same exact-f32
     fmaf chains, but not always in the same ORDER: a GEMM routed to the stream-K kernels splits its k-range where the
     workgroup ranges fall, which depends on the packed row count, so a row's partial sums are associated differently in a
-    pack of 32 than alone (differences ~1e-6 relative; fixed for a given pack: runs are bit-reproducible).  Layers that
+    pack than alone (differences ~1e-6 relative; fixed for a given pack: runs are bit-reproducible).  Layers that
     feed an argmax (unit-decoder FFN / projections, encoder FFN2) are among them, so an exact tie-level flip between
     batchings is possible in principle; tests/test_bench_config_gpu.py and tests/test_multilingual_gpu.py hold the ids of
     192 packed utterances identical to the B = 1 oracle.  With detail=True every intermediate the

@@ -1,5 +1,6 @@
-"""how close to an arg-max flip does the packed-batch path run?  The same 32 utterances go once through the
-single-utterance entry points and once through the ragged pack of 32 the bench times (workload.run_batch's calls).  A GEMM routed
+"""how close to an arg-max flip does the packed-batch path run?  The same 32 / 64 utterances go once through the
+single-utterance entry points and once through the ragged pack the bench times (workload.run_batch's calls; 64 per pack is the
+bench default since round 4, 32 was rounds 1-3).  A GEMM routed
 to a stream-K kernel (conv_sk2, the fused FFN) associates a row's partial sums differently in a pack than alone, so logits differ
 at the 1e-6 level; an id can only flip where the top-1 / top-2 margin is smaller than that difference.  Per arg-max stage (ASR CTC,
 ST CTC, MT greedy, unit CTC) the test holds the ids identical, measures the maximum packed-vs-single logit difference and the
@@ -33,12 +34,13 @@ def _stage(name, single, packed, masked, report):
     assert not bool(risk.any()), f"{name}: {int(risk.sum())} rows have a margin below twice the packed-vs-single difference: {report[name]}"
 
 
-def test_pack_of_32_vs_single_utterance_argmax_margins(hip_model, synth_weights):
+@pytest.mark.parametrize("pack", [32, 64])
+def test_pack_vs_single_utterance_argmax_margins(hip_model, synth_weights, pack):
     from streamspeech_amd import synth, workload
     from streamspeech_amd.pipeline import mt_greedy
     cfg, vcfg, sd, vsd = synth_weights
     m = hip_model
-    utts = sorted(workload.make_utterances(96), key=lambda u: -u.seconds)[32:64]       # a middle-of-the-distribution bucket of the bench plan
+    utts = sorted(workload.make_utterances(3 * pack), key=lambda u: -u.seconds)[pack:2 * pack]   # a middle-of-the-distribution bucket of the bench plan
     pcms = [torch.from_numpy(synth.synth_pcm(1234 + u.idx, u.n_samples)).cuda() for u in utts]
     emb = torch.from_numpy(np.asarray(sd["target_unigram_decoder.embed_tokens.weight"])).double()
 
@@ -54,7 +56,7 @@ def test_pack_of_32_vs_single_utterance_argmax_margins(hip_model, synth_weights)
         s_mt.append(feats[: u.n_mt + 1].cpu())
         s_unit.append(m.t2u_units(feats[: u.n_mt + 1], want_logits=True)[2].cpu())
 
-    # ---- the ragged pack of 32 (the calls of workload.run_batch) ----
+    # ---- the ragged pack (the calls of workload.run_batch) ----
     feat, T = m.batch_fbank_cmvn(torch.cat(pcms), [u.n_samples for u in utts])
     enc, Tp = m.batch_encoder_forward(feat, T)
     m.batch_ctc_greedy(0, enc, Tp)
@@ -76,4 +78,4 @@ def test_pack_of_32_vs_single_utterance_argmax_margins(hip_model, synth_weights)
     lm_s = (torch.cat(s_mt).double() @ emb.T)[keep]
     lm_p = (p_mt.double() @ emb.T)[keep]
     _stage("mt_greedy", lm_s.float(), lm_p.float(), [cfg.pad, cfg.eos], report)
-    print("packed-vs-single arg-max margins:", report)
+    print(f"packed-vs-single arg-max margins (pack of {pack}):", report)
