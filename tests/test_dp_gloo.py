@@ -102,15 +102,15 @@ def test_bench_gpus_2_as_typed_self_launches_its_ranks():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["self_launched"] and out["dry_plan"]
-    assert [p["rank"] for p in out["per_rank"]] == [0, 1] and all(p["utterances"] == 4 * 32 for p in out["per_rank"])
+    assert [p["rank"] for p in out["per_rank"]] == [0, 1] and all(p["utterances"] == 4 * 64 for p in out["per_rank"])
     assert out["stand_in_wall_max_s"] == 1.001                    # MAX over ranks picked rank 1's
-    assert out["planned_utterances"] == 256 and out["comm"]["results_ok"] and out["comm"]["world"] == 2
+    assert out["planned_utterances"] == 512 and out["comm"]["results_ok"] and out["comm"]["world"] == 2
     # strong scaling: the one fixed set splits over the ranks
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--dry-plan", "--scaling", "strong"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
-    assert out["planned_utterances"] == 128 and out["steps_per_gpu"] == 2
+    assert out["planned_utterances"] == 256 and out["steps_per_gpu"] == 2
 
 
 def test_bench_failing_rank_gives_nonzero_exit():
