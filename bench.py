@@ -340,7 +340,7 @@ def long_prefix_sweep(model, voc, cfg, segment_ms, seconds):
 def streaming_mode(args, model, voc, lib, cfg, sd, vsd, vcfg):
     out = streaming_measure(model, voc, lib, cfg, args.segment_ms, args.utterances,
                             cpu_sd=None if args.no_cpu_baseline else (sd, vsd, vcfg), cpu_utts=4, long_seconds=(15, 30))
-    print(json.dumps(out), flush=True)
+    _emit(out)
 
 
 def _pmc_file():
@@ -351,6 +351,29 @@ def _pmc_file():
 
 
 PMC_FILE = _pmc_file()
+
+
+_REAL_STDOUT = None
+
+
+def _claim_stdout():
+    """The bench line is the ONLY thing this command may put on stdout.  Libraries underneath print there from C / C++ (RCCL's
+    version banner sits in the C stdio buffer until the process exits and would land AFTER the line; "[Gloo] Rank 0 is connected"),
+    so for the whole run file descriptor 1 points at stderr and the line goes to a private duplicate of the original stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def _emit(obj):
+    line = json.dumps(obj)
+    if _REAL_STDOUT is not None:
+        _REAL_STDOUT.write(line + "\n")
+        _REAL_STDOUT.flush()
+    else:
+        print(line, flush=True)
 
 
 class _stdout_to_stderr:
@@ -364,6 +387,10 @@ class _stdout_to_stderr:
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        try:
+            C.CDLL(None).fflush(None)          # C stdio buffers of the libraries (the banner must not surface later on the restored fd)
+        except Exception:  # noqa: BLE001
+            pass
         os.dup2(self.saved, 1)
         os.close(self.saved)
 
@@ -444,7 +471,7 @@ def rccl_probe_main():
     except Exception:  # noqa: BLE001
         pass
     dist.destroy_process_group()
-    print(json.dumps(out), flush=True)
+    _emit(out)
 
 
 def rccl_probe_subprocess(timeout_s=120):
@@ -491,12 +518,12 @@ def dry_plan(args, rank, world):
     wall_max, audio_tot, nutt = dp.reduce_stats(dist, wall, audio, float(len(timed_ids)))
     comm = comm_probe(dist, "cpu", reps=5) if dist is not None else None
     if rank == 0:
-        print(json.dumps({"metric": "real-time factor (RTFx = audio seconds / wall seconds) + utterances/sec, offline S2ST fr-en",
+        _emit(({"metric": "real-time factor (RTFx = audio seconds / wall seconds) + utterances/sec, offline S2ST fr-en",
                           "dry_plan": True, "value": None, "unit": "x real-time", "n_gpus": world, "steps": Ksteps, "warmup": max(0, args.warmup),
                           "scaling": args.scaling, "steps_per_gpu": len(groups), "utterances_per_step": Bsz,
                           "planned_audio_seconds": round(audio_tot, 2), "planned_utterances": int(nutt),
                           "stand_in_wall_max_s": wall_max, "per_rank": per_rank, "comm": comm,
-                          "self_launched": bool(os.environ.get("SS_BENCH_SELF_LAUNCHED"))}), flush=True)
+                          "self_launched": bool(os.environ.get("SS_BENCH_SELF_LAUNCHED"))}))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -534,6 +561,7 @@ def main():
     ap.add_argument("--no-rccl-probe", action="store_true", help="skip the RCCL probe of the N = 1 line")
     args = ap.parse_args()
     if args.rccl_probe:
+        _claim_stdout()
         return rccl_probe_main()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -541,6 +569,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus))        # typed without a launcher: one rank per GPU under torch.distributed.run
+    _claim_stdout()                              # from here on stdout carries the one JSON line and nothing else
     if world != args.gpus and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; running with the launcher's world size", file=sys.stderr)
     if args.dry_plan:
@@ -1025,7 +1054,7 @@ def main():
             out["streaming_320ms"] = st
         else:
             out["streaming_320ms"] = None
-        print(json.dumps(out), flush=True)
+        _emit(out)
     if dist is not None:
         dist.destroy_process_group()
 

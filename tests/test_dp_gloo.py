@@ -98,8 +98,8 @@ def test_bench_gpus_2_as_typed_self_launches_its_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--dry-plan"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout
+    lines = r.stdout.splitlines()            # the bench line and NOTHING else on stdout (library banners go to stderr)
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["self_launched"] and out["dry_plan"]
     assert [p["rank"] for p in out["per_rank"]] == [0, 1] and all(p["utterances"] == 4 * 64 for p in out["per_rank"])
