@@ -60,13 +60,11 @@ def run_utterance(agent, pcm: np.ndarray, segment_ms: int = 320, sr: int = 16000
             samples_out += len(seg.content)
         if finished:
             break
-    toks = getattr(agent, "tgt_subwords_indices", None)      # S2ST agent: the subwords committed when the source ended
-    mt_tokens = int(toks.size(-1)) if toks is not None and hasattr(toks, "size") else None
     iv, iv_ca = _intervals(delays, durations), _intervals(elapsed, durations)
     end = (iv[-1][0] + iv[-1][1]) if iv else src_ms_total
     end_ca = (iv_ca[-1][0] + iv_ca[-1][1]) if iv_ca else src_ms_total + 1e3 * busy
     return {"source_ms": src_ms_total, "compute_ms": 1e3 * busy, "calls": len(call_ms), "call_ms": call_ms,
-            "actions": "".join(actions), "writes": len(delays), "samples_out": samples_out, "mt_tokens_at_end": mt_tokens,
+            "actions": "".join(actions), "writes": len(delays), "samples_out": samples_out,
             "RTF": end / src_ms_total, "RTF_CA": end_ca / src_ms_total,
             "StartOffset": delays[0] if delays else src_ms_total, "StartOffset_CA": elapsed[0] if elapsed else src_ms_total + 1e3 * busy,
             "EndOffset": end - src_ms_total, "EndOffset_CA": end_ca - src_ms_total}
@@ -82,12 +80,10 @@ def summarize(runs: List[Dict]) -> Dict:
     reads = [c for r in runs for c, a in zip(r["call_ms"][:-1], r["actions"][:-1]) if a == "R"]
     writes = [c for r in runs for c, a in zip(r["call_ms"][:-1], r["actions"][:-1]) if a == "W"]
     finals = [r["call_ms"][-1] for r in runs]
-    toks = [r["mt_tokens_at_end"] for r in runs if r.get("mt_tokens_at_end") is not None]
     by_kind = {"read_calls": len(reads), "ms_per_read_call_mean": round(float(np.mean(reads)), 3) if reads else None,
                "ms_per_read_call_p95": round(float(np.percentile(reads, 95)), 3) if reads else None,
                "write_calls_before_source_end": len(writes), "ms_per_write_call_mean": round(float(np.mean(writes)), 3) if writes else None,
-               "source_finished_calls": len(finals), "ms_per_source_finished_call_mean": round(float(np.mean(finals)), 3),
-               "mt_subwords_at_source_end_mean": round(float(np.mean(toks)), 1) if toks else None}
+               "source_finished_calls": len(finals), "ms_per_source_finished_call_mean": round(float(np.mean(finals)), 3)}
     return {"calls_by_kind": by_kind, "utterances": len(runs), "audio_s": round(tot_src / 1e3, 2), "compute_s": round(tot_cmp / 1e3, 4),
             "rtfx_compute": round(tot_src / tot_cmp, 2), "ms_per_utterance": round(tot_cmp / len(runs), 3),
             "policy_calls": len(calls), "ms_per_policy_call_mean": round(float(np.mean(calls)), 3),
