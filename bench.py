@@ -806,6 +806,12 @@ def main():
             return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4), **common}
         ach = fl / (ms * 1e-3) / 1e12
+        if name.startswith("conv_c64w"):
+            # Winograd F(2,3) form (csrc/conv_c64w.hip): the census counts the conv's ALGORITHMIC (direct-form) FLOPs, as for every
+            # class; the kernel issues only 4 ceil(k/3) / (2 k) of them as MFMAs (2/3 at k = 3, 6/7 at k = 7, 8/11 at k = 11), so
+            # `frac` here can pass the rate the matrix cores sustain on the direct form -- it is not their busy fraction
+            common["note"] = ("Winograd F(2,3): algorithmic (direct-form) FLOPs over time; the MFMAs issued are 2/3 (k = 3), 6/7 (k = 7), "
+                              "8/11 (k = 11) of them")
         return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), **common}
 

@@ -1,0 +1,329 @@
+// Winograd F(2,3) form of the 64-channel HiFi-GAN stage convs of a packed batch (the launches conv_c64.hip takes: C = N = 64, k = 3 / 7 /
+// 11, dilation 1 / 3 / 5; reference fairseq/models/text_to_speech/hifigan.py:52-172).
+//
+// A k-tap dilated conv is ceil(k / 3) groups of three taps (the last group zero-padded).  On the dilation lattice a group is a
+// minimal-filtering problem F(2,3): the outputs of rows t and t + d need the inputs u, u + d, u + 2 d, u + 3 d (u = t - pad + 3 g d) and
+// FOUR channel-mixing products instead of six,
+//     m0 = G0 (x0 - x2)    m1 = G1 (x1 + x2)    m2 = G2 (x2 - x1)    m3 = G3 (x1 - x3)        y[t] = m0 + m1 + m2    y[t + d] = m1 - m2 - m3
+//     G0 = w0,  G1 = (w0 + w1 + w2) / 2,  G2 = (w0 - w1 + w2) / 2,  G3 = w2      (64 x 64 matrices, transformed once per layer: wino_pack)
+// and since the output transform is linear the four products are ACCUMULATED over the groups and the input channels in four
+// accumulator sets, transformed once at the end: 4 G MFMA k-blocks per output pair instead of 2 k -- 1.5x fewer matrix-core cycles at
+// k = 3, 1.17x at k = 7, 1.375x at k = 11.  In float32 the result is as close to float64 as the direct conv's (1.9e-7 relative either
+// way: tools/winograd_error.py, profiles/r04_winograd_error.txt), so every parity bar of the direct kernels holds unchanged.
+//
+// Structure = conv_c64.hip (slab of the block's input rows once into LDS with the input leaky-ReLU applied, weight fragments from L2
+// straight into registers through a ring, two workgroups per CU, swapped MFMA operands) with
+//   * a wave tile of 32 output PAIRS x 64 columns x 4 transform components = 32 accumulator tiles (128 registers);
+//   * the input transform on the A-fragment path: a sub-step (group, channel block, component) reads the two slab rows of its
+//     component as two ds_read_b128 per pair tile and combines them with one VALU op per element -- per-lane LDS addresses make the
+//     row pairing free (pair p of a block = rows 2 d (p / d) + p % d and + d), which is why this form fits the slab kernels and not
+//     conv_sk2 (its A tiles arrive by LDS-DMA);
+//   * 4 weight fragments + 4 LDS reads + 8 VALU ops per 32 MFMAs, ring of 8 fragments = two sub-steps (2048 MFMA cycles) ahead.
+// Blocks cover 256 / 252 / 240 output rows at dilation 1 / 3 / 5 (whole pairs; two slabs must fit a CU's LDS); a conv whose slab
+// does not fit two per CU (k = 11 at dilation 5) stays on conv_c64.hip.
+#include "gemm.hpp"
+
+#include <cstdlib>
+
+namespace ss {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+
+namespace {
+constexpr int CW_C = 64;
+constexpr int CW_LDA = CW_C + 4;               // padded slab row (floats), as conv_c64.hip
+constexpr int CW_MAXSEG = 256;
+constexpr int CW_MAXROWS = 320;                // slab rows a thread's staging registers cover (20 float4 per thread)
+[[maybe_unused]] constexpr int CW_RING = 8;
+[[maybe_unused]] constexpr int CW_NUM_RECORDS = 0x7ffffff0;
+[[maybe_unused]] constexpr int CW_NP = (CW_MAXROWS * (CW_C / 4) + 255) / 256;
+constexpr int cw_bme(int dil) { return dil == 1 ? 256 : dil == 3 ? 252 : 240; }   // output rows per block: whole pairs, <= 128 pairs
+}  // namespace
+
+// WW[co][(g * 4 + f) * C + ci] from W[co][tap * C + ci] (tap-major conv weights), taps beyond k are zero
+__global__ void wino_pack_kernel(const float* __restrict__ W, float* __restrict__ WW, int C, int taps, int groups) {
+  const int n = C * groups * C;                // (co, g, ci) triples
+  for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const int ci = idx % C, g = (idx / C) % groups, co = idx / (C * groups);
+    const float* w = W + (size_t)co * taps * C + ci;
+    const float w0 = 3 * g < taps ? w[(size_t)(3 * g) * C] : 0.f;
+    const float w1 = 3 * g + 1 < taps ? w[(size_t)(3 * g + 1) * C] : 0.f;
+    const float w2 = 3 * g + 2 < taps ? w[(size_t)(3 * g + 2) * C] : 0.f;
+    float* o = WW + (size_t)co * groups * 4 * C + (size_t)g * 4 * C + ci;
+    o[0] = w0;
+    o[C] = 0.5f * ((w0 + w1) + w2);
+    o[2 * C] = 0.5f * ((w0 - w1) + w2);
+    o[3 * C] = w2;
+  }
+}
+
+template <bool LRELU, int DIL>
+__global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, const int groups, const int slab_rows) {
+#if __HIP_DEVICE_COMPILE__
+  constexpr int C = CW_C, LDA = CW_LDA, NP = CW_NP, BME = cw_bme(DIL), NPAIR = BME / 2;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;                                                        // slab [slab_rows][68]
+  int* s_blk = reinterpret_cast<int*>(smem + ((slab_rows * LDA + 3) & ~3));   // block prefix per segment
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int Kw = groups * 4 * C;                                           // row length of the transformed weight matrix
+
+  const int nseg = p.nseg > 0 ? p.nseg : 1;
+  if (t == 0) {
+    int acc = 0;
+    for (int s = 0; s < nseg; ++s) {
+      s_blk[s] = acc;
+      const int len = p.nseg > 0 ? p.segs[4 * s + 1] : p.M;
+      acc += (len + BME - 1) / BME;
+    }
+    s_blk[nseg] = acc;
+  }
+  __syncthreads();
+  const int nblocks = s_blk[nseg];
+  const float slope = p.in_slope;
+
+  int seg = 0, seg_lo = 0, seg_hi = 0, m0 = 0;
+  auto locate = [&](int blk) {                 // blocks ascend per workgroup
+    while (blk >= s_blk[seg + 1]) ++seg;
+    seg_lo = p.nseg > 0 ? p.segs[4 * seg] : 0;
+    seg_hi = seg_lo + (p.nseg > 0 ? p.segs[4 * seg + 1] : p.in_len);
+    m0 = seg_lo + (blk - s_blk[seg]) * BME;    // first output row (packed coordinates)
+  };
+
+  // ---- weight fragments: L2 -> registers.  Fragment (idx = group * 4 + component, channel block cc, column tile ct) ----
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, CW_NUM_RECORDS, 0x00020000);
+  const int vo = (r * Kw + 4 * g) * 4;
+  auto wload = [&](int idx, int cc, int ct) -> f32x4 {
+    const int so = __builtin_amdgcn_readfirstlane(((ct * 16) * Kw + idx * C + cc * 16) * 4);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, vo, so, 0);
+    return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+  };
+
+  int blk = blockIdx.x;
+  if (blk >= nblocks) return;
+  f32x4 ring[CW_RING];                         // sub-steps 0 and 1 of group 0: (cc 0, f 0), (cc 0, f 1)
+#pragma unroll
+  for (int q = 0; q < CW_RING; ++q) ring[q] = wload(q >> 2, 0, q & 3);
+
+  // this lane's two pairs (pair tile i = 0 / 1 of the wave): first row of pair p = 2 d (p / d) + p % d, the second is + d
+  int toff[2];
+  bool pv[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pp = wave * 32 + i * 16 + r;
+    pv[i] = pp < NPAIR;
+    const int pc = pv[i] ? pp : NPAIR - 1;
+    toff[i] = 2 * DIL * (pc / DIL) + pc % DIL;
+  }
+
+  for (; blk < nblocks; blk += gridDim.x) {
+    locate(blk);
+    const int cm0 = m0;
+    const int m_hi = p.nseg > 0 ? seg_hi : min(seg_hi, p.M);
+    const bool edge = (m0 - p.pad < seg_lo) || (m0 - p.pad + slab_rows > seg_hi);
+    __syncthreads();                                       // previous block's slab reads are done
+    // ---- slab: global -> registers -> [zero padding, leaky-ReLU] -> LDS (as conv_c64.hip) ----
+    {
+      f32x4 pre[NP];
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        const int rho = (t >> 4) + 16 * u;
+        const int gc = min(max(m0 - p.pad + rho, seg_lo), seg_hi - 1);
+        pre[u] = *reinterpret_cast<const f32x4*>(p.A + (size_t)gc * p.lda + (t & 15) * 4);
+      }
+      float* dst = sA + (t >> 4) * LDA + (t & 15) * 4;
+#pragma unroll
+      for (int u = 0; u < NP; ++u) {
+        const int rho = (t >> 4) + 16 * u;
+        f32x4 v = pre[u];
+        if (edge) {
+          const int gin = m0 - p.pad + rho;
+          const bool ok = gin >= seg_lo && gin < seg_hi;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
+        }
+        if (LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
+        }
+        if (rho < slab_rows) *reinterpret_cast<f32x4*>(dst + u * 16 * LDA) = v;
+      }
+    }
+    __syncthreads();
+
+    f32x4 acc[4][2][4];                                    // [component][pair tile][column tile]
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[f][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // rows of component f (in units of d rows from the group's first input row): D_f = x[ja] (+/-) x[jb]
+    //   f = 0: x0 - x2    f = 1: x1 + x2    f = 2: x2 - x1    f = 3: x1 - x3
+    const float* pa0 = sA + toff[0] * LDA + 4 * g;         // + group * 3 d rows + j d rows + cc * 16
+    const float* pa1 = sA + toff[1] * LDA + 4 * g;
+    auto rd = [&](const float* base, int j, int cc) -> f32x4 { return *reinterpret_cast<const f32x4*>(base + j * DIL * LDA + cc * 16); };
+    auto xform = [&](int f, const f32x4 a, const f32x4 b) -> f32x4 { return f == 1 ? a + b : a - b; };
+    constexpr int JA[4] = {0, 1, 2, 1}, JB[4] = {2, 2, 1, 3};
+    f32x4 xa[2];
+    xa[0] = xform(0, rd(pa0, JA[0], 0), rd(pa0, JB[0], 0));
+    xa[1] = xform(0, rd(pa1, JA[0], 0), rd(pa1, JB[0], 0));
+#pragma unroll 1
+    for (int grp = 0; grp < groups; ++grp) {
+      const int grp_next = grp + 1 < groups ? grp + 1 : 0;              // after the last group: the next block's first fragments
+      const float* pn0 = grp + 1 < groups ? pa0 + 3 * DIL * LDA : pa0;  // (after the last group: a harmless re-read)
+      const float* pn1 = grp + 1 < groups ? pa1 + 3 * DIL * LDA : pa1;
+#pragma unroll
+      for (int ss = 0; ss < 16; ++ss) {                                 // sub-step = (channel block cc, component f)
+        const int f = ss & 3;                                            // (channel block ss >> 2: already in xa and in the ring)
+        const int sn = (ss + 1) & 15, ccn = sn >> 2, fn = sn & 3;       // the next sub-step's raw rows (next group after the last)
+        const f32x4 na0 = rd(ss < 15 ? pa0 : pn0, JA[fn], ccn), nb0 = rd(ss < 15 ? pa0 : pn0, JB[fn], ccn);
+        const f32x4 na1 = rd(ss < 15 ? pa1 : pn1, JA[fn], ccn), nb1 = rd(ss < 15 ? pa1 : pn1, JB[fn], ccn);
+        f32x4 wf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int q = ss * 4 + j;                                     // fragment of this group; its ring slot is re-armed two sub-steps ahead
+          wf[j] = ring[q % CW_RING];
+          const int s2 = ss + 2;
+          ring[q % CW_RING] = wload((s2 < 16 ? grp : grp_next) * 4 + (s2 & 3), (s2 & 15) >> 2, j);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              acc[f][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xa[i][e], acc[f][i][j], 0, 0, 0);   // D = G_f . D_f^T
+        xa[0] = xform(fn, na0, nb0);
+        xa[1] = xform(fn, na1, nb1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      pa0 = pn0;
+      pa1 = pn1;
+    }
+
+    // ---- output transform + epilogue: lane holds 4 consecutive channels (4g .. 4g+3 of column tile j) of both rows of pair r ----
+    int le = lane;
+    asm volatile("" : "+v"(le));               // addresses derived from `le` cannot be hoisted above the contraction
+    const int g_e = le >> 4;
+    f32x4 bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bb[j] = *reinterpret_cast<const f32x4*>(p.bias + j * 16 + g_e * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {                        // the pair's first / second row
+        const int m = cm0 + toff[i] + h * DIL;
+        const int mc = min(m, m_hi - 1);
+        f32x4 rr[4], rr2[4];
+        if (p.R) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rr[j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + j * 16 + g_e * 4);
+        }
+        if (p.R2) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) rr2[j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)mc * p.ldr2 + j * 16 + g_e * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int n = j * 16 + g_e * 4;
+          f32x4 v = h == 0 ? (acc[0][i][j] + acc[1][i][j]) + acc[2][i][j] : (acc[1][i][j] - acc[2][i][j]) - acc[3][i][j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += bb[j][e];
+          if (p.act == ACT_LRELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.act_slope;
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+          if (p.R) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rr[j][e];
+          }
+          if (p.R2) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = rr2[j][e] + v[e];
+          }
+          if (p.div > 0.f) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] / p.div;
+          }
+          if (pv[i] && m < m_hi) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+        }
+      }
+    }
+  }
+#endif
+}
+
+// ---- host side ---------------------------------------------------------------------------------
+static int g_c64w_on = getenv("SS_CONV_C64_WINOGRAD") ? atoi(getenv("SS_CONV_C64_WINOGRAD")) : 1;   // A/B knob: 0 = every conv of the stage on the direct kernel
+static int g_c64w_min_k = getenv("SS_CONV_C64_WINOGRAD_MIN_K") ? atoi(getenv("SS_CONV_C64_WINOGRAD_MIN_K")) : 3;
+void conv_c64w_debug(int enable) { if (enable >= 0) g_c64w_on = enable ? 1 : 0; }
+bool conv_c64w_enabled() { return g_c64w_on != 0; }
+
+static int cw_groups(const GemmArgs& a) { return (a.taps + 2) / 3; }
+static size_t cw_lds(const GemmArgs& a) {
+  const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
+  return (size_t)((slab_rows * CW_LDA + 3) & ~3) * sizeof(float) + (CW_MAXSEG + 2) * sizeof(int);
+}
+
+// the launches conv_c64.hip takes (checked by the caller: conv_c64_eligible) that also have transformed weights, a "same" geometry the
+// pairing covers and a slab two of which fit a CU
+bool conv_c64w_eligible(const GemmArgs& a) {
+  if (!g_c64w_on || !a.Wwino || a.taps < g_c64w_min_k || a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.C2) return false;
+  if (a.pad != a.dil * (a.taps - 1) / 2) return false;
+  // k = 7 at dilation 5: 1.17x fewer MFMAs against a 45-row halo on 240-row blocks -- measured slower than the direct form (283 vs 272 us)
+  static const int allow_k7d5 = getenv("SS_CONV_C64_WINOGRAD_K7D5") ? atoi(getenv("SS_CONV_C64_WINOGRAD_K7D5")) : 0;
+  if (a.taps <= 8 && a.taps > 3 && a.dil == 5 && !allow_k7d5) return false;
+  const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
+  return slab_rows <= CW_MAXROWS && 2 * cw_lds(a) <= 158 * 1024 && (size_t)cw_groups(a) * 4 * CW_C * CW_C * 4 < 0x7ff00000ull;
+}
+
+int launch_wino_pack(const float* W, float* WW, int C, int taps, hipStream_t stream) {
+  const int groups = (taps + 2) / 3, n = C * groups * C;
+  hipLaunchKernelGGL(wino_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, WW, C, taps, groups);
+  SS_LAUNCH_CHECK();
+  return SS_OK;
+}
+
+template <bool LRELU, int DIL>
+static int launch_c64w_t(GemmArgs a, hipStream_t stream) {
+  constexpr int BME = cw_bme(DIL);
+  const int groups = cw_groups(a);
+  const int slab_rows = BME + 3 * groups * DIL;
+  const size_t lds = cw_lds(a);
+  SS_MAX_LDS_ONCE((&conv_c64w_kernel<LRELU, DIL>), 96 * 1024);
+  SkWorkspace* st = nullptr;                       // (only for the device's CU count, cached per context)
+  int rc = sk_workspace_acquire(stream, &st);
+  if (rc != SS_OK) return rc;
+  const int nseg = a.nseg > 0 ? a.nseg : 1;
+  const long long max_blocks = (long long)cdiv(a.M, BME) + nseg;      // upper bound (per-segment round-up)
+  const int grid = (int)std::min<long long>(2ll * st->cus, std::max<long long>(1, max_blocks));
+  ProfRec rec{}; bool prof = false;
+  rc = prof_begin(a, stream, 27, rec, prof);       // census: the conv's algorithmic (direct-form) FLOPs; the kernel issues 4 G / (2 k) of them
+  if (rc != SS_OK) return rc;
+  a.W = a.Wwino;
+  hipLaunchKernelGGL((conv_c64w_kernel<LRELU, DIL>), dim3(grid), dim3(256), lds, stream, a, groups, slab_rows);
+  SS_LAUNCH_CHECK();
+  return prof_end(stream, rec, prof);
+}
+
+int launch_conv_c64w(const GemmArgs& a, hipStream_t stream) {
+  if (!conv_c64_eligible(a) || !conv_c64w_eligible(a)) return SS_ERR_ARG;
+  const bool lr = a.in_act == ACT_LRELU;
+  switch (a.dil) {
+    case 1: return lr ? launch_c64w_t<true, 1>(a, stream) : launch_c64w_t<false, 1>(a, stream);
+    case 3: return lr ? launch_c64w_t<true, 3>(a, stream) : launch_c64w_t<false, 3>(a, stream);
+    default: return lr ? launch_c64w_t<true, 5>(a, stream) : launch_c64w_t<false, 5>(a, stream);
+  }
+}
+
+}  // namespace ss

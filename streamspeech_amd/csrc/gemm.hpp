@@ -16,6 +16,7 @@ namespace ss {
 struct GemmArgs {
   const float* A = nullptr;   // input rows, row stride lda
   const float* W = nullptr;   // [N][taps*Cin]
+  const float* Wwino = nullptr;  // optional: the same weights in Winograd F(2,3) form [N][ceil(taps/3)*4*Cin] (conv_c64w.hip; made by launch_wino_pack)
   const float* bias = nullptr;  // [N] or null
   const float* R = nullptr;   // residual [M][ldr] or null
   const float* R2 = nullptr;  // second residual (MRF accumulate) or null
@@ -60,7 +61,7 @@ struct GemmArgs {
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 27;
+constexpr int kNumTileCfg = 28;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
@@ -136,6 +137,12 @@ int launch_resblock_fused(const float* X, int ldx, const float* const* W1, const
 bool conv_c64_eligible(const GemmArgs& a);
 bool conv_c64_enabled();
 int launch_conv_c64(const GemmArgs& a, hipStream_t stream);
+// conv_c64w.hip: the same launches in Winograd F(2,3) form (needs a.Wwino; k = 11 at dilation 5 stays on conv_c64)
+bool conv_c64w_eligible(const GemmArgs& a);       // call with conv_c64_eligible(a) already true
+int launch_conv_c64w(const GemmArgs& a, hipStream_t stream);
+int launch_wino_pack(const float* W, float* WW, int C, int taps, hipStream_t stream);   // WW: C * ceil(taps/3) * 4 * C floats
+void conv_c64w_debug(int enable);                 // A/B: 0 off, 1 on, -1 keep
+bool conv_c64w_enabled();
 void conv_c64_debug(int enable);          // A/B: 0 routes the stage back to conv_sk2<64> (pre-activated twins), 1 on, -1 keep
 
 // The same for the 32-channel stage (conv_c32.hip): each ResBlock conv as its own launch instead of one fused launch per ResBlock.

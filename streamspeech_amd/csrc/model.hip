@@ -935,7 +935,7 @@ extern "C" int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, 
 // =================================================================================================
 // vocoder
 // =================================================================================================
-struct ConvW { const float* w = nullptr; const float* b = nullptr; };
+struct ConvW { const float* w = nullptr; const float* b = nullptr; const float* ww = nullptr; };   // ww: Winograd form (64-channel stage ResBlock convs)
 struct ss_vocoder {
   ss_vocoder_config cfg;
   WeightTable wt;
@@ -945,6 +945,7 @@ struct ss_vocoder {
   LN dur_ln1, dur_ln2;
   std::vector<ConvW> ups;
   std::vector<ConvW> rb_c1, rb_c2;  // [(stage*n_res + j)*3 + d]
+  DevBuf wino;                       // Winograd F(2,3) forms of the 64-channel stage's ResBlock conv weights (conv_c64w.hip)
   DevBuf ws, small, segs;
   int x3 = 0;          // split-bf16 contraction of the C >= 64 generator convs (ss_vocoder_set_bf16x3); default off = exact f32
 };
@@ -987,6 +988,38 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
   }
   v->post = {w.get("voc.post.w", (int64_t)7 * C), w.get("voc.post.b", 1)};
   if (!w.missing.empty()) { sk_workspace_free(v->skws); delete v; return SS_ERR_MISSING_WEIGHT; }
+  {
+    // Winograd forms of the 64-channel stage's ResBlock convs (conv_c64w.hip), made once per context from the packed weights
+    size_t need = 0;
+    int Cs = C0;
+    for (int i = 0; i < cfg->n_up; ++i) {
+      Cs /= 2;
+      if (Cs == 64) for (int j = 0; j < cfg->n_res; ++j) need += 6 * (size_t)64 * ((cfg->resblock_kernel_sizes[j] + 2) / 3) * 4 * 64;
+    }
+    if (need) {
+      rc = v->wino.ensure(need * sizeof(float));
+      if (rc != SS_OK) { sk_workspace_free(v->skws); delete v; return rc; }
+      float* dst = v->wino.f();
+      Cs = C0;
+      for (int i = 0; i < cfg->n_up && rc == SS_OK; ++i) {
+        Cs /= 2;
+        if (Cs != 64) continue;
+        for (int j = 0; j < cfg->n_res && rc == SS_OK; ++j) {
+          const int kr = cfg->resblock_kernel_sizes[j];
+          const size_t n = (size_t)64 * ((kr + 2) / 3) * 4 * 64;
+          for (int dd = 0; dd < 3 && rc == SS_OK; ++dd) {
+            const int idx = (i * cfg->n_res + j) * 3 + dd;
+            rc = launch_wino_pack(v->rb_c1[idx].w, dst, 64, kr, nullptr);
+            v->rb_c1[idx].ww = dst; dst += n;
+            if (rc == SS_OK) rc = launch_wino_pack(v->rb_c2[idx].w, dst, 64, kr, nullptr);
+            v->rb_c2[idx].ww = dst; dst += n;
+          }
+        }
+      }
+      if (rc == SS_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = SS_ERR_HIP;
+      if (rc != SS_OK) { v->wino.release(); sk_workspace_free(v->skws); delete v; return rc; }
+    }
+  }
   *out = v;
   return SS_OK;
 }
@@ -999,7 +1032,7 @@ extern "C" int ss_vocoder_set_bf16x3(ss_vocoder* v, int on) {
 
 extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
   if (!v) return;
-  v->ws.release(); v->small.release(); v->segs.release();
+  v->ws.release(); v->small.release(); v->segs.release(); v->wino.release();
   sk_workspace_free(v->skws);
   delete v;
 }
@@ -1042,7 +1075,7 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
   auto preact = [c64](int channels) { return channels >= 64 && !(c64 && channels == 64); };
   auto mk = [v](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
     GemmArgs a;
-    a.A = A; a.lda = Cin; a.W = cw.w; a.bias = cw.b; a.C = Cc; a.ldc = ldc; a.ldr = ldc; a.ldr2 = ldc; a.ldc2 = ldc;
+    a.A = A; a.lda = Cin; a.W = cw.w; a.Wwino = cw.ww; a.bias = cw.b; a.C = Cc; a.ldc = ldc; a.ldr = ldc; a.ldr2 = ldc; a.ldc2 = ldc;
     a.N = Cout; a.Cin = Cin; a.taps = k; a.dil = dil; a.stride = 1; a.pad = dil * (k - 1) / 2; a.same_rows = 1;
     a.x3 = v->x3;
     return a;
@@ -1656,6 +1689,13 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
   a.M = M; a.N = N; a.Cin = Cin; a.taps = taps; a.dil = dil; a.stride = stride; a.pad = pad; a.in_len = in_len;
   a.chunk = chunk; a.in_act = in_act; a.in_slope = in_slope; a.act = act; a.alpha = alpha; a.div = div; a.glu = glu;
   a.same_rows = (stride == 1 && M == in_len) ? 1 : 0;
+  // unit-test path of the Winograd form (the model makes the transformed weights once per context): made here per call
+  static thread_local DevBuf wino_tmp;
+  if (conv_c64w_enabled() && N == 64 && Cin == 64 && taps >= 3 && conv_c64_eligible(a)) {
+    RET(wino_tmp.ensure((size_t)64 * ((taps + 2) / 3) * 4 * 64 * sizeof(float)));
+    RET(launch_wino_pack(dW, wino_tmp.f(), 64, taps, (hipStream_t)stream));
+    a.Wwino = wino_tmp.f();
+  }
   return launch_conv_gemm(a, (hipStream_t)stream);
 }
 
@@ -1683,7 +1723,12 @@ extern "C" int ss_op_ln_linear(void* stream, const float* dX, int ldx, const flo
   a.ln_g = ln_g; a.ln_b = ln_b;
   return launch_conv_gemm(a, (hipStream_t)stream);       // SS_ERR_ARG when no kernel with a LayerNorm prologue takes the shape
 }
-extern "C" int ss_debug_conv_c64(int enable) { conv_c64_debug(enable); return SS_OK; }
+// enable 0 / 1: the stage on conv_sk2<64> / on the slab kernels; 4 / 5: its Winograd form (conv_c64w.hip) off / on (the slab kernels stay on)
+extern "C" int ss_debug_conv_c64(int enable) {
+  if (enable == 4 || enable == 5) { conv_c64w_debug(enable == 5); return SS_OK; }
+  conv_c64_debug(enable);
+  return SS_OK;
+}
 extern "C" int ss_debug_conv_c32(int enable) { conv_c32_debug(enable); return SS_OK; }
 extern "C" int ss_debug_conv_c16(int enable) { conv_c16_debug(enable); return SS_OK; }
 extern "C" int ss_debug_rtlin(int grid, int enable) {

@@ -453,7 +453,8 @@ def test_stream_k_fixup_never_reads_stale_partials(lib):
 @pytest.mark.parametrize("C_", [64, 32, 16])
 @pytest.mark.parametrize("taps,dil,M,lrelu,extras", [(3, 1, 70000, True, True), (3, 5, 66000, True, False), (7, 3, 70077, True, True),
                                                       (11, 5, 66001, True, True), (11, 1, 70000, False, False), (3, 1, 65536, False, True),
-                                                      (2, 1, 66000, True, False)])
+                                                      (2, 1, 66000, True, False), (7, 5, 70001, True, True), (11, 3, 69999, True, False),
+                                                      (7, 1, 66003, False, True)])
 def test_conv_c64_slab_kernel(lib, C_, taps, dil, M, lrelu, extras):
     """csrc/conv_c64.hip (the 64-channel vocoder stage of a packed batch: input slab once into LDS with the leaky-ReLU applied on
     the way, weight fragments streamed from L2): dilated "same" convs with bias / residual / MRF accumulate / mean against torch,
@@ -476,6 +477,8 @@ def test_conv_c64_slab_kernel(lib, C_, taps, dil, M, lrelu, extras):
     y = F.conv1d(xin_p, w.double(), b.double(), dilation=dil)[0].t()
     ref = ((R2.double() + (y + R.double())) / 3.0) if extras else y
     kw = dict(taps=taps, dil=dil, pad=pad, in_act=3 if lrelu else 0, slope=0.1, R=R, R2=R2, div=3.0 if extras else 0.0)
+    if C == 64:
+        dbg(4)                    # the direct form first; the Winograd form of the same launch (conv_c64w.hip) below
     n0 = _class_launches_ops(lib, cls)
     got = run_conv_gemm(lib, x, conv_tap_major(w), b, M, C, C, **kw)
     assert _class_launches_ops(lib, cls) == n0 + 1, "the slab kernel must have taken the launch"
@@ -488,6 +491,21 @@ def test_conv_c64_slab_kernel(lib, C_, taps, dil, M, lrelu, extras):
         dbg(1)
     assert _class_launches_ops(lib, cls) == n0 + 1
     assert (got - old).abs().max() < 2e-5
+    if C == 64:
+        # Winograd F(2,3) on the dilation lattice: every k >= 3 conv whose slab fits two per CU (not k = 11 at dilation 5); pairs (t, t + d)
+        # of 256- / 252- / 240-row blocks, ragged last block, residual / MRF epilogue on both rows of a pair
+        takes = taps >= 3 and not (taps == 11 and dil == 5) and not (taps == 7 and dil == 5)      # (k = 7 at dilation 5: measured slower, stays direct)
+        dbg(5)
+        nw = _class_launches_ops(lib, "conv_c64w<256,64>")
+        gotw = run_conv_gemm(lib, x, conv_tap_major(w), b, M, C, C, **kw)
+        assert _class_launches_ops(lib, "conv_c64w<256,64>") == nw + (1 if takes else 0)
+        assert _class_launches_ops(lib, cls) == n0 + (1 if takes else 2)
+        assert torch.isfinite(gotw).all()
+        assert (gotw.double() - ref).abs().max() < TOL, f"max err {(gotw.double() - ref).abs().max()}"
+        assert (gotw - got).abs().max() < 2e-5
+        e_dir = ((got.double() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()
+        e_win = ((gotw.double() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()
+        assert e_win < 2.0 * e_dir + 1e-8, (float(e_dir), float(e_win))     # as close to float64 as the direct form (tools/winograd_error.py)
 
 
 def _class_launches_ops(lib, name):

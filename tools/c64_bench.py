@@ -42,7 +42,7 @@ def main():
     print(f"{M} rows x {CH} channels; conv1 = dilated conv of lrelu(x) + bias; conv2 = conv of lrelu(h) + bias + residual")
     print("taps dil | conv1: stream-K (pre-activated in, LRELU epilogue) | slab | conv2: stream-K (+ twin out) | slab   [us (TF/s)]")
     for taps in (3, 7, 11):
-        for dil in (1, 5):
+        for dil in (1, 3, 5):
             W, b = rn(CH, taps * CH, sc=(taps * CH) ** -0.5), rn(CH, sc=0.1)
             fl = 2.0 * M * CH * CH * taps
             pad = dil * (taps - 1) // 2

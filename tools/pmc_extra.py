@@ -8,7 +8,7 @@ import re
 import sys
 from collections import defaultdict
 
-KEEP = ("conv_sk2_kernel", "conv_c64_kernel", "conv_c32_kernel", "conv_c16_kernel", "resblock_fused_kernel", "ffn_fused_kernel",
+KEEP = ("conv_sk2_kernel", "conv_c64_kernel", "conv_c64w_kernel", "conv_c32_kernel", "conv_c16_kernel", "resblock_fused_kernel", "ffn_fused_kernel",
         "rt_linear_kernel", "conv_gemm_kernel", "smallm_gemm_kernel", "attention_relpos_mfma_kernel", "attention_decode_kernel",
         "conv_slab_kernel", "fbank", "dwconv")
 
