@@ -255,7 +255,8 @@ int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable);
 int ss_debug_rtlin(int grid, int enable);
 /* A/B hook of the 64-channel vocoder-stage kernel (csrc/conv_c64.hip): 0 routes that stage's convs back to the stream-K kernel
  * with pre-activated twin tensors (round 3), 1 to it, -1 keeps the setting; 4 / 5 switch the Winograd F(2,3) form of those convs
- * (csrc/conv_c64w.hip) off / on without touching the first setting. */
+ * (csrc/conv_c64w.hip) off / on without touching the first setting; 6 / 7 route the 128-channel stage's ResBlock convs to conv_sk2<128>
+ * with twins / to the same Winograd kernel at 128 channels. */
 int ss_debug_conv_c64(int enable);
 /* The same for the 32-channel stage (csrc/conv_c32.hip): 0 = one fused launch per ResBlock (round 3), 1 = one launch per conv. */
 int ss_debug_conv_c32(int enable);

@@ -31,13 +31,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
 namespace {
-constexpr int CW_C = 64;
-constexpr int CW_LDA = CW_C + 4;               // padded slab row (floats), as conv_c64.hip
 constexpr int CW_MAXSEG = 256;
-constexpr int CW_MAXROWS = 320;                // slab rows a thread's staging registers cover (20 float4 per thread)
-[[maybe_unused]] constexpr int CW_RING = 8;
+constexpr int CW_MAXROWS = 320;                // slab rows a thread's staging registers cover (20 float4 per thread at 64 channels, 40 at 128)
 [[maybe_unused]] constexpr int CW_NUM_RECORDS = 0x7ffffff0;
-[[maybe_unused]] constexpr int CW_NP = (CW_MAXROWS * (CW_C / 4) + 255) / 256;
 constexpr int cw_bme(int dil) { return dil == 1 ? 256 : dil == 3 ? 252 : 240; }   // output rows per block: whole pairs, <= 128 pairs
 }  // namespace
 
@@ -58,16 +54,24 @@ __global__ void wino_pack_kernel(const float* __restrict__ W, float* __restrict_
   }
 }
 
-template <bool LRELU, int DIL>
-__global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, const int groups, const int slab_rows) {
+// CH = 64: two workgroups of 4 waves per CU.  CH = 128 (the 128-channel stage, which has no direct slab kernel -- conv_sk2<128> is what this
+// replaces): ONE workgroup of 8 waves per CU on one slab; waves 0-3 produce output columns 0-63, waves 4-7 columns 64-127 of the same 128
+// pairs, so every wave keeps the 32-tile accumulator set, the 8-fragment ring and the register budget (256) of the 64-channel form, and
+// each SIMD still holds two waves that hide each other's fragment latency (a 64-tile accumulator set per wave made hipcc shuffle
+// accumulators between register classes inside the loop: 1300 moves per 2048 MFMAs, 200+ spills).
+template <bool LRELU, int DIL, int CH>
+__global__ __launch_bounds__(CH == 64 ? 256 : 512, CH == 64 ? 2 : 1) void conv_c64w_kernel(const GemmArgs p, const int groups, const int slab_rows) {
 #if __HIP_DEVICE_COMPILE__
-  constexpr int C = CW_C, LDA = CW_LDA, NP = CW_NP, BME = cw_bme(DIL), NPAIR = BME / 2;
+  constexpr int C = CH, LDA = CH + 4, CT = 4, CB = CH / 16, NSS = CB * 4, RING = 2 * CT, TPR = CH / 4;   // TPR threads stage one row
+  constexpr int NT = CH == 64 ? 256 : 512, RPP = NT / TPR;                  // rows per staging pass (16)
+  constexpr int NP = (CW_MAXROWS + RPP - 1) / RPP, BME = cw_bme(DIL), NPAIR = BME / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                                                        // slab [slab_rows][68]
   int* s_blk = reinterpret_cast<int*>(smem + ((slab_rows * LDA + 3) & ~3));   // block prefix per segment
 
   const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((t >> 6) & 3);
+  const int cs = CH == 64 ? 0 : __builtin_amdgcn_readfirstlane(t >> 8);     // column set of this wave
   const int r = lane & 15, g = lane >> 4;
   const int Kw = groups * 4 * C;                                           // row length of the transformed weight matrix
 
@@ -97,16 +101,16 @@ __global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, con
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, CW_NUM_RECORDS, 0x00020000);
   const int vo = (r * Kw + 4 * g) * 4;
   auto wload = [&](int idx, int cc, int ct) -> f32x4 {
-    const int so = __builtin_amdgcn_readfirstlane(((ct * 16) * Kw + idx * C + cc * 16) * 4);
+    const int so = __builtin_amdgcn_readfirstlane((((cs * 4 + ct) * 16) * Kw + idx * C + cc * 16) * 4);
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, vo, so, 0);
     return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
   };
 
   int blk = blockIdx.x;
   if (blk >= nblocks) return;
-  f32x4 ring[CW_RING];                         // sub-steps 0 and 1 of group 0: (cc 0, f 0), (cc 0, f 1)
+  f32x4 ring[RING];                            // sub-steps 0 and 1 of group 0: (cc 0, f 0), (cc 0, f 1)
 #pragma unroll
-  for (int q = 0; q < CW_RING; ++q) ring[q] = wload(q >> 2, 0, q & 3);
+  for (int q = 0; q < RING; ++q) ring[q] = wload(q / CT, 0, q % CT);
 
   // this lane's two pairs (pair tile i = 0 / 1 of the wave): first row of pair p = 2 d (p / d) + p % d, the second is + d
   int toff[2];
@@ -125,19 +129,20 @@ __global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, con
     const int m_hi = p.nseg > 0 ? seg_hi : min(seg_hi, p.M);
     const bool edge = (m0 - p.pad < seg_lo) || (m0 - p.pad + slab_rows > seg_hi);
     __syncthreads();                                       // previous block's slab reads are done
-    // ---- slab: global -> registers -> [zero padding, leaky-ReLU] -> LDS (as conv_c64.hip) ----
-    {
-      f32x4 pre[NP];
+    // ---- slab: global -> registers -> [zero padding, leaky-ReLU] -> LDS (as conv_c64.hip), 20 float4 per thread in flight at a time ----
+#pragma unroll 1
+    for (int u0 = 0; u0 < NP; u0 += 20) {
+      f32x4 pre[20];
 #pragma unroll
-      for (int u = 0; u < NP; ++u) {
-        const int rho = (t >> 4) + 16 * u;
+      for (int u = 0; u < 20; ++u) {
+        const int rho = t / TPR + RPP * (u0 + u);
         const int gc = min(max(m0 - p.pad + rho, seg_lo), seg_hi - 1);
-        pre[u] = *reinterpret_cast<const f32x4*>(p.A + (size_t)gc * p.lda + (t & 15) * 4);
+        pre[u] = *reinterpret_cast<const f32x4*>(p.A + (size_t)gc * p.lda + (t % TPR) * 4);
       }
-      float* dst = sA + (t >> 4) * LDA + (t & 15) * 4;
+      float* dst = sA + (t / TPR + RPP * u0) * LDA + (t % TPR) * 4;
 #pragma unroll
-      for (int u = 0; u < NP; ++u) {
-        const int rho = (t >> 4) + 16 * u;
+      for (int u = 0; u < 20; ++u) {
+        const int rho = t / TPR + RPP * (u0 + u);
         f32x4 v = pre[u];
         if (edge) {
           const int gin = m0 - p.pad + rho;
@@ -149,18 +154,18 @@ __global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, con
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
         }
-        if (rho < slab_rows) *reinterpret_cast<f32x4*>(dst + u * 16 * LDA) = v;
+        if (rho < slab_rows) *reinterpret_cast<f32x4*>(dst + u * RPP * LDA) = v;
       }
     }
     __syncthreads();
 
-    f32x4 acc[4][2][4];                                    // [component][pair tile][column tile]
+    f32x4 acc[4][2][CT];                                   // [component][pair tile][column tile]
 #pragma unroll
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[f][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < CT; ++j) acc[f][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // rows of component f (in units of d rows from the group's first input row): D_f = x[ja] (+/-) x[jb]
     //   f = 0: x0 - x2    f = 1: x1 + x2    f = 2: x2 - x1    f = 3: x1 - x3
@@ -178,25 +183,25 @@ __global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, con
       const float* pn0 = grp + 1 < groups ? pa0 + 3 * DIL * LDA : pa0;  // (after the last group: a harmless re-read)
       const float* pn1 = grp + 1 < groups ? pa1 + 3 * DIL * LDA : pa1;
 #pragma unroll
-      for (int ss = 0; ss < 16; ++ss) {                                 // sub-step = (channel block cc, component f)
+      for (int ss = 0; ss < NSS; ++ss) {                                // sub-step = (channel block cc, component f)
         const int f = ss & 3;                                            // (channel block ss >> 2: already in xa and in the ring)
-        const int sn = (ss + 1) & 15, ccn = sn >> 2, fn = sn & 3;       // the next sub-step's raw rows (next group after the last)
-        const f32x4 na0 = rd(ss < 15 ? pa0 : pn0, JA[fn], ccn), nb0 = rd(ss < 15 ? pa0 : pn0, JB[fn], ccn);
-        const f32x4 na1 = rd(ss < 15 ? pa1 : pn1, JA[fn], ccn), nb1 = rd(ss < 15 ? pa1 : pn1, JB[fn], ccn);
-        f32x4 wf[4];
+        const int sn = (ss + 1) % NSS, ccn = sn >> 2, fn = sn & 3;       // the next sub-step's raw rows (next group after the last)
+        const f32x4 na0 = rd(ss < NSS - 1 ? pa0 : pn0, JA[fn], ccn), nb0 = rd(ss < NSS - 1 ? pa0 : pn0, JB[fn], ccn);
+        const f32x4 na1 = rd(ss < NSS - 1 ? pa1 : pn1, JA[fn], ccn), nb1 = rd(ss < NSS - 1 ? pa1 : pn1, JB[fn], ccn);
+        f32x4 wf[CT];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int q = ss * 4 + j;                                     // fragment of this group; its ring slot is re-armed two sub-steps ahead
-          wf[j] = ring[q % CW_RING];
+        for (int j = 0; j < CT; ++j) {
+          const int q = ss * CT + j;                                    // fragment of this group; its ring slot is re-armed two sub-steps ahead
+          wf[j] = ring[q % RING];
           const int s2 = ss + 2;
-          ring[q % CW_RING] = wload((s2 < 16 ? grp : grp_next) * 4 + (s2 & 3), (s2 & 15) >> 2, j);
+          ring[q % RING] = wload((s2 < NSS ? grp : grp_next) * 4 + (s2 & 3), (s2 % NSS) >> 2, j);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < CT; ++j)
               acc[f][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xa[i][e], acc[f][i][j], 0, 0, 0);   // D = G_f . D_f^T
         xa[0] = xform(fn, na0, nb0);
         xa[1] = xform(fn, na1, nb1);
@@ -210,11 +215,11 @@ __global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, con
     int le = lane;
     asm volatile("" : "+v"(le));               // addresses derived from `le` cannot be hoisted above the contraction
     const int g_e = le >> 4;
-    f32x4 bb[4];
+    f32x4 bb[CT];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CT; ++j) {
       bb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bb[j] = *reinterpret_cast<const f32x4*>(p.bias + j * 16 + g_e * 4);
+      if (p.bias) bb[j] = *reinterpret_cast<const f32x4*>(p.bias + cs * 64 + j * 16 + g_e * 4);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -222,18 +227,18 @@ __global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, con
       for (int h = 0; h < 2; ++h) {                        // the pair's first / second row
         const int m = cm0 + toff[i] + h * DIL;
         const int mc = min(m, m_hi - 1);
-        f32x4 rr[4], rr2[4];
+        f32x4 rr[CT], rr2[CT];
         if (p.R) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) rr[j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + j * 16 + g_e * 4);
+          for (int j = 0; j < CT; ++j) rr[j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + cs * 64 + j * 16 + g_e * 4);
         }
         if (p.R2) {
 #pragma unroll
-          for (int j = 0; j < 4; ++j) rr2[j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)mc * p.ldr2 + j * 16 + g_e * 4);
+          for (int j = 0; j < CT; ++j) rr2[j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)mc * p.ldr2 + cs * 64 + j * 16 + g_e * 4);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int n = j * 16 + g_e * 4;
+        for (int j = 0; j < CT; ++j) {
+          const int n = cs * 64 + j * 16 + g_e * 4;
           f32x4 v = h == 0 ? (acc[0][i][j] + acc[1][i][j]) + acc[2][i][j] : (acc[1][i][j] - acc[2][i][j]) - acc[3][i][j];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bb[j][e];
@@ -255,7 +260,15 @@ __global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, con
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = v[e] / p.div;
           }
-          if (pv[i] && m < m_hi) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+          if (pv[i] && m < m_hi) {
+            *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
+            if (CH == 128 && p.C2) {                         // pre-activated twin for a consumer that cannot activate while staging (conv_sk2)
+              f32x4 w2;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) w2[e] = v[e] > 0.f ? v[e] : v[e] * p.c2_slope;
+              *reinterpret_cast<f32x4*>(p.C2 + (size_t)m * p.ldc2 + n) = w2;
+            }
+          }
         }
       }
     }
@@ -264,15 +277,19 @@ __global__ __launch_bounds__(256, 2) void conv_c64w_kernel(const GemmArgs p, con
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int g_c64w_on = getenv("SS_CONV_C64_WINOGRAD") ? atoi(getenv("SS_CONV_C64_WINOGRAD")) : 1;   // A/B knob: 0 = every conv of the stage on the direct kernel
+static int g_c64w_on = getenv("SS_CONV_C64_WINOGRAD") ? atoi(getenv("SS_CONV_C64_WINOGRAD")) : 1;   // A/B knob: 0 = every conv of the 64-channel stage on the direct kernel
+static int g_c128w_on = getenv("SS_CONV_C128_WINOGRAD") ? atoi(getenv("SS_CONV_C128_WINOGRAD")) : 1; // A/B knob: 0 = the 128-channel stage on conv_sk2<128> (pre-activated twins)
 static int g_c64w_min_k = getenv("SS_CONV_C64_WINOGRAD_MIN_K") ? atoi(getenv("SS_CONV_C64_WINOGRAD_MIN_K")) : 3;
+static long long g_c128w_min_rows = getenv("SS_CONV_C128_MIN_ROWS") ? atoll(getenv("SS_CONV_C128_MIN_ROWS")) : 65536;   // >= a block per CU
 void conv_c64w_debug(int enable) { if (enable >= 0) g_c64w_on = enable ? 1 : 0; }
 bool conv_c64w_enabled() { return g_c64w_on != 0; }
+void conv_c128w_debug(int enable) { if (enable >= 0) g_c128w_on = enable ? 1 : 0; }
+bool conv_c128w_enabled() { return g_c128w_on != 0; }
 
 static int cw_groups(const GemmArgs& a) { return (a.taps + 2) / 3; }
-static size_t cw_lds(const GemmArgs& a) {
+static size_t cw_lds(const GemmArgs& a, int ch) {
   const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
-  return (size_t)((slab_rows * CW_LDA + 3) & ~3) * sizeof(float) + (CW_MAXSEG + 2) * sizeof(int);
+  return (size_t)((slab_rows * (ch + 4) + 3) & ~3) * sizeof(float) + (CW_MAXSEG + 2) * sizeof(int);
 }
 
 // the launches conv_c64.hip takes (checked by the caller: conv_c64_eligible) that also have transformed weights, a "same" geometry the
@@ -284,7 +301,20 @@ bool conv_c64w_eligible(const GemmArgs& a) {
   static const int allow_k7d5 = getenv("SS_CONV_C64_WINOGRAD_K7D5") ? atoi(getenv("SS_CONV_C64_WINOGRAD_K7D5")) : 0;
   if (a.taps <= 8 && a.taps > 3 && a.dil == 5 && !allow_k7d5) return false;
   const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
-  return slab_rows <= CW_MAXROWS && 2 * cw_lds(a) <= 158 * 1024 && (size_t)cw_groups(a) * 4 * CW_C * CW_C * 4 < 0x7ff00000ull;
+  return slab_rows <= CW_MAXROWS && 2 * cw_lds(a, 64) <= 158 * 1024 && (size_t)cw_groups(a) * 4 * 64 * 64 * 4 < 0x7ff00000ull;
+}
+
+// The 128-channel stage: every "same" conv with C = N = 128, k >= 3 at dilation 1 / 3 / 5 of a packed batch big enough to give each CU a
+// block (one workgroup per CU: the slab is 137-158 KB).  There is no direct slab kernel at this width (measured slower than conv_sk2<128>:
+// profiles/r04_c128_bench.txt), so the stage takes this path only if ALL its convs are eligible (model.hip asks with a probe).
+bool conv_c128w_eligible(const GemmArgs& a) {
+  if (!g_c128w_on || !a.Wwino || !a.same_rows || a.stride != 1 || a.chunk || a.glu || a.ln_g || a.x3 || a.Cin != 128 || a.N != 128) return false;
+  if (a.lda != 128 || (a.ldc & 3) || (a.R && (a.ldr & 3)) || (a.R2 && (a.ldr2 & 3)) || (a.C2 && (a.ldc2 & 3))) return false;
+  if (a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.pad != a.dil * (a.taps - 1) / 2) return false;
+  if (a.nseg > CW_MAXSEG || a.M < g_c128w_min_rows || ((size_t)(a.M + a.pad + 512) * a.lda) * 4 >= 0x7ff00000ull) return false;
+  if (!(a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) || !(a.act == ACT_NONE || a.act == ACT_LRELU)) return false;
+  const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
+  return slab_rows <= CW_MAXROWS && cw_lds(a, 128) <= 160 * 1024;
 }
 
 int launch_wino_pack(const float* W, float* WW, int C, int taps, hipStream_t stream) {
@@ -294,36 +324,45 @@ int launch_wino_pack(const float* W, float* WW, int C, int taps, hipStream_t str
   return SS_OK;
 }
 
-template <bool LRELU, int DIL>
-static int launch_c64w_t(GemmArgs a, hipStream_t stream) {
+template <bool LRELU, int DIL, int CH>
+static int launch_cw_t(GemmArgs a, hipStream_t stream) {
   constexpr int BME = cw_bme(DIL);
   const int groups = cw_groups(a);
   const int slab_rows = BME + 3 * groups * DIL;
-  const size_t lds = cw_lds(a);
-  SS_MAX_LDS_ONCE((&conv_c64w_kernel<LRELU, DIL>), 96 * 1024);
+  const size_t lds = cw_lds(a, CH);
+  SS_MAX_LDS_ONCE((&conv_c64w_kernel<LRELU, DIL, CH>), CH == 64 ? 96 * 1024 : 160 * 1024);
   SkWorkspace* st = nullptr;                       // (only for the device's CU count, cached per context)
   int rc = sk_workspace_acquire(stream, &st);
   if (rc != SS_OK) return rc;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   const long long max_blocks = (long long)cdiv(a.M, BME) + nseg;      // upper bound (per-segment round-up)
-  const int grid = (int)std::min<long long>(2ll * st->cus, std::max<long long>(1, max_blocks));
+  const int grid = (int)std::min<long long>((CH == 64 ? 2ll : 1ll) * st->cus, std::max<long long>(1, max_blocks));
   ProfRec rec{}; bool prof = false;
-  rc = prof_begin(a, stream, 27, rec, prof);       // census: the conv's algorithmic (direct-form) FLOPs; the kernel issues 4 G / (2 k) of them
+  rc = prof_begin(a, stream, CH == 64 ? 27 : 28, rec, prof);   // census: the conv's algorithmic (direct-form) FLOPs; the kernel issues 4 G / (2 k) of them
   if (rc != SS_OK) return rc;
   a.W = a.Wwino;
-  hipLaunchKernelGGL((conv_c64w_kernel<LRELU, DIL>), dim3(grid), dim3(256), lds, stream, a, groups, slab_rows);
+  hipLaunchKernelGGL((conv_c64w_kernel<LRELU, DIL, CH>), dim3(grid), dim3(CH == 64 ? 256 : 512), lds, stream, a, groups, slab_rows);
   SS_LAUNCH_CHECK();
   return prof_end(stream, rec, prof);
 }
 
-int launch_conv_c64w(const GemmArgs& a, hipStream_t stream) {
-  if (!conv_c64_eligible(a) || !conv_c64w_eligible(a)) return SS_ERR_ARG;
+template <int CH>
+static int launch_cw(const GemmArgs& a, hipStream_t stream) {
   const bool lr = a.in_act == ACT_LRELU;
   switch (a.dil) {
-    case 1: return lr ? launch_c64w_t<true, 1>(a, stream) : launch_c64w_t<false, 1>(a, stream);
-    case 3: return lr ? launch_c64w_t<true, 3>(a, stream) : launch_c64w_t<false, 3>(a, stream);
-    default: return lr ? launch_c64w_t<true, 5>(a, stream) : launch_c64w_t<false, 5>(a, stream);
+    case 1: return lr ? launch_cw_t<true, 1, CH>(a, stream) : launch_cw_t<false, 1, CH>(a, stream);
+    case 3: return lr ? launch_cw_t<true, 3, CH>(a, stream) : launch_cw_t<false, 3, CH>(a, stream);
+    default: return lr ? launch_cw_t<true, 5, CH>(a, stream) : launch_cw_t<false, 5, CH>(a, stream);
   }
+}
+
+int launch_conv_c64w(const GemmArgs& a, hipStream_t stream) {
+  if (!conv_c64_eligible(a) || !conv_c64w_eligible(a)) return SS_ERR_ARG;
+  return launch_cw<64>(a, stream);
+}
+int launch_conv_c128w(const GemmArgs& a, hipStream_t stream) {
+  if (!conv_c128w_eligible(a)) return SS_ERR_ARG;
+  return launch_cw<128>(a, stream);
 }
 
 }  // namespace ss

@@ -61,7 +61,7 @@ struct GemmArgs {
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 28;
+constexpr int kNumTileCfg = 29;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
@@ -143,6 +143,11 @@ int launch_conv_c64w(const GemmArgs& a, hipStream_t stream);
 int launch_wino_pack(const float* W, float* WW, int C, int taps, hipStream_t stream);   // WW: C * ceil(taps/3) * 4 * C floats
 void conv_c64w_debug(int enable);                 // A/B: 0 off, 1 on, -1 keep
 bool conv_c64w_enabled();
+// the same kernel at 128 channels (one workgroup per CU): the 128-channel stage's ResBlock convs instead of conv_sk2<128> + twins
+bool conv_c128w_eligible(const GemmArgs& a);
+int launch_conv_c128w(const GemmArgs& a, hipStream_t stream);
+void conv_c128w_debug(int enable);
+bool conv_c128w_enabled();
 void conv_c64_debug(int enable);          // A/B: 0 routes the stage back to conv_sk2<64> (pre-activated twins), 1 on, -1 keep
 
 // The same for the 32-channel stage (conv_c32.hip): each ResBlock conv as its own launch instead of one fused launch per ResBlock.

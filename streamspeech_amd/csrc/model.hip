@@ -989,12 +989,13 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
   v->post = {w.get("voc.post.w", (int64_t)7 * C), w.get("voc.post.b", 1)};
   if (!w.missing.empty()) { sk_workspace_free(v->skws); delete v; return SS_ERR_MISSING_WEIGHT; }
   {
-    // Winograd forms of the 64-channel stage's ResBlock convs (conv_c64w.hip), made once per context from the packed weights
+    // Winograd forms of the 64- and 128-channel stages' ResBlock convs (conv_c64w.hip), made once per context from the packed weights
+    auto wino_stage = [](int ch) { return ch == 64 || ch == 128; };
     size_t need = 0;
     int Cs = C0;
     for (int i = 0; i < cfg->n_up; ++i) {
       Cs /= 2;
-      if (Cs == 64) for (int j = 0; j < cfg->n_res; ++j) need += 6 * (size_t)64 * ((cfg->resblock_kernel_sizes[j] + 2) / 3) * 4 * 64;
+      if (wino_stage(Cs)) for (int j = 0; j < cfg->n_res; ++j) need += 6 * (size_t)Cs * ((cfg->resblock_kernel_sizes[j] + 2) / 3) * 4 * Cs;
     }
     if (need) {
       rc = v->wino.ensure(need * sizeof(float));
@@ -1003,15 +1004,15 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
       Cs = C0;
       for (int i = 0; i < cfg->n_up && rc == SS_OK; ++i) {
         Cs /= 2;
-        if (Cs != 64) continue;
+        if (!wino_stage(Cs)) continue;
         for (int j = 0; j < cfg->n_res && rc == SS_OK; ++j) {
           const int kr = cfg->resblock_kernel_sizes[j];
-          const size_t n = (size_t)64 * ((kr + 2) / 3) * 4 * 64;
+          const size_t n = (size_t)Cs * ((kr + 2) / 3) * 4 * Cs;
           for (int dd = 0; dd < 3 && rc == SS_OK; ++dd) {
             const int idx = (i * cfg->n_res + j) * 3 + dd;
-            rc = launch_wino_pack(v->rb_c1[idx].w, dst, 64, kr, nullptr);
+            rc = launch_wino_pack(v->rb_c1[idx].w, dst, Cs, kr, nullptr);
             v->rb_c1[idx].ww = dst; dst += n;
-            if (rc == SS_OK) rc = launch_wino_pack(v->rb_c2[idx].w, dst, 64, kr, nullptr);
+            if (rc == SS_OK) rc = launch_wino_pack(v->rb_c2[idx].w, dst, Cs, kr, nullptr);
             v->rb_c2[idx].ww = dst; dst += n;
           }
         }
@@ -1072,7 +1073,34 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
     return channels == 64 ? conv_c64_eligible(probe) : channels == 32 ? conv_c32_eligible(probe) : conv_c16_eligible(probe);
   };
   const bool c64 = slab_stage(64), c32 = slab_stage(32), c16 = slab_stage(16);
-  auto preact = [c64](int channels) { return channels >= 64 && !(c64 && channels == 64); };
+  // The 128-channel stage of a packed batch: its ResBlock convs in Winograd form on the slab kernel (conv_c64w.hip at 128 channels), which
+  // activates while staging -- so the convs of that stage neither read nor write twins; only the up-conv that LEAVES the stage (on conv_sk2)
+  // still reads one, written by the stage's last conv.  Taken only if every conv of the stage is eligible (there is no direct slab form).
+  const bool c128 = [&]() {
+    if (v->x3 || !conv_c128w_enabled()) return false;
+    long long rows = Ft; int ch = c.upsample_initial_channel, stage = -1;
+    for (int i = 0; i < c.n_up && stage < 0; ++i) { rows *= c.upsample_rates[i]; ch /= 2; if (ch == 128) stage = i; }
+    if (stage < 0 || rows >= (1ll << 30)) return false;
+    int sc = 1, gM = 0, gnseg = 0; const int* gsegs = nullptr;
+    for (int i = 0; i <= stage; ++i) sc *= c.upsample_rates[i];
+    geom(sc, gM, gsegs, gnseg);                              // the row geometry the stage's launches will carry
+    for (int j = 0; j < c.n_res; ++j)
+      for (int dd = 0; dd < 3; ++dd)
+        for (int which = 0; which < 2; ++which) {
+          const int idx = (stage * c.n_res + j) * 3 + dd;
+          GemmArgs probe;
+          probe.same_rows = 1; probe.Cin = probe.N = probe.lda = probe.ldc = probe.ldr = probe.ldr2 = probe.ldc2 = 128;
+          probe.taps = c.resblock_kernel_sizes[j]; probe.dil = which ? 1 : c.resblock_dilations[j][dd];
+          probe.pad = probe.dil * (probe.taps - 1) / 2; probe.M = probe.in_len = gM; probe.nseg = gnseg; probe.in_act = ACT_LRELU;
+          probe.Wwino = which ? v->rb_c2[idx].ww : v->rb_c1[idx].ww;
+          if (!conv_c128w_eligible(probe)) return false;
+        }
+    return true;
+  }();
+  // does a ResBlock conv of this stage read a pre-activated twin?  (does the producer have to write one?)
+  auto preact = [c64, c128](int channels) { return channels >= 64 && !(c64 && channels == 64) && !(c128 && channels == 128); };
+  // the up-conv that leaves a stage runs on conv_sk2 for >= 128 channels (N = stride x C / 2) and on conv_c64 for the 64-channel stage
+  auto up_preact = [c64](int channels) { return channels >= 64 && !(c64 && channels == 64); };
   auto mk = [v](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
     GemmArgs a;
     a.A = A; a.lda = Cin; a.W = cw.w; a.Wwino = cw.ww; a.bias = cw.b; a.C = Cc; a.ldc = ldc; a.ldr = ldc; a.ldr2 = ldc; a.ldc2 = ldc;
@@ -1084,12 +1112,12 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
   RET(on_stage(scale));
   {
     GemmArgs a = mk(frames, c.model_in_dim, v->pre, C, 7, 1, b.bx, C);
-    if (preact(C)) a.C2 = b.bxa;
+    if (up_preact(C)) a.C2 = b.bxa;
     RET(conv(a, scale));
   }
   for (int i = 0; i < c.n_up; ++i) {
     const int st = c.upsample_rates[i], Co = C / 2;
-    const bool pa_in = preact(C), pa = preact(Co);
+    const bool pa_in = up_preact(C), pa = preact(Co);
     {
       // leaky_relu(0.1) -> ConvTranspose1d as a 3-tap polyphase conv with N = st*Co: row q of the
       // [T, st*Co] result is rows q*st .. q*st+st-1 of the [T*st, Co] signal.
@@ -1101,7 +1129,7 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
     }
     scale *= st; C = Co;
     RET(on_stage(scale));
-    const bool pa_next = (i + 1 < c.n_up) && preact(C);     // the next up-conv reads leaky_relu(x)
+    const bool pa_next = (i + 1 < c.n_up) && up_preact(C);  // the next up-conv reads leaky_relu(x)
     for (int j = 0; j < c.n_res; ++j) {
       const int kr = c.resblock_kernel_sizes[j];
       // narrow stages: each (dilated conv, plain conv, residual) pair as ONE launch with the intermediate in LDS
@@ -1691,9 +1719,10 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
   a.same_rows = (stride == 1 && M == in_len) ? 1 : 0;
   // unit-test path of the Winograd form (the model makes the transformed weights once per context): made here per call
   static thread_local DevBuf wino_tmp;
-  if (conv_c64w_enabled() && N == 64 && Cin == 64 && taps >= 3 && conv_c64_eligible(a)) {
-    RET(wino_tmp.ensure((size_t)64 * ((taps + 2) / 3) * 4 * 64 * sizeof(float)));
-    RET(launch_wino_pack(dW, wino_tmp.f(), 64, taps, (hipStream_t)stream));
+  if ((conv_c64w_enabled() && N == 64 && Cin == 64 && taps >= 3 && conv_c64_eligible(a)) ||
+      (conv_c128w_enabled() && N == 128 && Cin == 128 && taps >= 3 && a.same_rows && !glu)) {
+    RET(wino_tmp.ensure((size_t)N * ((taps + 2) / 3) * 4 * N * sizeof(float)));
+    RET(launch_wino_pack(dW, wino_tmp.f(), N, taps, (hipStream_t)stream));
     a.Wwino = wino_tmp.f();
   }
   return launch_conv_gemm(a, (hipStream_t)stream);
@@ -1723,9 +1752,11 @@ extern "C" int ss_op_ln_linear(void* stream, const float* dX, int ldx, const flo
   a.ln_g = ln_g; a.ln_b = ln_b;
   return launch_conv_gemm(a, (hipStream_t)stream);       // SS_ERR_ARG when no kernel with a LayerNorm prologue takes the shape
 }
-// enable 0 / 1: the stage on conv_sk2<64> / on the slab kernels; 4 / 5: its Winograd form (conv_c64w.hip) off / on (the slab kernels stay on)
+// enable 0 / 1: the stage on conv_sk2<64> / on the slab kernels; 4 / 5: its Winograd form (conv_c64w.hip) off / on (the slab kernels stay on);
+// 6 / 7: the 128-channel stage on conv_sk2<128> / on the Winograd slab kernel
 extern "C" int ss_debug_conv_c64(int enable) {
   if (enable == 4 || enable == 5) { conv_c64w_debug(enable == 5); return SS_OK; }
+  if (enable == 6 || enable == 7) { conv_c128w_debug(enable == 7); return SS_OK; }     // the 128-channel stage: conv_sk2<128> + twins / Winograd slab
   conv_c64_debug(enable);
   return SS_OK;
 }
