@@ -806,7 +806,7 @@ def main():
             return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4), **common}
         ach = fl / (ms * 1e-3) / 1e12
-        if name.startswith(("conv_c64w", "conv_c128w")):
+        if name.startswith(("conv_c64w", "conv_c128w", "conv_c32w")):
             # Winograd F(2,3) forms (csrc/conv_c64w.hip, 64 and 128 channels): the census counts the conv's ALGORITHMIC (direct-form) FLOPs, as for every
             # class; the kernel issues only 4 ceil(k/3) / (2 k) of them as MFMAs (2/3 at k = 3, 6/7 at k = 7, 8/11 at k = 11), so
             # `frac` here can pass the rate the matrix cores sustain on the direct form -- it is not their busy fraction

@@ -258,7 +258,8 @@ int ss_debug_rtlin(int grid, int enable);
  * (csrc/conv_c64w.hip) off / on without touching the first setting; 6 / 7 route the 128-channel stage's ResBlock convs to conv_sk2<128>
  * with twins / to the same Winograd kernel at 128 channels. */
 int ss_debug_conv_c64(int enable);
-/* The same for the 32-channel stage (csrc/conv_c32.hip): 0 = one fused launch per ResBlock (round 3), 1 = one launch per conv. */
+/* The same for the 32-channel stage (csrc/conv_c32.hip): 0 = one fused launch per ResBlock (round 3), 1 = one launch per conv;
+ * 4 / 5 = the Winograd form of those per-conv launches (csrc/conv_c64w.hip at 32 channels) off / on. */
 int ss_debug_conv_c32(int enable);
 int ss_debug_conv_c16(int enable);       /* ... and for the 16-channel stage (csrc/conv_c16.hip) */
 /* Unit-test entry of the LayerNorm-prologue linears (what ln_linear() in model.hip issues for QKV / pointwise conv 1 / the FFNs

@@ -60,18 +60,19 @@ __global__ void wino_pack_kernel(const float* __restrict__ W, float* __restrict_
 // each SIMD still holds two waves that hide each other's fragment latency (a 64-tile accumulator set per wave made hipcc shuffle
 // accumulators between register classes inside the loop: 1300 moves per 2048 MFMAs, 200+ spills).
 template <bool LRELU, int DIL, int CH>
-__global__ __launch_bounds__(CH == 64 ? 256 : 512, CH == 64 ? 2 : 1) void conv_c64w_kernel(const GemmArgs p, const int groups, const int slab_rows) {
+__global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2 : 3) void conv_c64w_kernel(const GemmArgs p, const int groups, const int slab_rows) {
 #if __HIP_DEVICE_COMPILE__
-  constexpr int C = CH, LDA = CH + 4, CT = 4, CB = CH / 16, NSS = CB * 4, RING = 2 * CT, TPR = CH / 4;   // TPR threads stage one row
-  constexpr int NT = CH == 64 ? 256 : 512, RPP = NT / TPR;                  // rows per staging pass (16)
-  constexpr int NP = (CW_MAXROWS + RPP - 1) / RPP, BME = cw_bme(DIL), NPAIR = BME / 2;
+  // (CH = 32: the k = 11 ResBlock convs of the 32-channel stage, three workgroups per CU: 2 column tiles, 16 MFMAs per sub-step)
+  constexpr int C = CH, LDA = CH + 4, CT = CH >= 64 ? 4 : CH / 16, CB = CH / 16, NSS = CB * 4, RING = 2 * CT, TPR = CH / 4;   // TPR threads stage one row
+  constexpr int NT = CH == 128 ? 512 : 256, RPP = NT / TPR;                 // rows per staging pass (16; 32 at 32 channels)
+  constexpr int NP = (CW_MAXROWS + RPP - 1) / RPP, NPC = NP < 20 ? NP : 20, BME = cw_bme(DIL), NPAIR = BME / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                                                        // slab [slab_rows][68]
   int* s_blk = reinterpret_cast<int*>(smem + ((slab_rows * LDA + 3) & ~3));   // block prefix per segment
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane((t >> 6) & 3);
-  const int cs = CH == 64 ? 0 : __builtin_amdgcn_readfirstlane(t >> 8);     // column set of this wave
+  const int cs = CH <= 64 ? 0 : __builtin_amdgcn_readfirstlane(t >> 8);     // column set of this wave
   const int r = lane & 15, g = lane >> 4;
   const int Kw = groups * 4 * C;                                           // row length of the transformed weight matrix
 
@@ -131,17 +132,17 @@ __global__ __launch_bounds__(CH == 64 ? 256 : 512, CH == 64 ? 2 : 1) void conv_c
     __syncthreads();                                       // previous block's slab reads are done
     // ---- slab: global -> registers -> [zero padding, leaky-ReLU] -> LDS (as conv_c64.hip), 20 float4 per thread in flight at a time ----
 #pragma unroll 1
-    for (int u0 = 0; u0 < NP; u0 += 20) {
-      f32x4 pre[20];
+    for (int u0 = 0; u0 < NP; u0 += NPC) {
+      f32x4 pre[NPC];
 #pragma unroll
-      for (int u = 0; u < 20; ++u) {
+      for (int u = 0; u < NPC; ++u) {
         const int rho = t / TPR + RPP * (u0 + u);
         const int gc = min(max(m0 - p.pad + rho, seg_lo), seg_hi - 1);
         pre[u] = *reinterpret_cast<const f32x4*>(p.A + (size_t)gc * p.lda + (t % TPR) * 4);
       }
       float* dst = sA + (t / TPR + RPP * u0) * LDA + (t % TPR) * 4;
 #pragma unroll
-      for (int u = 0; u < 20; ++u) {
+      for (int u = 0; u < NPC; ++u) {
         const int rho = t / TPR + RPP * (u0 + u);
         f32x4 v = pre[u];
         if (edge) {
@@ -330,18 +331,18 @@ static int launch_cw_t(GemmArgs a, hipStream_t stream) {
   const int groups = cw_groups(a);
   const int slab_rows = BME + 3 * groups * DIL;
   const size_t lds = cw_lds(a, CH);
-  SS_MAX_LDS_ONCE((&conv_c64w_kernel<LRELU, DIL, CH>), CH == 64 ? 96 * 1024 : 160 * 1024);
+  SS_MAX_LDS_ONCE((&conv_c64w_kernel<LRELU, DIL, CH>), CH == 128 ? 160 * 1024 : 96 * 1024);
   SkWorkspace* st = nullptr;                       // (only for the device's CU count, cached per context)
   int rc = sk_workspace_acquire(stream, &st);
   if (rc != SS_OK) return rc;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   const long long max_blocks = (long long)cdiv(a.M, BME) + nseg;      // upper bound (per-segment round-up)
-  const int grid = (int)std::min<long long>((CH == 64 ? 2ll : 1ll) * st->cus, std::max<long long>(1, max_blocks));
+  const int grid = (int)std::min<long long>((CH == 128 ? 1ll : CH == 64 ? 2ll : 3ll) * st->cus, std::max<long long>(1, max_blocks));
   ProfRec rec{}; bool prof = false;
-  rc = prof_begin(a, stream, CH == 64 ? 27 : 28, rec, prof);   // census: the conv's algorithmic (direct-form) FLOPs; the kernel issues 4 G / (2 k) of them
+  rc = prof_begin(a, stream, CH == 64 ? 27 : CH == 128 ? 28 : 29, rec, prof);   // census: the conv's algorithmic (direct-form) FLOPs; the kernel issues 4 G / (2 k) of them
   if (rc != SS_OK) return rc;
   a.W = a.Wwino;
-  hipLaunchKernelGGL((conv_c64w_kernel<LRELU, DIL, CH>), dim3(grid), dim3(CH == 64 ? 256 : 512), lds, stream, a, groups, slab_rows);
+  hipLaunchKernelGGL((conv_c64w_kernel<LRELU, DIL, CH>), dim3(grid), dim3(CH == 128 ? 512 : 256), lds, stream, a, groups, slab_rows);
   SS_LAUNCH_CHECK();
   return prof_end(stream, rec, prof);
 }
@@ -359,6 +360,20 @@ static int launch_cw(const GemmArgs& a, hipStream_t stream) {
 int launch_conv_c64w(const GemmArgs& a, hipStream_t stream) {
   if (!conv_c64_eligible(a) || !conv_c64w_eligible(a)) return SS_ERR_ARG;
   return launch_cw<64>(a, stream);
+}
+// The 32-channel stage's per-conv launches (model.hip: k >= 11) -- the convs conv_c32.hip takes, with transformed weights
+static int g_c32w_on = getenv("SS_CONV_C32_WINOGRAD") ? atoi(getenv("SS_CONV_C32_WINOGRAD")) : 1;
+void conv_c32w_debug(int enable) { if (enable >= 0) g_c32w_on = enable ? 1 : 0; }
+bool conv_c32w_enabled() { return g_c32w_on != 0; }
+bool conv_c32w_eligible(const GemmArgs& a) {                 // call with conv_c32_eligible(a) already true
+  if (!g_c32w_on || !a.Wwino || a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.C2) return false;
+  if (a.pad != a.dil * (a.taps - 1) / 2) return false;
+  const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
+  return slab_rows <= CW_MAXROWS && 3 * cw_lds(a, 32) <= 158 * 1024;
+}
+int launch_conv_c32w(const GemmArgs& a, hipStream_t stream) {
+  if (!conv_c32_eligible(a) || !conv_c32w_eligible(a)) return SS_ERR_ARG;
+  return launch_cw<32>(a, stream);
 }
 int launch_conv_c128w(const GemmArgs& a, hipStream_t stream) {
   if (!conv_c128w_eligible(a)) return SS_ERR_ARG;

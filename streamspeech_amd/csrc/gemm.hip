@@ -630,7 +630,7 @@ static const char* kTileNames[kNumTileCfg] = {
     "conv_slab<32>", "conv_slab<16>", "conv_sk2<256,128,32>", "conv_sk2_bf16x3<256,128,32>",
     // whole-ResBlock launches of the narrow vocoder stages (resblock.hip) and the fused encoder FFN (ffn.hip): kernels of their own,
     // booked under their own names (round 3 booked resblock_fused under conv_slab<..>: VERDICT r3 "mislabelled second kernel")
-    "resblock_fused<32>", "resblock_fused<16>", "ffn_fused<256,2048>", "rt_linear<48,256>", "conv_c64<256,64>", "conv_c32<256,32>", "conv_c16<256,16>", "conv_c64w<256,64>", "conv_c128w<256,128>"};
+    "resblock_fused<32>", "resblock_fused<16>", "ffn_fused<256,2048>", "rt_linear<48,256>", "conv_c64<256,64>", "conv_c32<256,32>", "conv_c16<256,16>", "conv_c64w<256,64>", "conv_c128w<256,128>", "conv_c32w<256,32>"};
 static int g_prof_mask = 0;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
@@ -901,7 +901,7 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   // 64-channel vocoder stage of a packed batch: input slab in LDS once, W fragments from L2 (conv_c64.hip)
   if (!g_force_bm && conv_c64_eligible(a)) return conv_c64w_eligible(a) ? launch_conv_c64w(a, stream) : launch_conv_c64(a, stream);
   if (!g_force_bm && conv_c128w_eligible(a)) return launch_conv_c128w(a, stream);
-  if (!g_force_bm && conv_c32_eligible(a)) return launch_conv_c32(a, stream);
+  if (!g_force_bm && conv_c32_eligible(a)) return conv_c32w_eligible(a) ? launch_conv_c32w(a, stream) : launch_conv_c32(a, stream);
   if (!g_force_bm && conv_c16_eligible(a)) return launch_conv_c16(a, stream);
   // K = 256 linears of packed batches (encoder projections, CTC heads, cross K|V): row tile in LDS, W fragments from L2 (rtlin.hip)
   if (!g_force_bm && rtlin_eligible(a)) return launch_rtlin(a, stream);

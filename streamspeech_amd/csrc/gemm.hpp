@@ -61,7 +61,7 @@ struct GemmArgs {
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 29;
+constexpr int kNumTileCfg = 30;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
@@ -148,6 +148,11 @@ bool conv_c128w_eligible(const GemmArgs& a);
 int launch_conv_c128w(const GemmArgs& a, hipStream_t stream);
 void conv_c128w_debug(int enable);
 bool conv_c128w_enabled();
+// ... and at 32 channels (three workgroups per CU): the per-conv launches of the 32-channel stage (k = 11)
+bool conv_c32w_eligible(const GemmArgs& a);       // call with conv_c32_eligible(a) already true
+int launch_conv_c32w(const GemmArgs& a, hipStream_t stream);
+void conv_c32w_debug(int enable);
+bool conv_c32w_enabled();
 void conv_c64_debug(int enable);          // A/B: 0 routes the stage back to conv_sk2<64> (pre-activated twins), 1 on, -1 keep
 
 // The same for the 32-channel stage (conv_c32.hip): each ResBlock conv as its own launch instead of one fused launch per ResBlock.

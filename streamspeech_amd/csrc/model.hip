@@ -989,8 +989,8 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
   v->post = {w.get("voc.post.w", (int64_t)7 * C), w.get("voc.post.b", 1)};
   if (!w.missing.empty()) { sk_workspace_free(v->skws); delete v; return SS_ERR_MISSING_WEIGHT; }
   {
-    // Winograd forms of the 64- and 128-channel stages' ResBlock convs (conv_c64w.hip), made once per context from the packed weights
-    auto wino_stage = [](int ch) { return ch == 64 || ch == 128; };
+    // Winograd forms of the 32-, 64- and 128-channel stages' ResBlock convs (conv_c64w.hip), made once per context from the packed weights
+    auto wino_stage = [](int ch) { return ch == 32 || ch == 64 || ch == 128; };
     size_t need = 0;
     int Cs = C0;
     for (int i = 0; i < cfg->n_up; ++i) {
@@ -1720,7 +1720,8 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
   // unit-test path of the Winograd form (the model makes the transformed weights once per context): made here per call
   static thread_local DevBuf wino_tmp;
   if ((conv_c64w_enabled() && N == 64 && Cin == 64 && taps >= 3 && conv_c64_eligible(a)) ||
-      (conv_c128w_enabled() && N == 128 && Cin == 128 && taps >= 3 && a.same_rows && !glu)) {
+      (conv_c128w_enabled() && N == 128 && Cin == 128 && taps >= 3 && a.same_rows && !glu) ||
+      (conv_c32w_enabled() && N == 32 && Cin == 32 && taps >= 3 && conv_c32_eligible(a))) {
     RET(wino_tmp.ensure((size_t)N * ((taps + 2) / 3) * 4 * N * sizeof(float)));
     RET(launch_wino_pack(dW, wino_tmp.f(), N, taps, (hipStream_t)stream));
     a.Wwino = wino_tmp.f();
@@ -1760,7 +1761,11 @@ extern "C" int ss_debug_conv_c64(int enable) {
   conv_c64_debug(enable);
   return SS_OK;
 }
-extern "C" int ss_debug_conv_c32(int enable) { conv_c32_debug(enable); return SS_OK; }
+extern "C" int ss_debug_conv_c32(int enable) {      // 0 / 1: the per-conv slab kernel off / on; 4 / 5: its Winograd form off / on
+  if (enable == 4 || enable == 5) { conv_c32w_debug(enable == 5); return SS_OK; }
+  conv_c32_debug(enable);
+  return SS_OK;
+}
 extern "C" int ss_debug_conv_c16(int enable) { conv_c16_debug(enable); return SS_OK; }
 extern "C" int ss_debug_rtlin(int grid, int enable) {
   if (grid < 0) return SS_ERR_ARG;

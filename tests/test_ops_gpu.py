@@ -477,7 +477,7 @@ def test_conv_c64_slab_kernel(lib, C_, taps, dil, M, lrelu, extras):
     y = F.conv1d(xin_p, w.double(), b.double(), dilation=dil)[0].t()
     ref = ((R2.double() + (y + R.double())) / 3.0) if extras else y
     kw = dict(taps=taps, dil=dil, pad=pad, in_act=3 if lrelu else 0, slope=0.1, R=R, R2=R2, div=3.0 if extras else 0.0)
-    if C == 64:
+    if C in (64, 32):
         dbg(4)                    # the direct form first; the Winograd form of the same launch (conv_c64w.hip) below
     n0 = _class_launches_ops(lib, cls)
     got = run_conv_gemm(lib, x, conv_tap_major(w), b, M, C, C, **kw)
@@ -491,14 +491,15 @@ def test_conv_c64_slab_kernel(lib, C_, taps, dil, M, lrelu, extras):
         dbg(1)
     assert _class_launches_ops(lib, cls) == n0 + 1
     assert (got - old).abs().max() < 2e-5
-    if C == 64:
+    if C in (64, 32):
         # Winograd F(2,3) on the dilation lattice: every k >= 3 conv whose slab fits two per CU (not k = 11 at dilation 5); pairs (t, t + d)
-        # of 256- / 252- / 240-row blocks, ragged last block, residual / MRF epilogue on both rows of a pair
-        takes = taps >= 3 and not (taps == 11 and dil == 5) and not (taps == 7 and dil == 5)      # (k = 7 at dilation 5: measured slower, stays direct)
+        # of 256- / 252- / 240-row blocks, ragged last block, residual / MRF epilogue on both rows of a pair.  32 channels: every k >= 3.
+        takes = taps >= 3 and (C == 32 or (not (taps == 11 and dil == 5) and not (taps == 7 and dil == 5)))      # (64 channels, k = 7 at dilation 5: measured slower, stays direct)
+        wcls = "conv_c64w<256,64>" if C == 64 else "conv_c32w<256,32>"
         dbg(5)
-        nw = _class_launches_ops(lib, "conv_c64w<256,64>")
+        nw = _class_launches_ops(lib, wcls)
         gotw = run_conv_gemm(lib, x, conv_tap_major(w), b, M, C, C, **kw)
-        assert _class_launches_ops(lib, "conv_c64w<256,64>") == nw + (1 if takes else 0)
+        assert _class_launches_ops(lib, wcls) == nw + (1 if takes else 0)
         assert _class_launches_ops(lib, cls) == n0 + (1 if takes else 2)
         assert torch.isfinite(gotw).all()
         assert (gotw.double() - ref).abs().max() < TOL, f"max err {(gotw.double() - ref).abs().max()}"

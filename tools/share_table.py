@@ -11,6 +11,7 @@ CLASSES = [("conv_sk2<256,128,32>", ["void ss::conv_sk2_kernel"]),
            ("conv_sk<128,BN,32>", ["void ss::conv_sk_kernel"]),
            ("conv_c64<256,64>", ["void ss::conv_c64_kernel"]),
            ("conv_c64w<256,64>", ["void ss::conv_c64w_kernel<true, 1, 64", "void ss::conv_c64w_kernel<true, 3, 64", "void ss::conv_c64w_kernel<true, 5, 64", "void ss::conv_c64w_kernel<false, 1, 64", "void ss::conv_c64w_kernel<false, 3, 64", "void ss::conv_c64w_kernel<false, 5, 64"]),
+           ("conv_c32w<256,32>", ["void ss::conv_c64w_kernel<true, 1, 32", "void ss::conv_c64w_kernel<true, 3, 32", "void ss::conv_c64w_kernel<true, 5, 32", "void ss::conv_c64w_kernel<false, 1, 32", "void ss::conv_c64w_kernel<false, 3, 32", "void ss::conv_c64w_kernel<false, 5, 32"]),
            ("conv_c128w<256,128>", ["void ss::conv_c64w_kernel<true, 1, 128", "void ss::conv_c64w_kernel<true, 3, 128", "void ss::conv_c64w_kernel<true, 5, 128", "void ss::conv_c64w_kernel<false, 1, 128", "void ss::conv_c64w_kernel<false, 3, 128", "void ss::conv_c64w_kernel<false, 5, 128"]),
            ("conv_c32<256,32>", ["void ss::conv_c32_kernel"]),
            ("conv_c16<256,16>", ["void ss::conv_c16_kernel"]),
