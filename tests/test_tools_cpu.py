@@ -73,3 +73,25 @@ def test_roofline_table_reads_rocprofv3_kernel_stats(tmp_path):
     assert len(rows) == 2
     assert "conv_sk2_kernel<128, false, false>" in rows[0] and "| 10 | 300.0 | 75.0 | 300.0 | 1000 | 0.12 | 62.0 |" in rows[0]
     assert "conv_slab_kernel<32, 32, true>" in rows[1] and rows[1].rstrip().endswith("| — | — | — | — |")
+
+
+def test_winograd_restatement_equals_the_direct_conv():
+    """tools/winograd_error.py: the float32 Winograd F(2,3) form on the dilation lattice (tap groups accumulated in the transform domain,
+    the algorithm of csrc/conv_c64w.hip) reproduces the direct dilated conv for every (k, dilation) of the vocoder, odd lengths included,
+    and the pmc_traffic class split of the one kernel template by its channel argument."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import winograd_error as W
+    torch.manual_seed(1)
+    for k in (3, 7, 11):
+        for dil in (1, 3, 5):
+            x = torch.randn(8, 203)
+            w = torch.randn(8, 8, k) * (8 * k) ** -0.5
+            ref = W.direct(x, w, dil, torch.float64)
+            got = W.winograd23(x, w, dil)
+            assert got.shape == ref.shape
+            assert W.rel(got, ref) < 1e-6, (k, dil, W.rel(got, ref))
+            assert W.rel(W.direct(x, w, dil, torch.float32), ref) < 1e-6
+    import re
+    name = "void ss::conv_c64w_kernel<true, 3, 128>(ss::GemmArgs, int, int)"
+    assert re.search(r"conv_c64w_kernel<(true|false), \d+, (\d+)>", name).group(2) == "128"
