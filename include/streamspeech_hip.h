@@ -233,6 +233,21 @@ int ss_prof_totals(int cls, double* h_flops_total, double* h_bytes_total, int64_
 int ss_prof_num_classes(void);
 const char* ss_prof_class_name(int cls);
 
+/* Pack-invariant arithmetic of the ragged-batch twins (default on; SS_PACK_INVARIANT=0 at context creation or on = 0 here switch it
+ * off).  The reference decodes ONE utterance per call (agent/speech_to_speech.streamspeech.agent.py:425-478), so an utterance's ids
+ * cannot depend on what else is being decoded.  With on = 1 every stage of ss_batch_encoder_forward / ss_batch_ctc_greedy /
+ * ss_batch_mt_greedy / ss_batch_t2u_units computes a packed utterance with a summation order that is a function of that utterance
+ * alone: every GEMM is one accumulator chain per output element over ascending k (LDS-tiled kernel without split-K, the row-tile
+ * kernel, stream-K cut on whole tiles: the same bits), the fused FFN computes every row tile whole in one workgroup, the LayerNorm
+ * form and the attention kernel are fixed per layer, the lock-step MT decode uses one split-K form per layer shape -- so the
+ * logits of an utterance are bit-identical alone, in any pack and at any position of a pack (tests/test_margin_gpu.py,
+ * tests/test_pack_invariance_gpu.py).  on = 0: the fastest kernel for each launch's row count (stream-K k-splits, split-K tiles). */
+int ss_model_set_pack_invariant(ss_model* m, int on);
+int ss_model_get_pack_invariant(ss_model* m);
+/* Test hook: arithmetic mode of the ss_op_* entry points called from the calling thread -- 0 the fastest kernel per shape, 1 the
+ * pack-invariant one-chain form, 2 the fixed small-M form of the lock-step decode rows (the model entry points set their own). */
+int ss_debug_canon(int mode);
+
 /* Test hook (tests/test_margin_gpu.py): the dense logits [rows, cols] the LAST ss_batch_ctc_greedy / ss_batch_t2u_units call of
  * this context took its arg-max over (they live in the context's scratch until the next call that reuses it).  d_out == NULL:
  * size query only.  Lets a test measure top-1 / top-2 margins of the packed-batch path against the single-utterance path. */
@@ -246,8 +261,8 @@ int ss_debug_last_logits(ss_model* m, void* stream, float* d_out, int64_t cap_fl
 int ss_op_ffn_fused(void* stream, const float* dX, int ldx, float* dY, int ldy, const float* ln_g, const float* ln_b,
                     const float* dW1, const float* db1, const float* dW2, const float* db2, float alpha,
                     const float* ln2_g, const float* ln2_b, int M, int D, int F);
-/* A/B + test hook of the same kernel: grid > 0 fixes its workgroup count (0: heuristic); row_tiles_per_wave 3 | 4 picks 48- or
- * 64-row tiles (0: keep); enable 0 / 1 switches its use by ss_batch_encoder_forward off / on (-1: keep). */
+/* A/B + test hook of the same kernel: grid > 0 fixes its workgroup count (0: heuristic); row_tiles_per_wave 1..4 forces 16- .. 64-row
+ * tiles (0: back to the default: 48 rows, or the pack-invariant form's own choice); enable 0 / 1 switches its use by ss_batch_encoder_forward off / on (-1: keep). */
 int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable);
 /* A/B + test hook of the row-tile linear kernel (csrc/rtlin.hip: every K = 256 linear of more than 192 rows that goes through
  * ss_op_conv_gemm / the model entry points): grid > 0 fixes its workgroup count (0: heuristic); enable 0 / 1 routes those linears

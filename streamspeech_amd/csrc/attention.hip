@@ -622,7 +622,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if ((a.ldk & 3) || (a.ldv & 3)) return SS_ERR_ARG;
   const int gz = a.nseg > 0 ? a.nseg : 1;
   if (a.q0 != 0 && (a.nseg > 0 || a.causal)) return SS_ERR_ARG;
-  if (!a.P && tq <= 8 && a.q0 == 0) {
+  if (!a.P && tq <= 8 && a.q0 == 0 && !a.no_decode_kernel) {
     hipLaunchKernelGGL(attention_decode_kernel, dim3(tq, a.H, gz), dim3(256), 0, stream, a);
     SS_LAUNCH_CHECK();
     return SS_OK;

@@ -36,6 +36,10 @@ struct AttnArgs {
   unsigned* cnt = nullptr;     // [cnt_slots] arrivals per (query tile, head); zero between launches
   int part_slots = 0, cnt_slots = 0;
   int ksplit = 0, ktiles_per_split = 0;   // filled in by launch_attention
+  // Kernel choice for plain (no rel-pos) attention.  0: by query count (the decode kernel up to 8 queries); 1: always the MFMA tile
+  // kernel -- ragged batches whose max_q depends on the pack (T2U encoder rows) must not change kernels with it (pack-invariant bits);
+  // the lock-step MT decode (max_q = 1 by construction) keeps 0.
+  int no_decode_kernel = 0;
 };
 constexpr int ATTN_PART_FLOATS = 5 * 256 * 4;   // 5 b128 per thread: o[4], {m, l, -, -}
 constexpr int ATTN_PART_SLOTS = 512, ATTN_CNT_SLOTS = 512;

@@ -147,7 +147,11 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   const int tiles_n = p.N / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const long long U = (long long)tiles_m * tiles_n * nk;
-  const long long u0 = (long long)w * U / q.G, u1 = (long long)(w + 1) * U / q.G;
+  long long u0 = (long long)w * U / q.G, u1 = (long long)(w + 1) * U / q.G;
+  if (p.canon) {       // pack-invariant form: ranges end on tile boundaries, every tile is ONE k-chain (no partial is ever parked)
+    const long long T = (long long)tiles_m * tiles_n;
+    u0 = ((long long)w * T / q.G) * nk; u1 = ((long long)(w + 1) * T / q.G) * nk;
+  }
   if (u1 <= u0) return;
   const int t_first = (int)(u0 / nk), t_last = (int)((u1 - 1) / nk);
 
@@ -641,6 +645,7 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   long long G = g_force > 0 ? g_force : cus;        // one workgroup per CU (147 | 123 KB of LDS each), all resident
   if (G > cus) G = cus;
   if (G > U / 4) G = U / 4;                         // at least 4 k-steps per workgroup
+  if (a.canon && G > U / nk) G = U / nk;            // whole tiles per workgroup
   if (G < 1) G = 1;
   Sk2Args q;
   q.ws = st->ws; q.sync = st->sync2; q.G = (int)G; q.dbg = nullptr;

@@ -29,6 +29,7 @@
 // the association order of the 2048-term hidden sum.
 #include "gemm.hpp"
 
+#include <cstdio>
 #include <cstdlib>
 
 // Without a fence per step hipcc sinks every weight load to just before its first use (one step = 400-500 cycles ahead instead
@@ -68,6 +69,7 @@ struct FfnKArgs {
   const float *ln_g, *ln_b, *W1, *b1, *W2, *b2, *ln2_g, *ln2_b;
   float alpha;
   int M, F, G;
+  int canon;              // != 0: ranges end on tile boundaries -- every row tile is computed whole by one workgroup (pack-invariant bits)
   int zero;               // 0 at run time, opaque at compile time (see xoff in the unit loop)
   float* ws;              // [2 G][64 x 256] parked partials: slot 2 w (+1: the workgroup's second incomplete tile)
   unsigned* cnt;          // [tiles] arrival counters, zero between launches
@@ -76,7 +78,7 @@ struct FfnKArgs {
 }  // namespace
 
 template <int WMT>
-__global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnKArgs p) {
+__global__ __launch_bounds__(256, WMT <= 2 ? 2 : 1) void ffn_fused_kernel(const FfnKArgs p) {
 #if __HIP_DEVICE_COMPILE__
   constexpr int FF_BM = 16 * WMT;
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -91,7 +93,10 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnKArgs p) {
   const int F = p.F, UT = F / FF_UN;
   const int tiles = (p.M + FF_BM - 1) / FF_BM;
   const long long U = (long long)tiles * UT;
-  const long long u0 = (long long)w * U / p.G, u1 = (long long)(w + 1) * U / p.G;
+  long long u0 = (long long)w * U / p.G, u1 = (long long)(w + 1) * U / p.G;
+  if (p.canon) {        // whole tiles: wave w of the owner contracts hidden units [UT/4 w, UT/4 (w+1)) of every row, whatever M and G are
+    u0 = ((long long)w * tiles / p.G) * UT; u1 = ((long long)(w + 1) * tiles / p.G) * UT;
+  }
   if (u1 <= u0) return;
   const int t_first = (int)(u0 / UT), t_last = (int)((u1 - 1) / UT);
 
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(256, 1) void ffn_fused_kernel(const FfnKArgs p) {
     // ---- several workgroups share the tile: park, count, the last arrival finishes ----
     const int wf_ = (int)(((ut0 + 1) * p.G - 1) / U);             // workgroup that owns the tile's first unit
     const int wl_ = (int)(((ut0 + UT) * p.G - 1) / U);            // ... its last unit
-    if (wl_ > wf_) {
+    if (!p.canon && wl_ > wf_) {
       {
         const int slot = 2 * w + (tile == t_first ? 0 : 1);
         const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + (size_t)slot * FF_SLOT), 0, FF_SLOT * 4, 0x00020000);
@@ -388,7 +393,16 @@ static int g_ffn_force_g = 0;                         // tests / tuning: fixed g
 void ffn_fused_debug_grid(int g) { g_ffn_force_g = g; }
 
 static int g_ffn_wm = getenv("SS_FFN_WM") ? atoi(getenv("SS_FFN_WM")) : 3;   // MFMA row tiles per wave (4: 64-row tiles, 3: 48-row tiles)
-void ffn_fused_debug_rows(int wm) { if (wm == 3 || wm == 4) g_ffn_wm = wm; }
+static int g_ffn_wm_forced = getenv("SS_FFN_WM") ? 1 : 0;                    // the pack-invariant form picks its own unless forced
+void ffn_fused_debug_rows(int wm) { if (wm >= 1 && wm <= 4) { g_ffn_wm = wm; g_ffn_wm_forced = 1; } else if (wm == 0) { g_ffn_wm = 3; g_ffn_wm_forced = 0; } }
+
+// relative cost of a row at tile height 16 h (h = 1..4), SS_FFN_COST="c1,c2,c3,c4" overrides (tuning)
+static double g_ffn_cost[5] = {0.0, 1.45, 1.12, 1.0, 1.04};
+[[maybe_unused]] static const int g_ffn_cost_init = [] {
+  const char* e = getenv("SS_FFN_COST");
+  if (e) sscanf(e, "%lf,%lf,%lf,%lf", &g_ffn_cost[1], &g_ffn_cost[2], &g_ffn_cost[3], &g_ffn_cost[4]);
+  return 0;
+}();
 
 bool ffn_fused_eligible(int D, int F, int act, int M, int ldx, int ldy) {
   return D == FF_D && F >= 64 && F % 64 == 0 && F <= 8192 && act == ACT_SILU && M > 0 && (ldx & 3) == 0 && (ldy & 3) == 0 &&
@@ -405,6 +419,23 @@ static int launch_ffn_t(FfnKArgs a, int D, const float* ln2_g, hipStream_t strea
   if (rc != SS_OK) return rc;
   const int tiles = cdiv(a.M, BM);
   const long long U = (long long)tiles * (a.F / FF_UN);
+  if (a.canon) {
+    // pack-invariant form: whole tiles per workgroup; two resident workgroups per CU at 16- / 32-row tiles (128 accumulator registers)
+    long long G = g_ffn_force_g > 0 ? g_ffn_force_g : (long long)st->cus * (WMT <= 2 ? 2 : 1);
+    if (G > tiles) G = tiles;
+    if (G < 1) G = 1;
+    a.G = (int)G; a.ws = st->ws; a.cnt = st->sync3; a.zero = 0;
+    GemmArgs ga;
+    ga.M = a.M; ga.N = D; ga.Cin = a.F; ga.in_len = a.M;
+    ga.algo_flops = 4.0 * (double)a.M * D * a.F;
+    ga.algo_bytes = 4.0 * (2.0 * (double)a.M * D + 2.0 * (double)D * a.F + a.F + 3.0 * D + (ln2_g ? 2.0 * D : 0.0));
+    ProfRec rec{}; bool prof = false;
+    rc = prof_begin(ga, stream, 22, rec, prof);
+    if (rc != SS_OK) return rc;
+    hipLaunchKernelGGL(ffn_fused_kernel<WMT>, dim3((unsigned)G), dim3(256), kLds, stream, a);
+    SS_LAUNCH_CHECK();
+    return prof_end(stream, rec, prof);
+  }
   // One workgroup per CU.  A tile is shared by at most ~8 workgroups (each parks a partial that the tile's last arrival reads
   // back: beyond that the finisher's serial read is the kernel's tail), and every workgroup gets at least 4 units (one per wave).
   long long G = g_ffn_force_g > 0 ? g_ffn_force_g : st->cus;
@@ -427,12 +458,32 @@ static int launch_ffn_t(FfnKArgs a, int D, const float* ln2_g, hipStream_t strea
 
 int launch_ffn_fused(const float* X, int ldx, float* Y, int ldy, const float* ln_g, const float* ln_b, const float* W1,
                      const float* b1, const float* W2, const float* b2, float alpha, const float* ln2_g, const float* ln2_b,
-                     int M, int D, int F, hipStream_t stream) {
+                     int M, int D, int F, hipStream_t stream, int canon) {
   if (!ffn_fused_eligible(D, F, ACT_SILU, M, ldx, ldy) || !X || !Y || !ln_g || !ln_b || !W1 || !b1 || !W2 || !b2) return SS_ERR_ARG;
   FfnKArgs a;
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.ln_g = ln_g; a.ln_b = ln_b; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
-  a.ln2_g = ln2_g; a.ln2_b = ln2_g ? ln2_b : nullptr; a.alpha = alpha; a.M = M; a.F = F;
-  return g_ffn_wm == 4 ? launch_ffn_t<4>(a, D, ln2_g, stream) : launch_ffn_t<3>(a, D, ln2_g, stream);
+  a.ln2_g = ln2_g; a.ln2_b = ln2_g ? ln2_b : nullptr; a.alpha = alpha; a.M = M; a.F = F; a.canon = canon ? 1 : 0;
+  int wm = g_ffn_wm;
+  if (canon && !g_ffn_wm_forced) {
+    // Tile height of the pack-invariant form (a row's bits do not depend on it): the one whose tiles go over the CUs in the fewest
+    // rows per CU, weighted by what a row costs at that height (fewer MFMAs per weight fragment at low heights; tools/ffn_bench.py)
+    SkWorkspace* st = nullptr;
+    int rc = sk_workspace_acquire(stream, &st);
+    if (rc != SS_OK) return rc;
+    const double cost[5] = {0.0, g_ffn_cost[1], g_ffn_cost[2], g_ffn_cost[3], g_ffn_cost[4]};
+    double best = 1e300;
+    for (int h = 1; h <= 4; ++h) {
+      const long long tiles = cdiv(M, 16 * h);
+      const double t = (double)((tiles + st->cus - 1) / st->cus) * 16 * h * cost[h];
+      if (t < best) { best = t; wm = h; }
+    }
+  }
+  switch (wm) {
+    case 1: return launch_ffn_t<1>(a, D, ln2_g, stream);
+    case 2: return launch_ffn_t<2>(a, D, ln2_g, stream);
+    case 4: return launch_ffn_t<4>(a, D, ln2_g, stream);
+    default: return launch_ffn_t<3>(a, D, ln2_g, stream);
+  }
 }
 
 }  // namespace ss

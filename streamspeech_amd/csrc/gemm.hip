@@ -860,6 +860,53 @@ int sk_workspace_error_count() {
 }
 
 void debug_force_tile(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn; g_force_ks = ks; conv_sk_set_groups(bm == 1 && bn == 8); }
+bool debug_tile_forced() { return g_force_bm != 0; }
+
+static thread_local int t_canon = CANON_NONE;
+CanonScope::CanonScope(int mode) : prev(t_canon) { t_canon = mode; }
+CanonScope::~CanonScope() { t_canon = prev; }
+int canon_mode() { return t_canon; }
+void canon_debug_set(int mode) { t_canon = mode; }
+
+// CANON_SMALLM: what the no-LDS kernel computes at all (smallm_eligible minus the tuning hooks)
+static bool smallm_shape_ok(const GemmArgs& a) {
+  const bool glu_ok = !a.glu || (a.N % 32 == 0 && a.act == ACT_NONE && a.alpha == 1.f && !a.R);
+  return a.taps == 1 && a.stride == 1 && a.pad == 0 && glu_ok && a.nseg == 0 && a.chunk == 0 && a.in_act == ACT_NONE && !a.R2 &&
+         !a.C2 && a.div == 0.f && !a.ln_out && (a.act == ACT_NONE || a.act == ACT_SILU || a.act == ACT_RELU) && a.M > 0 &&
+         a.M <= 192 && a.Cin % 64 == 0 && (a.lda & 3) == 0 && (!a.ln_g || a.Cin <= 512);
+}
+
+// Pack-invariant routes (GemmArgs::canon): see gemm.hpp.  Nothing here may make the BITS depend on M; the choice among kernels
+// that give the same bits may.
+static int launch_canon(const GemmArgs& a, hipStream_t stream) {
+  const int M = a.nseg > 0 ? a.max_seg_out : a.M;
+  const bool k32 = (a.Cin % 32) == 0;
+  const int nseg = a.nseg > 0 ? a.nseg : 1;
+  if (a.ln_out) return SS_ERR_ARG;
+  if (a.canon == CANON_SMALLM) {
+    if (!smallm_shape_ok(a)) return SS_ERR_ARG;
+    if (a.glu) return launch_smallm<2, 2, true>(a, stream, 13);
+    // split-K form by (N, K) alone: 4 waves on one 16-column tile's k-quarters, or 2 x 2 when N alone fills the chip
+    if (a.Cin >= 1024 || a.N <= 4096) return launch_smallm<4, 1>(a, stream, 12);
+    return launch_smallm<2, 2>(a, stream, 13);
+  }
+  // ---- CANON_SEQ: one accumulator chain per output element ----
+  if (rtlin_shape_ok(a) && (a.ln_g || rtlin_eligible(a))) return launch_rtlin(a, stream);
+  if (a.ln_g) return SS_ERR_ARG;            // LayerNorm prologue: the row-tile kernel only (K = 256); callers normalise first otherwise
+  if (conv_sk2_eligible(a) && !a.x3 && 2.0 * (double)a.M * a.N * a.taps * a.Cin >= g_sk_min_flops) {
+    // stream-K cut on WHOLE tiles: worth it when the tiles fill the CUs in (nearly) whole rounds
+    const long long tiles = (long long)cdiv(a.M, 256) * (a.N / (a.N % 128 == 0 ? 128 : 64));
+    const long long cus = 256, rounds = (tiles + cus - 1) / cus;
+    if (a.N % 128 == 0 && (long long)a.taps * a.Cin >= 256 && tiles * 100 >= rounds * cus * 80) return launch_conv_sk2(a, stream);
+  }
+  if (a.N <= 16) return launch_cfg<128, 16, 16, 4, 1, 1>(a, stream, 0);
+  if (a.N <= 32 && !a.glu) return k32 ? launch_cfg<128, 32, 32, 4, 1, 1>(a, stream, 1) : launch_cfg<128, 32, 16, 4, 1, 1>(a, stream, 2);
+  if (M <= 16) return k32 ? launch_cfg<16, 128, 32, 1, 4>(a, stream, 3) : launch_cfg<16, 128, 16, 1, 4>(a, stream, 4);
+  const long t3264 = (long)cdiv(M, 32) * cdiv(a.N, 64) * nseg;
+  if (!k32) return launch_cfg<32, 64, 16, 2, 2, 1>(a, stream, 10);
+  if (a.glu || t3264 >= 768) return launch_cfg<32, 64, 32, 2, 2, 1>(a, stream, 9);
+  return launch_cfg<32, 32, 32, 2, 2, 1>(a, stream, 11);
+}
 
 bool smallm_eligible(const GemmArgs& a) {
   if (g_force_bm > 1) return false;
@@ -888,6 +935,8 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.glu && (a.N % 32 != 0 || a.C2)) return SS_ERR_ARG;
   const bool k32 = (a.Cin % 32) == 0;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
+  if (a.canon == CANON_NONE) a.canon = t_canon;
+  if (a.canon != CANON_NONE && !g_force_bm) return launch_canon(a, stream);
   // a forced tile (tuning hook) keeps M <= 4 launches off the GEMV -- except when the caller asked for ln_out, which only the GEMV writes
   if ((!g_force_bm || a.ln_out) && gemv_eligible(a)) return launch_gemv(a, stream);
   if (a.ln_out) return SS_ERR_ARG;      // only the GEMV form publishes the normalised rows

@@ -57,7 +57,24 @@ struct GemmArgs {
   // stream-K kernel (conv_sk.hip).
   int same_rows = 0;
   int x3 = 0;                 // 1: split-bf16 (3 x bf16 MFMA) contraction where the kernel has one (conv_sk2 only; opt-in, see ss_vocoder_set_bf16x3)
+  // Pack-invariant arithmetic: the bits of output row m must be a function of row m's operands alone -- not of
+  // the row count M, the grid, or where stream-K cut the k-range.  CANON_SEQ: ONE accumulator chain per output element over k
+  // ascending (16-wide slabs, MFMA e contracts k = {e, 4+e, 8+e, 12+e}): conv_gemm_kernel without split-K, rt_linear, conv_sk2 cut
+  // on whole tiles -- these three give the same bits (tests/test_pack_invariance_gpu.py), so the choice among them may depend on M.
+  // CANON_SMALLM: the no-LDS small-M kernel with a split-K form fixed by (N, K) alone (the lock-step MT decode rows).
+  // 0: the launcher takes the calling thread's CanonScope mode (none outside a scope = fastest kernel for the shape).
+  int canon = 0;
 };
+constexpr int CANON_NONE = 0, CANON_SEQ = 1, CANON_SMALLM = 2;
+// RAII: launches of the calling thread whose GemmArgs::canon is 0 take `mode` until the scope ends (the ss_batch_* entry points
+// open one: a packed utterance gets the arithmetic it would get alone or in any other pack)
+struct CanonScope {
+  explicit CanonScope(int mode);
+  ~CanonScope();
+  int prev;
+};
+int canon_mode();                      // the calling thread's current mode
+void canon_debug_set(int mode);        // test hook: the calling thread's mode outside any scope (ss_debug_canon)
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
@@ -170,6 +187,7 @@ void conv_c16_debug(int enable);
 // Row-tile linear layer for K = 256 projections of packed batches (rtlin.hip): the row tile (LayerNorm-ed when a.ln_g is set) in
 // LDS, weight fragments straight from L2 to registers, bias / activation / alpha / residual or GLU epilogue per 16-column unit.
 bool rtlin_eligible(const GemmArgs& a);
+bool rtlin_shape_ok(const GemmArgs& a);   // what the kernel can compute at all (rtlin_eligible = this + "worth it at this row count")
 int launch_rtlin(const GemmArgs& a, hipStream_t stream);
 void rtlin_debug(int grid, int enable);   // tests / A-B: fixed workgroup count (0 = heuristic); enable 0 / 1 (-1: keep)
 
@@ -179,7 +197,9 @@ void rtlin_debug(int grid, int enable);   // tests / A-B: fixed workgroup count 
 bool ffn_fused_eligible(int D, int F, int act, int M, int ldx, int ldy);
 int launch_ffn_fused(const float* X, int ldx, float* Y, int ldy, const float* ln_g, const float* ln_b, const float* W1,
                      const float* b1, const float* W2, const float* b2, float alpha, const float* ln2_g, const float* ln2_b,
-                     int M, int D, int F, hipStream_t stream);
+                     int M, int D, int F, hipStream_t stream, int canon = 0);
+// canon != 0: every row tile is computed whole by ONE workgroup (wave w contracts hidden units [32 w, 32 w + 32) whatever M is),
+// so a row's bits do not depend on the row count / grid; the tile height is picked for the fewest rounds over the CUs.
 void ffn_fused_debug_grid(int g);    // tests / tuning: fixed workgroup count (0 = heuristic)
 void ffn_fused_debug_rows(int wm);   // tests / tuning: 16-row MFMA tiles per wave (3: 48-row tiles, 4: 64-row tiles)
 
@@ -191,6 +211,7 @@ bool smallm_eligible(const GemmArgs& a);
 
 // Tuning hook: force the tile of the LDS-tiled kernel (bm = 0 restores the heuristic).
 void debug_force_tile(int bm, int bn, int ks);
+bool debug_tile_forced();
 
 // Launches on `stream`; returns SS_OK / SS_ERR_*.
 int launch_conv_gemm(const GemmArgs& a, hipStream_t stream);

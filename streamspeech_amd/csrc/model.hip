@@ -95,11 +95,27 @@ int ln_linear(hipStream_t s, const float* x, int M, const LN& ln, const Lin& l, 
   a.A = x; a.lda = K; a.W = l.w; a.bias = l.b; a.C = C; a.ldc = ldc;
   a.M = M; a.N = N; a.Cin = K; a.in_len = M; a.act = act; a.alpha = alpha; a.glu = glu;
   a.same_rows = 1;
+  const int canon = debug_tile_forced() ? CANON_NONE : canon_mode();
+  if (canon == CANON_SMALLM) {                // lock-step MT decode rows: LayerNorm in the small-M kernel's prologue, always
+    a.ln_g = ln.g; a.ln_b = ln.b;
+    return launch_conv_gemm(a, s);
+  }
+  if (canon == CANON_SEQ) {
+    // pack-invariant: the LayerNorm form must not change with the row count -- K = 256 layers always take the row-tile kernel's
+    // (rtlin.hip), the others always the LayerNorm kernel + a GEMM
+    GemmArgs b = a;
+    b.ln_g = ln.g; b.ln_b = ln.b;
+    if (rtlin_shape_ok(b)) return launch_conv_gemm(b, s);
+    int rc = layernorm(s, x, h, ln, M, K);
+    if (rc != SS_OK) return rc;
+    a.A = h;
+    return launch_conv_gemm(a, s);
+  }
   if (smallm_eligible(a) && K <= 512) {
     a.ln_g = ln.g; a.ln_b = ln.b;
     return launch_conv_gemm(a, s);
   }
-  {
+  if (!debug_tile_forced()) {                 // (a forced tile keeps launch_conv_gemm off the row-tile kernel: ADVICE r4)
     GemmArgs b = a;
     b.ln_g = ln.g; b.ln_b = ln.b;
     if (rtlin_eligible(b)) return launch_conv_gemm(b, s);      // LayerNorm in the row tile's way into LDS (rtlin.hip)
@@ -114,6 +130,7 @@ int ln_linear(hipStream_t s, const float* x, int M, const LN& ln, const Lin& l, 
 
 static int g_ffn_fusion = getenv("SS_NO_FFN_FUSION") && atoi(getenv("SS_NO_FFN_FUSION")) ? 0 : 1;   // A/B knob: encoder FFNs of packed batches as one launch each (ffn.hip)
 static int g_ffn_min_rows = getenv("SS_FFN_MIN_ROWS") ? atoi(getenv("SS_FFN_MIN_ROWS")) : 1000;      // below: the two-launch form (too few row tiles to fill the chip)
+static const int g_pack_invariant_default = getenv("SS_PACK_INVARIANT") ? atoi(getenv("SS_PACK_INVARIANT")) : 1;   // A/B knob: default of ss_model_set_pack_invariant for new contexts
 
 // =================================================================================================
 // model
@@ -175,6 +192,9 @@ struct ss_model {
   // next call that uses the same scratch buffer)
   const float* dbg_logits = nullptr;
   int dbg_rows = 0, dbg_cols = 0;
+  // ss_model_set_pack_invariant: 1 = every ss_batch_* stage upstream of an arg-max computes a packed utterance with arithmetic that
+  // is a function of that utterance alone (same bits alone, in any pack, at any position); 0 = fastest kernel per shape (round-4 routes)
+  int pack_invariant = g_pack_invariant_default;
 };
 
 // Key-split scratch of this context for the single-utterance rel-pos attention: allocated and zeroed on first use (the
@@ -1320,6 +1340,8 @@ extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const 
                                         int attn_chunk, int conv_chunk, float* d_enc_out, int32_t* h_Tp) {
   if (!m || B <= 0) return SS_ERR_ARG;
   SkScope sk_scope(m->skws);
+  CanonScope canon_scope(m->pack_invariant ? CANON_SEQ : CANON_NONE);
+  const bool canon = m->pack_invariant && !debug_tile_forced();
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int d = c.enc_dim, f = c.enc_ffn, k = c.conv_kernel, Ld = c.enc_layers * d;
@@ -1375,11 +1397,13 @@ extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const 
   for (int l = 0; l < c.enc_layers; ++l) {
     const EncLayer& e = m->enc[l];
     // macaron FFN: x += 0.5 * W2 SiLU(W1 LN(x)); packed batches: ONE launch (ffn.hip), the [rows, 2048] hidden tile stays on chip
-    const bool fuse_ffn = g_ffn_fusion && M2 >= g_ffn_min_rows && ffn_fused_eligible(d, f, ACT_SILU, M2, d, d) && e.ffn1_w1.b &&
-                          e.ffn1_w2.b && e.ffn2_w1.b && e.ffn2_w2.b;
+    // (pack-invariant contexts: ALWAYS the fused launch in its whole-tile form -- the two-launch form sums the 2048 hidden terms in
+    //  another order, and which of the two runs must not depend on the row count)
+    const bool fuse_ffn = (canon || (g_ffn_fusion && M2 >= g_ffn_min_rows)) && ffn_fused_eligible(d, f, ACT_SILU, M2, d, d) &&
+                          e.ffn1_w1.b && e.ffn1_w2.b && e.ffn2_w1.b && e.ffn2_w2.b;
     if (fuse_ffn) {
       RET(launch_ffn_fused(x, d, x, d, e.ffn1_ln.g, e.ffn1_ln.b, e.ffn1_w1.w, e.ffn1_w1.b, e.ffn1_w2.w, e.ffn1_w2.b, 0.5f, nullptr,
-                           nullptr, M2, d, f, s));
+                           nullptr, M2, d, f, s, canon));
     } else {
       RET(ln_linear(s, x, M2, e.ffn1_ln, e.ffn1_w1, f, d, ff, f, h, ACT_SILU));
       RET(linear(s, ff, f, M2, e.ffn1_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
@@ -1398,7 +1422,7 @@ extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const 
     RET(linear(s, g2, d, M2, e.pw2, d, d, x, d, ACT_NONE, 1.f, x, d));
     if (fuse_ffn) {                          // second FFN + the layer's final LayerNorm in the same launch
       RET(launch_ffn_fused(x, d, x, d, e.ffn2_ln.g, e.ffn2_ln.b, e.ffn2_w1.w, e.ffn2_w1.b, e.ffn2_w2.w, e.ffn2_w2.b, 0.5f,
-                           e.final_ln.g, e.final_ln.b, M2, d, f, s));
+                           e.final_ln.g, e.final_ln.b, M2, d, f, s, canon));
     } else {
       RET(ln_linear(s, x, M2, e.ffn2_ln, e.ffn2_w1, f, d, ff, f, h, ACT_SILU));
       RET(linear(s, ff, f, M2, e.ffn2_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
@@ -1413,6 +1437,7 @@ extern "C" int ss_batch_ctc_greedy(ss_model* m, void* stream, int head, int B, c
                                    int32_t* d_counts) {
   if (!m || B <= 0 || head < 0 || head > 1) return SS_ERR_ARG;
   SkScope sk_scope(m->skws);
+  CanonScope canon_scope(m->pack_invariant ? CANON_SEQ : CANON_NONE);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const Offsets o = prefix(h_Tp, B);
@@ -1436,6 +1461,7 @@ extern "C" int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float*
                                   int32_t* h_n_out, float* d_feats, int feat_rows) {
   if (!m || B <= 0 || B > 128 || !d_feats) return SS_ERR_ARG;
   SkScope sk_scope(m->skws);
+  CanonScope canon_scope(m->pack_invariant ? CANON_SEQ : CANON_NONE);     // cross K|V over the packed encoder rows
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int D = c.dec_dim, F = c.dec_ffn, V = c.tgt_vocab, H = c.dec_heads;
@@ -1482,6 +1508,9 @@ extern "C" int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float*
   int checked = 1;     // token rows [1, checked) already copied to the host
   int step = 0;        // position being fed
   constexpr int kCheck = 4;
+  // the decode rows (one per utterance): the small-M kernel in a split-K form fixed by the layer shape -- not by B (with B <= 4 the
+  // heuristic would take the GEMV, with B = 64 another wave arrangement for the vocabulary projection)
+  CanonScope decode_scope(m->pack_invariant ? CANON_SMALLM : CANON_NONE);
   while (true) {
     // feed position `step` of every utterance
     RET(launch_embed_tokens(tok + (size_t)step * B, m->mt_emb, m->mt_pos, sqrtf((float)D), step + c.pad + 1, x, B, D, s, 0, -1, c.tgt_vocab));
@@ -1532,6 +1561,7 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
                                   int32_t* d_counts) {
   if (!m || B <= 0) return SS_ERR_ARG;
   SkScope sk_scope(m->skws);
+  CanonScope canon_scope(m->pack_invariant ? CANON_SEQ : CANON_NONE);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int D = c.dec_dim, F = c.dec_ffn, V = c.unit_vocab, H = c.dec_heads, up = c.ctc_upsample;
@@ -1572,6 +1602,7 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
     at.Q = selfbuf; at.ldq = 3 * D; at.K = selfbuf + D; at.V = selfbuf + 2 * D; at.ldk = at.ldv = 3 * D;
     at.O = h; at.ldo = D; at.H = H; at.scale = 1.f; at.causal = t2u_causal ? 1 : 0;
     at.segs = dt; at.nseg = B; at.max_q = on.mx;
+    at.no_decode_kernel = m->pack_invariant;       // max_q is the pack's longest utterance: it must not pick the kernel
     RET(dec_layer_ex(s, c, m->t2u[l], x, Nn, selfbuf, 3 * D, at, nullptr, h, q2, ff));
   }
   RET(launch_layernorm(x, D, t2u_out, D, m->t2u_ln.g, m->t2u_ln.b, Nn, D, 1e-5f, s));
@@ -1581,10 +1612,11 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
     AttnArgs at;
     at.Q = selfbuf; at.ldq = 3 * D; at.K = selfbuf + D; at.V = selfbuf + 2 * D; at.ldk = at.ldv = 3 * D;
     at.O = h; at.ldo = D; at.H = H; at.scale = 1.f; at.causal = 1;
-    at.segs = dt + 4 * B; at.nseg = B; at.max_q = on.mx * up;
+    at.segs = dt + 4 * B; at.nseg = B; at.max_q = on.mx * up; at.no_decode_kernel = m->pack_invariant;
     AttnArgs ac;
     ac.Q = q2; ac.ldq = D; ac.K = crosskv; ac.V = crosskv + D; ac.ldk = ac.ldv = 2 * D;
     ac.O = h; ac.ldo = D; ac.H = H; ac.scale = 1.f; ac.segs = dt + 8 * B; ac.nseg = B; ac.max_q = on.mx * up;
+    ac.no_decode_kernel = m->pack_invariant;
     RET(dec_layer_ex(s, c, m->unit[l], x, U, selfbuf, 3 * D, at, &ac, h, q2, ff));
   }
   RET(launch_layernorm(x, D, h, D, m->unit_ln.g, m->unit_ln.b, U, D, 1e-5f, s));
@@ -1729,6 +1761,13 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
   return launch_conv_gemm(a, (hipStream_t)stream);
 }
 
+extern "C" int ss_model_set_pack_invariant(ss_model* m, int on) {
+  if (!m) return SS_ERR_ARG;
+  m->pack_invariant = on ? 1 : 0;
+  return SS_OK;
+}
+extern "C" int ss_model_get_pack_invariant(ss_model* m) { return m ? m->pack_invariant : SS_ERR_ARG; }
+
 extern "C" int ss_debug_last_logits(ss_model* m, void* stream, float* d_out, int64_t cap_floats, int* h_rows, int* h_cols) {
   if (!m || !h_rows || !h_cols) return SS_ERR_ARG;
   *h_rows = m->dbg_rows; *h_cols = m->dbg_cols;
@@ -1742,7 +1781,15 @@ extern "C" int ss_debug_last_logits(ss_model* m, void* stream, float* d_out, int
 extern "C" int ss_op_ffn_fused(void* stream, const float* dX, int ldx, float* dY, int ldy, const float* ln_g, const float* ln_b,
                                const float* dW1, const float* db1, const float* dW2, const float* db2, float alpha,
                                const float* ln2_g, const float* ln2_b, int M, int D, int F) {
-  return launch_ffn_fused(dX, ldx, dY, ldy, ln_g, ln_b, dW1, db1, dW2, db2, alpha, ln2_g, ln2_b, M, D, F, (hipStream_t)stream);
+  return launch_ffn_fused(dX, ldx, dY, ldy, ln_g, ln_b, dW1, db1, dW2, db2, alpha, ln2_g, ln2_b, M, D, F, (hipStream_t)stream,
+                          canon_mode() == CANON_SEQ);
+}
+// Test hook: the arithmetic mode of the ss_op_* entry points called from this thread (0 fastest kernel per shape, 1 the pack-invariant
+// one-chain form, 2 the fixed small-M form of the lock-step decode rows); the model entry points set their own.
+extern "C" int ss_debug_canon(int mode) {
+  if (mode < 0 || mode > 2) return SS_ERR_ARG;
+  canon_debug_set(mode);
+  return SS_OK;
 }
 extern "C" int ss_op_ln_linear(void* stream, const float* dX, int ldx, const float* ln_g, const float* ln_b, const float* dW,
                                const float* dbias, const float* dR, int ldr, float* dC, int ldc, int M, int N, int K, int act,
@@ -1773,9 +1820,9 @@ extern "C" int ss_debug_rtlin(int grid, int enable) {
   return SS_OK;
 }
 extern "C" int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable) {
-  if (grid < 0 || !(row_tiles_per_wave == 0 || row_tiles_per_wave == 3 || row_tiles_per_wave == 4)) return SS_ERR_ARG;
+  if (grid < 0 || row_tiles_per_wave < 0 || row_tiles_per_wave > 4) return SS_ERR_ARG;
   ffn_fused_debug_grid(grid);
-  if (row_tiles_per_wave) ffn_fused_debug_rows(row_tiles_per_wave);
+  ffn_fused_debug_rows(row_tiles_per_wave);
   if (enable >= 0) g_ffn_fusion = enable ? 1 : 0;
   return SS_OK;
 }

@@ -254,21 +254,26 @@ static long long g_rt_min_units = getenv("SS_RTLIN_MIN_UNITS") ? atoll(getenv("S
 static int g_rt_force_g = 0;
 void rtlin_debug(int grid, int enable) { g_rt_force_g = grid; if (enable >= 0) g_rt_off = enable ? 0 : 1; }
 
-bool rtlin_eligible(const GemmArgs& a) {
-  if (g_rt_off) return false;
+bool rtlin_shape_ok(const GemmArgs& a) {
   const int M = a.M;
   const bool glu_ok = !a.glu || (a.N % 32 == 0 && a.act == ACT_NONE && a.alpha == 1.f && !a.R);
   return a.taps == 1 && a.stride == 1 && a.pad == 0 && a.Cin == RT_K && a.chunk == 0 && a.in_act == ACT_NONE && !a.R2 && !a.C2 &&
-         a.div == 0.f && !a.ln_out && !a.x3 && glu_ok && a.N % 16 == 0 && a.N >= 16 && M >= g_rt_min_rows && a.nseg == 0 &&
+         a.div == 0.f && !a.ln_out && !a.x3 && glu_ok && a.N % 16 == 0 && a.N >= 16 && M >= 1 && a.nseg == 0 &&
          (a.act == ACT_NONE || a.act == ACT_SILU || a.act == ACT_RELU) && (a.lda & 3) == 0 && (a.ldc & 3) == 0 &&
          (!a.R || (a.ldr & 3) == 0) && a.A != a.C && a.in_len >= M && (!a.ln_g || a.ln_b) &&
-         (size_t)a.N * RT_K * 4 < 0x7ff00000ull &&
+         (size_t)a.N * RT_K * 4 < 0x7ff00000ull;
+}
+
+bool rtlin_eligible(const GemmArgs& a) {
+  if (g_rt_off) return false;
+  const int M = a.M;
+  return rtlin_shape_ok(a) && M >= g_rt_min_rows &&
          (g_rt_force_g > 0 || a.N >= 2048 ||                      // >= 128 units per row tile: the prologue is noise at any row count
           (long long)cdiv(M, RT_BM) * (a.N / 16) >= g_rt_min_units);      // (N / 16: a GLU unit is 32 weight rows)
 }
 
 int launch_rtlin(const GemmArgs& a, hipStream_t stream) {
-  if (!rtlin_eligible(a)) return SS_ERR_ARG;
+  if (!rtlin_shape_ok(a)) return SS_ERR_ARG;
   int cus = 0;
   {
     SkWorkspace* st = nullptr;                     // (only for the device's CU count, cached per context)

@@ -303,6 +303,13 @@ class HipModel(BatchMixin):
         L.check(self.lib.ss_mt_set_persistent(self.h, int(workgroups)), "ss_mt_set_persistent")
         self.persistent_mt = int(workgroups)
 
+    def set_pack_invariant(self, on: bool = True):
+        """Pack-invariant arithmetic of the batch_* calls of this context (default on): see ss_model_set_pack_invariant."""
+        L.check(self.lib.ss_model_set_pack_invariant(self.h, int(bool(on))), "ss_model_set_pack_invariant")
+
+    def pack_invariant(self) -> bool:
+        return bool(self.lib.ss_model_get_pack_invariant(self.h))
+
     def mt_truncate(self, length: int):
         L.check(self.lib.ss_mt_truncate(self.h, length), "ss_mt_truncate")
 

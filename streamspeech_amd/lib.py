@@ -49,6 +49,9 @@ SIGNATURES = {
     "ss_ctc_greedy": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ss_mt_begin": (_i, [_vp, _vp, _vp, _i]),
     "ss_mt_set_persistent": (_i, [_vp, _i]),
+    "ss_model_set_pack_invariant": (_i, [_vp, _i]),
+    "ss_model_get_pack_invariant": (_i, [_vp]),
+    "ss_debug_canon": (_i, [_i]),
     "ss_mt_get_persistent": (_i, [_vp]),
     "ss_debug_mt_inject_timeout": (_i, [_vp]),
     "ss_mt_append": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i]),

@@ -77,7 +77,7 @@ def test_ffn_fused_vs_float64(lib, wm, M, Fh, grid, ln2):
         got = run(lib, x, p, ln2=ln2)
         got2 = run(lib, x, p, ln2=ln2, inplace=False, ldx=D + 8)
     finally:
-        lib.ss_debug_ffn(0, 3, -1)
+        lib.ss_debug_ffn(0, 0, -1)
     ref = reference(x, p, 0.5, ln2)
     assert torch.isfinite(got).all()
     err = (got.double() - ref).abs().max().item()
@@ -106,26 +106,35 @@ def test_ffn_fused_is_bit_reproducible_under_concurrent_load(lib):
 
 
 def test_batch_encoder_with_and_without_ffn_fusion(hip_model):
-    """The packed-batch encoder with the fused FFN launches (default) against the same call with two GEMM launches + LayerNorm per
-    FFN (ss_debug_ffn(.., enable = 0)): same rows to summation-order accuracy, identical CTC ids."""
-    import numpy as np
+    """The packed-batch encoder three ways: the default pack-invariant form (whole-tile fused FFN, one-chain GEMMs), the round-4
+    routes (stream-K fused FFN: ss_model_set_pack_invariant(0)) and those with two GEMM launches + LayerNorm per FFN
+    (ss_debug_ffn(.., enable = 0)): same rows to summation-order accuracy, identical CTC ids."""
     from streamspeech_amd import lib as L, synth
     lib = L.load()
     T = [1203, 900, 777, 640, 512, 300, 150, 83] * 4
     fb = torch.cat([torch.from_numpy(synth.synth_fbank(50 + i, t)) for i, t in enumerate(T)]).cuda()
-    enc_f, Tp = hip_model.batch_encoder_forward(fb, T)
-    ids_f = [hip_model.batch_ctc_greedy(h, enc_f, Tp) for h in (0, 1)]
-    enc_f = enc_f.clone()
-    assert lib.ss_debug_ffn(0, 0, 0) == 0
+
+    def run():
+        enc, Tp = hip_model.batch_encoder_forward(fb, T)
+        return enc.clone(), list(Tp), [hip_model.batch_ctc_greedy(h, enc, Tp) for h in (0, 1)]
+
+    assert hip_model.pack_invariant()
+    enc_c, Tp, ids_c = run()
+    hip_model.set_pack_invariant(False)
     try:
-        enc_u, Tp2 = hip_model.batch_encoder_forward(fb, T)
-        ids_u = [hip_model.batch_ctc_greedy(h, enc_u, Tp2) for h in (0, 1)]
+        enc_f, Tp1, ids_f = run()
+        assert lib.ss_debug_ffn(0, 0, 0) == 0
+        try:
+            enc_u, Tp2, ids_u = run()
+        finally:
+            lib.ss_debug_ffn(0, 0, 1)
     finally:
-        lib.ss_debug_ffn(0, 0, 1)
-    assert list(Tp) == list(Tp2) and sum(Tp) >= 1000
-    err = (enc_f - enc_u).abs().max().item()
-    assert err < 5e-5, f"fused vs two-launch encoder rows differ by {err}"
-    assert ids_f == ids_u
+        hip_model.set_pack_invariant(True)
+    assert Tp == Tp1 == Tp2 and sum(Tp) >= 1000
+    for name, e in (("stream-K fused", enc_f), ("pack-invariant", enc_c)):
+        err = (e - enc_u).abs().max().item()
+        assert err < 5e-5, f"{name} vs two-launch encoder rows differ by {err}"
+    assert ids_f == ids_u == ids_c
     n = L.load().ss_prof_num_classes()
     names = [L.load().ss_prof_class_name(c).decode() for c in range(n)]
     assert "ffn_fused<256,2048>" in names

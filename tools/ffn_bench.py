@@ -61,7 +61,7 @@ def main():
             x.copy_(x0)
             t = timed(fused)
             out.append(f"{t:7.1f} ({fl / t * 1e-6:5.1f})")
-        lib.ss_debug_ffn(0, 3, -1)
+        lib.ss_debug_ffn(0, 0, -1)
         out.append(f"{timed(lambda: fused(True)):7.1f}")
         print(" | ".join(out), flush=True)
 
