@@ -39,14 +39,18 @@ def _t(x) -> torch.Tensor:
 class SD:
     """Read-only view of a state dict that hands out torch tensors (zero-copy from numpy)."""
 
-    def __init__(self, sd):
+    def __init__(self, sd, dtype=torch.float32):
+        # dtype = torch.float64: the SAME float32 weights and tables, every operation carried out in double precision -- the
+        # adjudicator of arg-max rows whose float32 top-1 / top-2 gap is inside float32 rounding (tests/test_bench_config_gpu.py);
+        # float32 (default) is the reference's arithmetic and what every fixture was generated with
         self.sd = sd
+        self.dtype = dtype
         self._cache = {}
 
     def __getitem__(self, k) -> torch.Tensor:
         v = self._cache.get(k)
         if v is None:
-            v = _t(self.sd[k]).float()
+            v = _t(self.sd[k]).to(self.dtype)
             self._cache[k] = v
         return v
 
@@ -206,11 +210,11 @@ def encoder_forward(sd, fbank, cfg, attn_chunk: int = 999999, conv_chunk: int = 
     attn_chunk = encoder.chunk_size, conv_chunk = the ChunkCausalConv1d chunk the agent sets
     (agent/speech_to_speech.streamspeech.agent.py:395-413)."""
     sd = sd if isinstance(sd, SD) else SD(sd)
-    fbank = _t(fbank).float()
+    fbank = _t(fbank).to(sd.dtype)
     x = subsample(sd, fbank, conv_chunk)
     T, d = x.shape
     x = math.sqrt(d) * x
-    pos = rel_pos_table(T, d)
+    pos = rel_pos_table(T, d).to(sd.dtype)
     x = linear(x, sd, "encoder.linear")
     mask = chunk_mask(T, attn_chunk) if attn_chunk < T else None
     L = cfg.enc_layers if n_layers is None else n_layers
@@ -237,7 +241,7 @@ def ctc_head(sd, enc_out, name: str, cfg):
     """agent/ctc_decoder.py:39-111 + fairseq ctc_decoder.py:11-18: Linear -> log_softmax ->
     pad/unk = -inf -> argmax -> collapse with blank = 0.  Returns (tokens, index, raw argmax, logits)."""
     sd = sd if isinstance(sd, SD) else SD(sd)
-    logits = linear(_t(enc_out), sd, f"{name}_decoder.proj")
+    logits = linear(_t(enc_out).to(sd.dtype), sd, f"{name}_decoder.proj")
     lp = F.log_softmax(logits, dim=-1)
     lp[:, cfg.pad] = -math.inf
     lp[:, cfg.unk] = -math.inf
@@ -305,7 +309,7 @@ def mt_decoder_features(sd, tokens: List[int], enc_out, cfg) -> torch.Tensor:
     (post final LayerNorm).  Embedding = sqrt(512)*E[tok] + sinusoid(pos), positions from
     padding_idx+1 = 2 (fairseq/utils.py:256-266)."""
     sd = sd if isinstance(sd, SD) else SD(sd)
-    enc_out = _t(enc_out)
+    enc_out = _t(enc_out).to(sd.dtype)
     p = "target_unigram_decoder"
     D = cfg.dec_dim
     tok = torch.tensor(tokens, dtype=torch.long)
@@ -358,7 +362,7 @@ def t2u_encoder(sd, x, cfg, causal: bool = False, n_tail_pad: int = 0) -> torch.
     """synthesizer_encoder: ctc_unity/modules/transformer_encoder.py:32-77 (2 pre-LN layers + LN);
     causal iff --uni-encoder (simultaneous checkpoints)."""
     sd = sd if isinstance(sd, SD) else SD(sd)
-    x = _t(x)
+    x = _t(x).to(sd.dtype)
     for i in range(cfg.t2u_layers):
         x = encoder_layer(sd, f"synthesizer_encoder.layers.{i}", x, cfg.dec_heads, causal, n_tail_pad)
     return layer_norm(x, sd["synthesizer_encoder.layer_norm.weight"], sd["synthesizer_encoder.layer_norm.bias"])
@@ -371,7 +375,7 @@ def unit_decoder_logits(sd, t2u_out, cfg, n_tail_pad: int = 0) -> torch.Tensor:
     B = 1 every position gets sinusoid row padding_idx+1 (=2) -- or the zero pad row where the
     feature value equals padding_idx (1.0) exactly."""
     sd = sd if isinstance(sd, SD) else SD(sd)
-    t2u_out = _t(t2u_out)
+    t2u_out = _t(t2u_out).to(sd.dtype)
     n, D = t2u_out.shape
     x = t2u_out[:, None, :].repeat(1, cfg.ctc_upsample, 1).reshape(n * cfg.ctc_upsample, D)
     table = sinusoid_table(cfg.pad + 1 + 1024, D, cfg.pad)
