@@ -83,7 +83,7 @@ CPU_STAGES = ("a1_fbank_cmvn", "a2_a7_encoder", "a8_ctc_heads", "a9_a10_mt_greed
               "a14_a15_vocoder")
 
 
-def cpu_baseline(sd, vsd, cfg, vcfg, utts, reps=5, warm=2, budget_s=30.0):
+def cpu_baseline(sd, vsd, cfg, vcfg, utts, reps=5, warm=2, budget_s=30.0, hip_model=None, dev=None):
     """The CPU oracle (torch fp32, the box's host cores) on a bounded sample of the same workload, timed as BASELINE.md
     §3 / SURVEY.md §8d prescribe: per utterance `warm` untimed passes, then `reps` timed passes, MEDIAN per stage
     (a1 ... a15) and end to end.  The sample is three utterances spread over the length distribution (short / median /
@@ -143,14 +143,96 @@ def cpu_baseline(sd, vsd, cfg, vcfg, utts, reps=5, warm=2, budget_s=30.0):
                             "median_ms": round(1e3 * med["end_to_end"], 1), "rtfx": round(u.seconds / med["end_to_end"], 2)})
             if time.perf_counter() - t_begin > budget_s:
                 break
+    check = oracle_check(sd, cfg, hip_model, sample[:len(per_utt)], dev) if hip_model is not None else None
     return {"value": round(audio / wall, 3), "unit": "x real-time (audio s / wall s)", "utterances_per_sec": round(len(per_utt) / wall, 3),
-            "cores": nthreads, "host_cpus": os.cpu_count(), "kind": "port",
+            "cores": nthreads, "host_cpus": os.cpu_count(), "kind": "port", "oracle_check": check,
             "sample": f"{len(per_utt)} utterances of the same synthetic workload (short / median / long: "
                       + ", ".join(f"{p['seconds']} s" for p in per_utt) + f"; {audio:.1f} s of audio), each {warm} warm-ups then "
                       f"{reps} timed passes, median per stage and end to end",
             "per_utterance": per_utt,
             "stage_ms_per_audio_second": {k: round(1e3 * v / audio, 2) for k, v in stage_tot.items()},
             "port_vs_reference_modules": "profiles/r03_cpu_port_vs_reference.json (this container, same inputs and threads)"}
+
+
+def hip_stage_logits(model, u, pcm_dev):
+    """One utterance ALONE through the ss_batch_* calls (pack-invariant arithmetic: the bits it has in any pack): raw arg-max ids
+    and dense logits of every arg-max stage."""
+    feat, T = model.batch_fbank_cmvn(pcm_dev, [u.n_samples])
+    enc, Tp = model.batch_encoder_forward(feat, T)
+    out = {"fbank": feat.cpu().numpy()}
+    for h, k in ((0, "asr"), (1, "st")):
+        raw = model.batch_ctc_greedy(h, enc, Tp, return_raw=True)[0][2]
+        out[k] = (list(raw), model.last_logits().cpu())
+    toks, feats, n = model.batch_mt_greedy(enc, Tp, [u.n_mt])
+    out["mt"] = list(toks[0])
+    raw = model.batch_t2u_units(feats, n, return_raw=True)[1][0]
+    out["unit"] = (list(raw), model.last_logits().cpu())
+    out["enc"], out["mt_states"] = enc.cpu(), feats[0, :n[0]].cpu()
+    return out
+
+
+def pack_invariance_check(model, work, n_alone=3):
+    """Inside the bench process, on the timed packs themselves: utterances of the shortest and of a middle pack, alone vs in
+    their pack -- encoder rows, both CTC heads' logits, MT decoder states and unit logits must be BIT-identical (the reference
+    decodes one utterance per call: agent/speech_to_speech.streamspeech.agent.py:425-478)."""
+    checked, ok = 0, True
+    for us, pk in (work[-1], work[len(work) // 2]):
+        feat, T = model.batch_fbank_cmvn(pk, [u.n_samples for u in us])
+        enc, Tp = model.batch_encoder_forward(feat, T)
+        model.batch_ctc_greedy(0, enc, Tp)
+        asr = model.last_logits().cpu()
+        model.batch_ctc_greedy(1, enc, Tp)
+        st = model.last_logits().cpu()
+        toks, feats, n = model.batch_mt_greedy(enc, Tp, [u.n_mt for u in us])
+        model.batch_t2u_units(feats, n)
+        unit = model.last_logits().cpu()
+        enc_c, feats_c = enc.cpu(), feats.cpu()
+        o1 = np.cumsum([0] + list(Tp))
+        o2 = np.cumsum([0] + [x * model.cfg.ctc_upsample for x in n])
+        ps = np.cumsum([0] + [u.n_samples for u in us])
+        for b in sorted({0, len(us) // 2, len(us) - 1})[:n_alone]:
+            a = hip_stage_logits(model, us[b], pk[ps[b]:ps[b + 1]])
+            same = (torch.equal(a["enc"], enc_c[o1[b]:o1[b + 1]]) and torch.equal(a["asr"][1], asr[o1[b]:o1[b + 1]]) and
+                    torch.equal(a["st"][1], st[o1[b]:o1[b + 1]]) and torch.equal(a["mt_states"], feats_c[b, :n[b]]) and
+                    torch.equal(a["unit"][1], unit[o2[b]:o2[b + 1]]) and a["mt"] == list(toks[b]))
+            ok, checked = ok and same, checked + 1
+    return {"utterances_checked": checked, "packs": 2, "stages": ["encoder rows", "ASR CTC logits", "ST CTC logits", "MT decoder states",
+                                                                  "unit logits"],
+            "alone_equals_in_pack_bitwise": bool(ok), "pack_invariant_context": bool(model.pack_invariant())}
+
+
+def oracle_check(sd, cfg, model, sample, dev):
+    """cpu_baseline leg only: the ids of the three CPU-baseline utterances, HIP (alone through the ss_batch_* calls = the bits they
+    have in any pack) against the float32 oracle fed the HIP fbank; strict, a differing row must pass the float64 adjudication of
+    oracle/adjudicate.py (and is then counted as a near-tie row)."""
+    from oracle import adjudicate as J
+    from oracle import streamspeech_oracle as O
+    osd = O.SD(sd)
+    rows_total, lines, identical = 0, [], True
+    with torch.inference_mode():
+        for u in sample:
+            pcm = torch.from_numpy(synth.synth_pcm(1234 + u.idx, u.n_samples)).to(dev)
+            h = hip_stage_logits(model, u, pcm)
+            enc = O.encoder_forward(osd, h["fbank"], cfg)
+            ref = {"asr": O.ctc_head(osd, enc, "source_unigram", cfg), "st": O.ctc_head(osd, enc, "ctc_target_unigram", cfg)}
+            toks = O.mt_greedy(osd, enc, cfg, max_new_tokens=u.n_mt)
+            if toks != h["mt"]:
+                raise RuntimeError(f"utterance {u.idx}: MT ids differ from the oracle: {h['mt']} vs {toks}")
+            body = toks[:-1] if toks and toks[-1] == cfg.eos else toks
+            logits = O.unit_decoder_logits(osd, O.t2u_encoder(osd, O.mt_decoder_features(osd, [cfg.eos] + body, enc, cfg), cfg), cfg)
+            ref_unit_raw = O.unit_ctc_generate(logits, cfg)[1]
+            for stage, ref_raw, ref_logits in (("asr", ref["asr"][2], ref["asr"][3]), ("st", ref["st"][2], ref["st"][3]),
+                                               ("unit", ref_unit_raw, logits)):
+                rows_total += len(ref_raw)
+                rows = J.differing_rows(h[stage][0], ref_raw)
+                if rows:
+                    identical = False
+                    L64 = J.float64_logits(sd, cfg, h["fbank"], stage, toks)
+                    lines += J.adjudicate(f"utt {u.idx} ({u.seconds:.2f} s) {stage}", rows, L64, ref_logits, h[stage][1], [cfg.pad, cfg.unk])
+    return {"utterances": len(sample), "argmax_rows_compared": rows_total, "ids_identical_to_float32_oracle": identical,
+            "near_tie_rows": len(lines), "adjudicated_in_float64": lines,
+            "rule": "strict ids; a differing row must be a float64 top-2 exchange with gap < 2^-20 x max|logit| (oracle/adjudicate.py); "
+                    "the measured configuration at full size (192 utterances of 3 packs of 64, ~120 k rows): tests/test_bench_config_gpu.py"}
 
 
 def census(lib):
@@ -1034,6 +1116,7 @@ def main():
             "single_stream_mt_step": {"persistent_workgroups_default": pmt_default, "after_the_pass": pmt_after},
             "batch1_8streams": None if b1_rtfx is None else {"rtfx": round(b1_rtfx, 1), "utterances_per_sec": round(b1_ups, 1),
                                                              "note": "one utterance per call (no ragged packs), 8 concurrent streams, 64 utterances"},
+            "pack_invariance": pack_invariance_check(model, work) if (Bsz > 1 and len(work) >= 2) else None,
             "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),   # must be 0 (bounded waits of the stream-K fix-up); also asserted for the timed region
             "roofline": roofline,
             "bf16x3": bf16x3_line,
@@ -1047,9 +1130,11 @@ def main():
             "timed_region_monotonic_ns": [t0_mono_ns, t1_mono_ns],   # tools/trace_gaps.py: window of a rocprofv3 kernel trace
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, workload.make_utterances(Wn + Kpool + 1)[Wn:])
+            out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, workload.make_utterances(Wn + Kpool + 1)[Wn:], hip_model=model, dev=dev)
+            out["near_tie_rows"] = out["cpu_baseline"]["oracle_check"]["near_tie_rows"]
         else:
             out["cpu_baseline"] = None
+            out["near_tie_rows"] = None
         if world == 1 and not args.no_streaming_line:
             # BASELINE.json configs[2] inside the driver's line: the agent's policy() loop on 320-ms segments (incremental state
             # and the reference's full recompute), its CPU baseline on the same utterances, and the long-source sweep

@@ -172,6 +172,9 @@ int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, int n, int 
  *   still decoded (the reference emits their units too, agent :661-717). */
 
 /* ---- a14-a15: CodeHiFiGANVocoderWithDur.forward (agent/tts/vocoder.py:48-60). -------------- */
+/* d_blob must be device-visible when this is called (the upload complete, not merely queued on some stream): the Winograd forms
+ * of the ResBlock conv weights are made here on the null stream (once per blob and device -- later contexts over the same blob
+ * borrow them) and the call returns with the device synchronised.  The same holds for ss_model_create (projected rel-pos table). */
 int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_blob, size_t blob_floats,
                       const char* const* names, const int64_t* offsets, const int64_t* numels,
                       int n_slots, ss_vocoder** out);

@@ -1,0 +1,66 @@
+"""TEST INFRASTRUCTURE (like everything under oracle/): float64 adjudication of arg-max rows on which two float32 evaluations of
+the same B = 1 arithmetic -- the CPU oracle's torch kernels and the HIP kernels -- pick different ids.
+
+The reference's decoders are arg-maxes over float32 logits (agent/ctc_decoder.py:39-111, agent/ctc_generator.py:40-123,
+agent/sequence_generator.py:592-673).  Float32 logits of this 12-layer encoder carry ~2^-20 x max|logit| of rounding (measured:
+the float32 oracle itself sits 0.8-1.9e-5 from its own float64 evaluation on logits of magnitude 14-17), so a row whose exact
+top-1 / top-2 gap is smaller than that is NOT decided by float32 -- any summation order may land on either side, the reference's
+included.  A differing row passes only if the float64 evaluation (same float32 weights, tables and inputs, every operation in
+double: streamspeech_oracle.SD(dtype=float64)) shows exactly that:
+  (1) the two ids are exactly the float64 top-2 of the row,
+  (2) their float64 gap is below 2^-20 x max|logit| of the row,
+  (3) the HIP logits of the row are as close to float64 as the float32 oracle's are (within 2x) and within 2^-18 x max|logit|.
+Only tests/ and bench.py's cpu_baseline leg may import this module."""
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import streamspeech_oracle as O
+
+GAP_BAR = 2.0 ** -20          # x max|logit| of the row
+HIP_ERR_BAR = 2.0 ** -18      # x max|logit| of the row
+
+
+def float64_logits(sd, cfg, fbank, stage: str, mt_tokens: Sequence[int] = ()) -> torch.Tensor:
+    """Dense float64 logits of one utterance for `stage` in {"asr", "st", "unit"} from its fbank (and, for the unit decoder, the MT
+    tokens both sides agreed on)."""
+    sd64 = O.SD(sd, dtype=torch.float64)
+    enc = O.encoder_forward(sd64, fbank, cfg)
+    if stage in ("asr", "st"):
+        return O.ctc_head(sd64, enc, "source_unigram" if stage == "asr" else "ctc_target_unigram", cfg)[3]
+    toks = list(mt_tokens)
+    body = toks[:-1] if toks and toks[-1] == cfg.eos else toks
+    feats = O.mt_decoder_features(sd64, [cfg.eos] + body, enc, cfg)
+    return O.unit_decoder_logits(sd64, O.t2u_encoder(sd64, feats, cfg), cfg)
+
+
+def differing_rows(hip_raw, ref_raw) -> List[Tuple[int, int, int]]:
+    hip_raw, ref_raw = list(hip_raw), list(ref_raw)
+    assert len(hip_raw) == len(ref_raw), "row count"
+    return [(t, a, b) for t, (a, b) in enumerate(zip(hip_raw, ref_raw)) if a != b]
+
+
+def adjudicate(tag: str, rows, L64, L32, Lhip, masked) -> List[str]:
+    """rows = [(t, hip id, float32-oracle id)].  Raises AssertionError unless every row meets (1)-(3); returns one report line per row."""
+    L64 = torch.as_tensor(np.asarray(L64)).double()
+    L32 = torch.as_tensor(np.asarray(L32)).double()
+    Lhip = torch.as_tensor(np.asarray(Lhip)).double()
+    keep = torch.ones(L64.shape[1], dtype=torch.bool)
+    keep[list(masked)] = False
+    out = []
+    for t, a, b in rows:
+        x = L64[t].clone()
+        x[~keep] = float("-inf")
+        top = torch.topk(x, 2)
+        scale = float(L64[t][keep].abs().max())
+        gap = float(top.values[0] - top.values[1])
+        e_or = float((L32[t][keep] - L64[t][keep]).abs().max())
+        e_hip = float((Lhip[t][keep] - L64[t][keep]).abs().max())
+        line = (f"{tag} row {t}: HIP {a} / float32 oracle {b} / float64 top-2 {top.indices.tolist()}, float64 gap {gap:.2e} "
+                f"(bar 2^-20 x {scale:.2f} = {scale * GAP_BAR:.2e}), float32 oracle off float64 by {e_or:.2e}, HIP by {e_hip:.2e}")
+        assert {a, b} == set(top.indices.tolist()), "not a top-2 exchange: " + line
+        assert gap < scale * GAP_BAR, "float32 decides this row: " + line
+        assert e_hip <= max(2 * e_or, 1e-9) and e_hip < scale * HIP_ERR_BAR, "HIP logits too far from float64: " + line
+        out.append(line)
+    return out

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
 #include <mutex>
 
 #define SS_OK 0
@@ -27,17 +28,21 @@
 // Raise a kernel's dynamic-LDS limit once PER DEVICE, from whichever host thread launches it first there (bench.py drives the
 // library from 8 threads; hipFuncSetAttribute applies to the current device's function object only, so a process that drives
 // several GPUs must repeat it on each -- ADVICE r3).  Wrap a template-id in parentheses: SS_MAX_LDS_ONCE((&k<A, B>), bytes).
+// (the launch path takes no lock -- one acquire load of the per-device bit; the mutex is only taken by the first
+//  launches of a kernel on a device.)
 #define SS_MAX_LDS_ONCE(kernel, bytes)                                                                          \
   do {                                                                                                          \
     static std::mutex _mu;                                                                                      \
-    static unsigned long long _done[2] = {0ull, 0ull};   /* devices 0..127 */                                   \
+    static std::atomic<unsigned long long> _done[2];     /* devices 0..127; zero-initialised (static storage) */ \
     int _dev = 0;                                                                                               \
     SS_HIP_CHECK(hipGetDevice(&_dev));                                                                          \
     if (_dev < 0 || _dev >= 128) return SS_ERR_ARG;                                                             \
-    std::lock_guard<std::mutex> _lk(_mu);                                                                       \
-    if (!((_done[_dev >> 6] >> (_dev & 63)) & 1ull)) {                                                          \
-      SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
-      _done[_dev >> 6] |= 1ull << (_dev & 63);                                                                  \
+    if (!((_done[_dev >> 6].load(std::memory_order_acquire) >> (_dev & 63)) & 1ull)) {                          \
+      std::lock_guard<std::mutex> _lk(_mu);                                                                     \
+      if (!((_done[_dev >> 6].load(std::memory_order_relaxed) >> (_dev & 63)) & 1ull)) {                        \
+        SS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes))); \
+        _done[_dev >> 6].fetch_or(1ull << (_dev & 63), std::memory_order_release);                              \
+      }                                                                                                         \
     }                                                                                                           \
   } while (0)
 

@@ -3,6 +3,8 @@
 // frame count in the vocoder and whatever the caller does with the returned ids.
 #include <algorithm>
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -175,6 +177,7 @@ struct ss_model {
   DevBuf attn_split;             // key-split scratch of the single-utterance rel-pos attention (attention.hpp); counters zeroed once
   DevBuf mt_gran;                // persistent decode step (mt_step.hip): granule region, zeroed once; the epoch grows per launch
   unsigned mt_epoch = 0;
+  hipStream_t mt_last_stream = nullptr;   // stream of the last persistent-step launch (mt_collect_errors reads / clears the error word there)
   int mt_inject_timeout = 0;     // ss_debug_mt_inject_timeout: the next persistent launch reports a time-out
   int mt_persistent = g_mt_persistent_default;   // workgroups of the persistent decode step (ss_mt_set_persistent); 0 = launch-per-op
   DevBuf mt_tok;                 // device token chain [max_tgt_pos] (greedy search feeds itself)
@@ -677,11 +680,16 @@ static unsigned* mt_err_word(ss_model* m) {
 }
 static int mt_collect_errors(ss_model* m) {
   if (!m->mt_gran.p) return SS_OK;
+  // on the stream the persistent step was last launched on (torch streams are non-blocking: the legacy null stream orders
+  // nothing against them -- ADVICE r4): the read sees every earlier launch's error word, the clear lands before any later one
+  hipStream_t s = m->mt_last_stream;
   unsigned e = 0;
-  SS_HIP_CHECK(hipMemcpy(&e, mt_err_word(m), sizeof(e), hipMemcpyDeviceToHost));     // synchronises with the context's stream work
+  SS_HIP_CHECK(hipMemcpyAsync(&e, mt_err_word(m), sizeof(e), hipMemcpyDeviceToHost, s));
+  SS_HIP_CHECK(hipStreamSynchronize(s));
   if (e) {
     g_mt_timeouts.fetch_add((int)e, std::memory_order_relaxed);
-    SS_HIP_CHECK(hipMemset(mt_err_word(m), 0, sizeof(unsigned)));
+    SS_HIP_CHECK(hipMemsetAsync(mt_err_word(m), 0, sizeof(unsigned), s));
+    SS_HIP_CHECK(hipStreamSynchronize(s));
   }
   return SS_OK;
 }
@@ -781,6 +789,7 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
     a.max_len = force_eos ? pos0 : 0x7fffffff;
     RET(mt_inject(m, a, s));
     a.epoch = mt_next_epochs(m, 1);
+    m->mt_last_stream = s;
     RET(launch_mt_step(a, m->mt_persistent, s));
     m->mt_len = pos0 + n;
     return SS_OK;
@@ -850,6 +859,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
       a.pos0 = first; a.n_steps = n_steps; a.min_len = min_len; a.max_len = max_len;
       RET(mt_inject(m, a, s));
       a.epoch = mt_next_epochs(m, n_steps);
+      m->mt_last_stream = s;
       RET(launch_mt_step(a, m->mt_persistent, s));
     }
     const int lo = start + 1, hi = max_len + 1;             // generated tokens live at chain indices lo .. hi
@@ -965,10 +975,19 @@ struct ss_vocoder {
   LN dur_ln1, dur_ln2;
   std::vector<ConvW> ups;
   std::vector<ConvW> rb_c1, rb_c2;  // [(stage*n_res + j)*3 + d]
-  DevBuf wino;                       // Winograd F(2,3) forms of the 64-channel stage's ResBlock conv weights (conv_c64w.hip)
+  float* wino = nullptr;             // Winograd F(2,3) forms of the 32- / 64- / 128-channel stages' ResBlock conv weights (conv_c64w.hip):
+  const float* wino_key = nullptr;   // ONE buffer per weight blob, shared by every context over that blob (wino_share below)
   DevBuf ws, small, segs;
   int x3 = 0;          // split-bf16 contraction of the C >= 64 generator convs (ss_vocoder_set_bf16x3); default off = exact f32
 };
+
+// Transformed weights are a function of the weight blob alone: contexts made over the same blob (HipVocoder.new_context: one per
+// concurrent stream) borrow one buffer instead of packing ~16 MB each.  Keyed by (device, blob pointer), ref-counted.
+namespace {
+struct WinoShared { DevBuf buf; size_t floats = 0; int refs = 0; };
+std::mutex g_wino_mu;
+std::map<std::pair<int, const float*>, WinoShared> g_wino;
+}  // namespace
 
 extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_blob, size_t blob_floats,
                                  const char* const* names, const int64_t* offsets, const int64_t* numels,
@@ -1018,9 +1037,18 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
       if (wino_stage(Cs)) for (int j = 0; j < cfg->n_res; ++j) need += 6 * (size_t)Cs * ((cfg->resblock_kernel_sizes[j] + 2) / 3) * 4 * Cs;
     }
     if (need) {
-      rc = v->wino.ensure(need * sizeof(float));
-      if (rc != SS_OK) { sk_workspace_free(v->skws); delete v; return rc; }
-      float* dst = v->wino.f();
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) { sk_workspace_free(v->skws); delete v; return SS_ERR_HIP; }
+      std::lock_guard<std::mutex> lk(g_wino_mu);          // (held over the pack: a second context of the same blob waits for it)
+      WinoShared& sh = g_wino[std::make_pair(dev, d_blob)];
+      const bool fresh = sh.refs == 0 || sh.floats != need;
+      if (fresh && sh.refs > 0) { g_wino.erase(std::make_pair(dev, d_blob)); sk_workspace_free(v->skws); delete v; return SS_ERR_ARG; }   // same blob, another config
+      if (fresh) {
+        rc = sh.buf.ensure(need * sizeof(float));
+        if (rc != SS_OK) { g_wino.erase(std::make_pair(dev, d_blob)); sk_workspace_free(v->skws); delete v; return rc; }
+        sh.floats = need;
+      }
+      float* dst = sh.buf.f();
       Cs = C0;
       for (int i = 0; i < cfg->n_up && rc == SS_OK; ++i) {
         Cs /= 2;
@@ -1030,15 +1058,22 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
           const size_t n = (size_t)Cs * ((kr + 2) / 3) * 4 * Cs;
           for (int dd = 0; dd < 3 && rc == SS_OK; ++dd) {
             const int idx = (i * cfg->n_res + j) * 3 + dd;
-            rc = launch_wino_pack(v->rb_c1[idx].w, dst, Cs, kr, nullptr);
+            if (fresh) rc = launch_wino_pack(v->rb_c1[idx].w, dst, Cs, kr, nullptr);
             v->rb_c1[idx].ww = dst; dst += n;
-            if (rc == SS_OK) rc = launch_wino_pack(v->rb_c2[idx].w, dst, Cs, kr, nullptr);
+            if (fresh && rc == SS_OK) rc = launch_wino_pack(v->rb_c2[idx].w, dst, Cs, kr, nullptr);
             v->rb_c2[idx].ww = dst; dst += n;
           }
         }
       }
-      if (rc == SS_OK && hipStreamSynchronize(nullptr) != hipSuccess) rc = SS_ERR_HIP;
-      if (rc != SS_OK) { v->wino.release(); sk_workspace_free(v->skws); delete v; return rc; }
+      // the pack ran on the null stream: d_blob must be device-visible when ss_vocoder_create is called (header), and the buffer is
+      // complete for every stream once this returns
+      if (fresh && rc == SS_OK && hipDeviceSynchronize() != hipSuccess) rc = SS_ERR_HIP;
+      if (rc != SS_OK) {
+        if (fresh) { sh.buf.release(); g_wino.erase(std::make_pair(dev, d_blob)); }
+        sk_workspace_free(v->skws); delete v; return rc;
+      }
+      ++sh.refs;
+      v->wino = sh.buf.f(); v->wino_key = d_blob;
     }
   }
   *out = v;
@@ -1053,7 +1088,15 @@ extern "C" int ss_vocoder_set_bf16x3(ss_vocoder* v, int on) {
 
 extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
   if (!v) return;
-  v->ws.release(); v->small.release(); v->segs.release(); v->wino.release();
+  v->ws.release(); v->small.release(); v->segs.release();
+  if (v->wino_key) {
+    std::lock_guard<std::mutex> lk(g_wino_mu);
+    for (auto it = g_wino.begin(); it != g_wino.end(); ++it)
+      if (it->first.second == v->wino_key && it->second.buf.f() == v->wino) {
+        if (--it->second.refs == 0) { it->second.buf.release(); g_wino.erase(it); }
+        break;
+      }
+  }
   sk_workspace_free(v->skws);
   delete v;
 }
@@ -1750,7 +1793,10 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
   a.chunk = chunk; a.in_act = in_act; a.in_slope = in_slope; a.act = act; a.alpha = alpha; a.div = div; a.glu = glu;
   a.same_rows = (stride == 1 && M == in_len) ? 1 : 0;
   // unit-test path of the Winograd form (the model makes the transformed weights once per context): made here per call
-  static thread_local DevBuf wino_tmp;
+  // (one buffer per stream of the calling thread: a re-pack for a launch on stream B must not overwrite the weights a kernel
+  //  queued on stream A is still reading -- ADVICE r4)
+  static thread_local std::map<hipStream_t, DevBuf> wino_tmps;
+  DevBuf& wino_tmp = wino_tmps[(hipStream_t)stream];
   if ((conv_c64w_enabled() && N == 64 && Cin == 64 && taps >= 3 && conv_c64_eligible(a)) ||
       (conv_c128w_enabled() && N == 128 && Cin == 128 && taps >= 3 && a.same_rows && !glu) ||
       (conv_c32w_enabled() && N == 32 && Cin == 32 && taps >= 3 && conv_c32_eligible(a))) {

@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
   // a workgroup can only overwrite them after it has gathered the previous step's candidates, which every other workgroup publishes
   // after its last read of that step -- the all-to-all exchanges are the barrier.
   int tk = p.tok[0];
+  // the prefix pass (launch-per-op, fed by ss_mt_greedy before this launch) may already have produced </s>: the search is over --
+  // do not feed it and decode on until a later step happens to emit </s> again (~125 us per step on the streaming latency path,
+  // and cache / feature rows past the end).  Uniform over workgroups: nobody waits for anybody.
+  if (p.pos0 > 0 && tk == p.eos) return;
 #pragma unroll 1
   for (int it = 0; it < p.n_steps; ++it) {
   const unsigned epoch = p.epoch + (unsigned)it;

@@ -48,41 +48,18 @@ def _hip_row_logits(m, pcm, u, stage, toks):
 
 
 def _adjudicate(tag, stage, rows, m, O, sd, cfg, u, pcm, fb, toks, ref32_logits, hip_raw, masked, log):
-    """rows = [(t, hip id, oracle id)]: float64 decides whether float32 could (see the module docstring)."""
-    sd64 = O.SD(sd, dtype=torch.float64)
-    enc64 = O.encoder_forward(sd64, fb, cfg)
-    if stage in ("asr", "st"):
-        L64 = O.ctc_head(sd64, enc64, "source_unigram" if stage == "asr" else "ctc_target_unigram", cfg)[3]
-    else:
-        body = toks[:-1] if toks and toks[-1] == cfg.eos else toks
-        f64 = O.mt_decoder_features(sd64, [cfg.eos] + list(body), enc64, cfg)
-        L64 = O.unit_decoder_logits(sd64, O.t2u_encoder(sd64, f64, cfg), cfg)
+    """rows = [(t, hip id, oracle id)]: float64 decides whether float32 could (oracle/adjudicate.py)."""
+    from oracle import adjudicate as J
+    L64 = J.float64_logits(sd, cfg, fb, stage, toks)
     Lh, raw_alone = _hip_row_logits(m, pcm, u, stage, toks)
     assert list(raw_alone) == list(hip_raw), f"{tag}: {stage}: the utterance alone and in its pack disagree -- pack invariance broken"
-    L32 = torch.as_tensor(np.asarray(ref32_logits)).double()
-    keep = torch.ones(L64.shape[1], dtype=torch.bool)
-    keep[masked] = False
-    for t, a, b in rows:
-        x = L64[t].clone()
-        x[~keep] = float("-inf")
-        top = torch.topk(x, 2)
-        scale = float(L64[t][keep].abs().max())
-        gap = float(top.values[0] - top.values[1])
-        e_or = float((L32[t][keep] - L64[t][keep]).abs().max())
-        e_hip = float((Lh[t].double()[keep] - L64[t][keep]).abs().max())
-        line = (f"{tag}: {stage} row {t}: HIP {a} / float32 oracle {b} / float64 top-2 {top.indices.tolist()}, float64 gap {gap:.2e} "
-                f"(bar 2^-20 x {scale:.2f} = {scale * 2 ** -20:.2e}), float32 oracle off float64 by {e_or:.2e}, HIP by {e_hip:.2e}")
-        assert {a, b} == set(top.indices.tolist()), "not a top-2 exchange: " + line
-        assert gap < scale * 2 ** -20, "float32 decides this row: " + line
-        assert e_hip <= max(2 * e_or, 1e-9) and e_hip < scale * 2 ** -18, "HIP logits too far from float64: " + line
-        log.append(line)
+    log.extend(J.adjudicate(f"{tag}: {stage}", rows, L64, ref32_logits, Lh, masked))
 
 
 def _argmax_rows(tag, stage, hip_raw, ref_raw):
     """-> rows [(t, hip id, oracle id)] where the raw arg-max ids differ (normally none)."""
-    hip_raw, ref_raw = list(hip_raw), list(ref_raw)
-    assert len(hip_raw) == len(ref_raw), f"{tag}: {stage} row count"
-    return [(t, a, b) for t, (a, b) in enumerate(zip(hip_raw, ref_raw)) if a != b]
+    from oracle import adjudicate as J
+    return J.differing_rows(hip_raw, ref_raw)
 
 
 def _oracle_utterance(O, osd, ovsd, cfg, vcfg, fb, u, workload, hip_unit_raw=None):
