@@ -596,7 +596,8 @@ def dry_plan(args, rank, world):
     if dist is not None:
         dist.barrier()
     wall = 1.0 + 0.001 * rank          # a stand-in wall time: the MAX must pick the last rank's
-    per_rank = dp.gather_per_rank(dist, wall, audio, float(len(timed_ids)))
+    placement = dp.pin_rank_to_gpu_numa(rank, world, pci_bus_id=os.environ.get("SS_BENCH_DRY_PCI", "0000:00:00.0"), apply=False)
+    per_rank = dp.gather_per_rank(dist, wall, audio, float(len(timed_ids)), placement=placement)
     wall_max, audio_tot, nutt = dp.reduce_stats(dist, wall, audio, float(len(timed_ids)))
     comm = comm_probe(dist, "cpu", reps=5) if dist is not None else None
     if rank == 0:
@@ -660,6 +661,7 @@ def main():
     # (SS_DIST_BACKEND=gloo python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2)
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
+    placement = dp.pin_rank_to_gpu_numa(local_rank, world)      # before any launching thread exists (children inherit the mask)
     dist = None
     force_dist = world == 1 and os.environ.get("SS_FORCE_DIST") == "1"   # a world of one still goes through RCCL: init, barrier, reductions
     if world > 1 or force_dist:
@@ -837,7 +839,7 @@ def main():
         raise errors[0]
 
     audio = sum(mine[i].seconds for i in timed_ids)
-    per_rank = dp.gather_per_rank(dist, wall, audio, float(K), device=dev)
+    per_rank = dp.gather_per_rank(dist, wall, audio, float(K), device=dev, placement=placement)
     wall, audio, nutt = dp.reduce_stats(dist, wall, audio, float(K), device=dev)
     rccl = None
     if dist is not None:                     # the DP path's collectives on the live communicator (untimed for `value`)
@@ -1125,6 +1127,9 @@ def main():
             "roofline_second_kernel": roofline_conv,
             "process_census": census(lib),
             "per_rank": per_rank,
+            "host_placement": {**placement, "rule": "ranks of an N > 1 run are pinned to the CPUs local to their GPU's NUMA node (dp.pin_rank_to_gpu_numa)"},
+            "multi_gpu_note": ("no N > 1 RCCL run has been made by the builder (no multi-GPU node in the build environment): the N > 1 path is "
+                               "covered by gloo tests (tests/test_dp_gloo.py, incl. `--gpus 8 --dry-plan`) and by RCCL as a world of one (`rccl`)"),
             "rccl": rccl if (rccl is not None or args.no_rccl_probe) else rccl_probe_subprocess(),
             "self_launched": bool(os.environ.get("SS_BENCH_SELF_LAUNCHED")),
             "timed_region_monotonic_ns": [t0_mono_ns, t1_mono_ns],   # tools/trace_gaps.py: window of a rocprofv3 kernel trace

@@ -2,7 +2,8 @@
 independent, every rank holds a full weight replica, and the ONLY communication is one barrier
 before the timed region plus one tiny all-reduce of (wall, audio seconds, utterances) after it.
 Backend "nccl" is RCCL over xGMI on ROCm; "gloo" is used by the CPU tests."""
-from typing import List, Sequence, Tuple
+import os
+from typing import List, Optional, Sequence, Tuple
 
 import torch
 
@@ -35,14 +36,79 @@ def reduce_stats(dist, wall: float, audio_s: float, n_utts: float, device="cpu")
     return float(mx[0]), float(t[1]), float(t[2])
 
 
-def gather_per_rank(dist, wall: float, audio_s: float, n_utts: float, device="cpu") -> List[dict]:
-    """Per-rank (wall, audio seconds, utterances) on every rank, so that load imbalance is visible in the bench line
-    (one more 3-double all-gather after the timed region; the scaling loss of this path is imbalance, not communication)."""
+def gather_per_rank(dist, wall: float, audio_s: float, n_utts: float, device="cpu", placement: Optional[dict] = None) -> List[dict]:
+    """Per-rank (wall, audio seconds, utterances[, NUMA node, pinned, local CPUs]) on every rank, so that load imbalance and host
+    placement are visible in the bench line (one more small all-gather after the timed region; the scaling loss of this path is
+    imbalance, not communication)."""
+    pl = placement or {}
+    extra = [float(-1 if pl.get("numa_node") is None else pl["numa_node"]), float(bool(pl.get("pinned"))), float(pl.get("cpus_local_to_gpu", 0))]
+
+    def row(r, o):
+        d = {"rank": r, "wall_s": round(float(o[0]), 5), "audio_s": round(float(o[1]), 2), "utterances": int(o[2])}
+        if placement is not None:
+            d.update({"numa_node": None if o[3] < 0 else int(o[3]), "pinned_to_numa_node": bool(o[4]), "cpus_local_to_gpu": int(o[5])})
+        return d
+
     if dist is None or not dist.is_initialized():
-        return [{"rank": 0, "wall_s": round(wall, 5), "audio_s": round(audio_s, 2), "utterances": int(n_utts)}]
+        return [row(0, [wall, audio_s, n_utts] + extra)]
     world = dist.get_world_size()
-    t = torch.tensor([wall, audio_s, n_utts], dtype=torch.float64, device=device)
+    t = torch.tensor([wall, audio_s, n_utts] + extra, dtype=torch.float64, device=device)
     out = [torch.zeros_like(t) for _ in range(world)]
     dist.all_gather(out, t)
-    return [{"rank": r, "wall_s": round(float(o[0]), 5), "audio_s": round(float(o[1]), 2), "utterances": int(o[2])}
-            for r, o in enumerate(out)]
+    return [row(r, [float(x) for x in o]) for r, o in enumerate(out)]
+
+
+# ---- host-side placement: a rank's launching threads on the CPUs next to its GPU ----------------------------------------
+def _parse_cpulist(text: str) -> List[int]:
+    out: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        out.extend(range(int(lo), int(hi or lo) + 1))
+    return out
+
+
+def gpu_local_cpus(pci_bus_id: str, sysfs_root: str = "/sys/bus/pci/devices") -> Tuple[Optional[int], List[int]]:
+    """(NUMA node, CPUs) the kernel reports as local to the PCI device `dddd:bb:dd.f` (sysfs numa_node / local_cpulist);
+    (None, []) when the host does not say (a VM without NUMA topology: numa_node = -1 and the list covers every CPU)."""
+    base = os.path.join(sysfs_root, pci_bus_id.lower())
+    try:
+        node = int(open(os.path.join(base, "numa_node")).read().strip())
+        cpus = _parse_cpulist(open(os.path.join(base, "local_cpulist")).read())
+    except (OSError, ValueError):
+        return None, []
+    return (node if node >= 0 else None), cpus
+
+
+def pin_rank_to_gpu_numa(device_index: int, world: int, min_cpus: int = 8, pci_bus_id: Optional[str] = None,
+                         sysfs_root: str = "/sys/bus/pci/devices", apply: bool = True) -> dict:
+    """One process per GPU, 8 launching threads each (bench.py): with 8 ranks on a two-socket host the scheduler is free to run
+    a rank's threads on the far socket, where every launch, doorbell write and pinned-buffer read crosses the inter-socket link
+    (VERDICT r4 #9).  Restrict this process to the CPUs local to its GPU's NUMA node -- only when there is more than one rank
+    (a single rank keeps the whole host: its CPU-baseline leg uses the host cores), only if the host reports a node, and only
+    if the node has at least `min_cpus` CPUs allowed to this process.  Returns what was done, for the bench line's per_rank."""
+    info = {"numa_node": None, "cpus_local_to_gpu": 0, "pinned": False, "why": ""}
+    try:
+        if pci_bus_id is None:
+            pr = torch.cuda.get_device_properties(device_index)
+            pci_bus_id = "%04x:%02x:%02x.0" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+        info["pci_bus_id"] = pci_bus_id
+        node, cpus = gpu_local_cpus(pci_bus_id, sysfs_root)
+        info["numa_node"] = node
+        allowed = os.sched_getaffinity(0)
+        local = sorted(set(cpus) & allowed)
+        info["cpus_local_to_gpu"] = len(local)
+        if world <= 1:
+            info["why"] = "one rank: the whole host stays available"
+        elif node is None:
+            info["why"] = "the host reports no NUMA node for the device"
+        elif len(local) < min_cpus or len(local) >= len(allowed):
+            info["why"] = "local CPU set too small or not a proper subset of the allowed CPUs"
+        elif apply:
+            os.sched_setaffinity(0, local)
+            info["pinned"] = True
+            info["why"] = f"{len(local)} of {len(allowed)} allowed CPUs are local to NUMA node {node}"
+    except Exception as e:  # noqa: BLE001  (placement is an optimisation: never fail a run over it)
+        info["why"] = f"not attempted: {type(e).__name__}: {e}"
+    return info

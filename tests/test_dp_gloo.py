@@ -124,3 +124,55 @@ def test_bench_failing_rank_gives_nonzero_exit():
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_gpus_8_dry_plan_balances_audio_and_prints_one_line():
+    """the driver's SCALE command shape at N = 8 on CPU -- `bench.py --gpus 8 --steps 20 --warmup 5 --dry-plan` as
+    typed: eight ranks over gloo, every rank's planned audio seconds within 1 % of the mean, exactly one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-plan"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["dry_plan"] and out["scaling"] == "weak"
+    audio = [p["audio_s"] for p in out["per_rank"]]
+    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and all(p["utterances"] == 20 * 64 for p in out["per_rank"])
+    mean = sum(audio) / 8
+    assert max(abs(a - mean) for a in audio) / mean < 0.01, audio
+    assert all("numa_node" in p and p["pinned_to_numa_node"] is False for p in out["per_rank"])     # dry plan never pins
+    assert out["comm"]["results_ok"] and out["comm"]["world"] == 8
+
+
+def test_numa_pinning_picks_the_gpus_local_cpus(tmp_path):
+    """dp.pin_rank_to_gpu_numa against a fake sysfs: a device on node 1 whose local CPUs are a proper subset of the allowed ones."""
+    from streamspeech_amd import dp
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        import pytest
+        pytest.skip("one CPU")
+    local = allowed[: max(1, len(allowed) // 2)]
+    d = tmp_path / "0000:c1:00.0"
+    d.mkdir()
+    (d / "numa_node").write_text("1\n")
+    (d / "local_cpulist").write_text(",".join(str(c) for c in local) + "\n")
+    assert dp.gpu_local_cpus("0000:C1:00.0", str(tmp_path)) == (1, local)
+    info = dp.pin_rank_to_gpu_numa(0, 8, min_cpus=1, pci_bus_id="0000:c1:00.0", sysfs_root=str(tmp_path), apply=False)
+    assert info["numa_node"] == 1 and info["cpus_local_to_gpu"] == len(local) and info["pinned"] is False   # apply=False: decision only
+    one = dp.pin_rank_to_gpu_numa(0, 1, min_cpus=1, pci_bus_id="0000:c1:00.0", sysfs_root=str(tmp_path))
+    assert one["pinned"] is False and "one rank" in one["why"]
+    import subprocess
+    import sys
+    code = ("import os,sys; sys.path.insert(0, %r); from streamspeech_amd import dp; "
+            "i = dp.pin_rank_to_gpu_numa(0, 8, min_cpus=1, pci_bus_id='0000:c1:00.0', sysfs_root=%r); "
+            "print(i['pinned'], sorted(os.sched_getaffinity(0)) == %r)") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), str(tmp_path), local)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.stdout.split() == ["True", "True"], (r.stdout, r.stderr[-500:])
+    (d / "numa_node").write_text("-1\n")
+    assert dp.pin_rank_to_gpu_numa(0, 8, pci_bus_id="0000:c1:00.0", sysfs_root=str(tmp_path))["pinned"] is False
