@@ -629,6 +629,7 @@ def main():
     ap.add_argument("--streams", type=int, default=8,
                     help="concurrent HIP streams per GPU (own scratch context each)")
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the single-stream latency measurement")
+    ap.add_argument("--no-soak", action="store_true", help="skip the >= 100-step sustained passes after the timed region")
     ap.add_argument("--batch", type=int, default=64,
                     help="utterances packed per ragged batch (1 = the one-utterance-at-a-time entry points)")
     ap.add_argument("--mode", choices=("offline", "streaming"), default="offline",
@@ -883,7 +884,12 @@ def main():
             pass
         common = {"kernel": name, "launches": int(n), "avg_launch_us": round(1e3 * ms / n, 2),
                   "algo_gflop_per_launch": round(fl / n / 1e9, 4), "algo_mbytes_per_launch": round(by / n / 1e6, 3),
-                  "traffic": traffic, "traffic_detail": traffic_detail, "kernel_time_over_wall": round(ms * 1e-3 / wall, 3)}
+                  "traffic": traffic,
+                  # `traffic` comes from a separate PMC run with its OWN launch mix: divide it by THAT run's algorithmic bytes (next
+                  # two keys), never by algo_mbytes_per_launch of this run
+                  "traffic_over_algorithmic": None if not traffic_detail else traffic_detail["traffic_over_algorithmic"],
+                  "algorithmic_mbytes_per_launch_of_the_pmc_run": None if not traffic_detail else traffic_detail["algorithmic_mbytes_per_launch_of_the_pmc_run"],
+                  "traffic_detail": traffic_detail, "kernel_time_over_wall": round(ms * 1e-3 / wall, 3)}
         if name.startswith("smallm"):
             # M <= 128 projections / M = 1 decode GEMVs stream their weights once: HBM-side roofline
             ach = by / (ms * 1e-3) / 1e9
@@ -920,9 +926,15 @@ def main():
                 "event_bracket_time_over_wall": r["kernel_time_over_wall"], "concurrent_streams": S}
 
     roofline, roofline_conv = in_region, in_region_conv
+    roofline_family, dispatch = None, None
+    WINO = [c for c in range(lib.ss_prof_num_classes()) if lib.ss_prof_class_name(c).decode().startswith(("conv_c64w", "conv_c128w", "conv_c32w", "conv_c256w"))]
     if dom is not None and S > 1 and work and not os.environ.get("SS_BENCH_NO_REPLAY"):   # (tools/jobs/*trace*: keep the trace to the timed region)
         lib.ss_prof_reset()
-        lib.ss_prof_enable((1 << dom) | ((1 << dom_conv) if dom_conv is not None else 0))
+        mask = (1 << dom) | ((1 << dom_conv) if dom_conv is not None else 0)
+        for c in WINO:
+            mask |= 1 << c
+        lib.ss_prof_enable(mask)
+        lib.ss_prof_shape_log(1)
         t_rep = time.perf_counter()
         for wk in work:
             if Bsz == 1:
@@ -932,6 +944,39 @@ def main():
         torch.cuda.synchronize()
         rep_wall = time.perf_counter() - t_rep
         lib.ss_prof_enable(0)
+        lib.ss_prof_shape_log(0)
+        # ---- which kernel class took which conv / linear shape in this run (the replay = the timed batches on one stream) ----
+        need = lib.ss_prof_shape_dump(None, 0)
+        buf = C.create_string_buffer(need + 16)
+        lib.ss_prof_shape_dump(buf, need + 16)
+        rows = [ln.split() for ln in buf.value.decode().splitlines()[1:]]
+        tot_fl = sum(float(r[7]) * int(r[5]) for r in rows) or 1.0
+        rows.sort(key=lambda r: -float(r[7]) * int(r[5]))
+        dispatch = {"columns": ["kernel class", "N", "taps", "Cin", "operands (1 R, 2 R2, 4 twin out, 8 in-act, 16 out-act, 32 GLU, 64 ragged)",
+                                "launches", "mean rows", "GFLOP per launch", "share of algorithmic FLOPs"],
+                    "shapes": [[lib.ss_prof_class_name(int(r[0])).decode(), int(r[1]), int(r[2]), int(r[3]), int(r[4]), int(r[5]), int(float(r[6])),
+                                float(r[7]), round(float(r[7]) * int(r[5]) / tot_fl, 4)] for r in rows[:48]],
+                    "shapes_total": len(rows), "covered_by": "the timed batches replayed on one stream (same dispatch as the timed region)"}
+        # ---- the Winograd F(2,3) family as ONE line: algorithmic fraction and the fraction of the matrix cores' issue rate ----
+        fam_ms = fam_fl = fam_iss = 0.0
+        fam_n, members = 0, {}
+        for c in WINO:
+            ms_c, fl_c, n_c, by_c = read_class(c)
+            if n_c:
+                iss = C.c_double()
+                lib.ss_prof_read_issued(c, C.byref(iss))
+                fam_ms, fam_fl, fam_iss, fam_n = fam_ms + ms_c, fam_fl + fl_c, fam_iss + iss.value, fam_n + n_c
+                members[lib.ss_prof_class_name(c).decode()] = {"launches": int(n_c), "ms": round(ms_c, 2), "algorithmic_tflops": round(fl_c / ms_c / 1e9, 2),
+                                                               "issued_tflops": round(iss.value / ms_c / 1e9, 2)}
+        if fam_n:
+            roofline_family = {"family": "conv_c64w_kernel<LRELU, DIL, CH> (Winograd F(2,3) on the dilation lattice; CH = 32 / 64 / 128 / 256)",
+                               "bound": "mfma", "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "launches": int(fam_n),
+                               "achieved": round(fam_fl / fam_ms / 1e9, 3), "frac": round(fam_fl / fam_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+                               "issued_mfma_tflops": round(fam_iss / fam_ms / 1e9, 3),
+                               "frac_issued": round(fam_iss / fam_ms / 1e9 / PEAK_F32_MFMA_TFLOPS, 4),
+                               "kernel_time_over_replay_wall": round(fam_ms * 1e-3 / rep_wall, 3), "members": members,
+                               "note": "`frac` counts the convs' ALGORITHMIC (direct-form) FLOPs; `frac_issued` counts the MFMAs the kernels issue "
+                                       "(4 ceil(k/3) / (2 k) of them) -- the matrix cores' busy fraction; HIP events on the one-stream replay"}
         wall_keep, wall = wall, rep_wall
         roofline = roofline_of(dom)
         roofline_conv = roofline_of(dom_conv) if dom_conv is not None and dom_conv != dom else None
@@ -996,6 +1041,17 @@ def main():
         lib.ss_prof_reset()
         bracket_ab = {"region_ms_with_event_brackets": round(1e3 * on, 2), "region_ms_without": round(1e3 * off, 2),
                       "with_over_without": round(on / off, 4), "note": "best of two region passes each, right after the timed region"}
+
+    # Sustained figure inside the driver's own line (the timed region is ~1 s): the same region repeated until >= 100
+    # more steps have run, one wall clock around all of them (untimed for `value`).
+    soak = None
+    if world == 1 and Bsz > 1 and S > 1 and work and not args.no_soak:
+        reps = max(1, -(-100 // len(work)))
+        dts = [region_pass() for _ in range(reps)]
+        soak = {"steps": reps * len(work), "value": round(reps * audio / sum(dts), 2), "unit": "x real-time", "ms_per_step": round(1e3 * sum(dts) / (reps * len(work)), 3),
+                "utterances": int(reps * nutt), "gpu_seconds": round(sum(dts), 3), "per_pass_value": [round(audio / d, 1) for d in dts],
+                "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),
+                "note": f"the timed region's {len(work)} batches x {reps} passes on the same {S} streams right after the timed region"}
 
     bf16x3_line = None
     if world == 1 and Bsz > 1 and work and not args.no_bf16x3_line:
@@ -1121,6 +1177,9 @@ def main():
             "pack_invariance": pack_invariance_check(model, work) if (Bsz > 1 and len(work) >= 2) else None,
             "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),   # must be 0 (bounded waits of the stream-K fix-up); also asserted for the timed region
             "roofline": roofline,
+            "roofline_family": roofline_family,
+            "soak": soak,
+            "dispatch": dispatch,
             "bf16x3": bf16x3_line,
             "multilingual": multilingual,
             "event_bracket_perturbation": bracket_ab,

@@ -233,6 +233,15 @@ int ss_prof_read(int cls, double* h_ms_total, double* h_flops_total, int64_t* h_
  * bytes of tile class `cls` over the WHOLE process -- the denominator for a rocprofv3 kernel-stats or PMC run of the
  * same process (bench.py prints them as "process_census"). */
 int ss_prof_totals(int cls, double* h_flops_total, double* h_bytes_total, int64_t* h_launches);
+/* Of the launches ss_prof_read covers: the FLOPs the kernels ISSUE as MFMAs.  Equal to the algorithmic count except for the Winograd
+ * F(2,3) classes, which issue 4 ceil(k/3) / (2 k) of it -- lets bench.py report a matrix-core busy fraction next to the algorithmic one. */
+int ss_prof_read_issued(int cls, double* h_issued_flops_total);
+/* Dispatch table: which kernel class took which conv / linear shape.  ss_prof_shape_log(1) starts a fresh in-process collection,
+ * ss_prof_shape_dump writes "class N taps Cin operands launches mean_rows gflop_per_launch mbyte_per_launch" lines (operands bit mask:
+ * 1 residual, 2 second residual, 4 twin output, 8 input activation, 16 output activation, 32 GLU, 64 ragged segments) into buf and
+ * returns the bytes needed (buf may be NULL).  SS_SHAPE_LOG=<path> writes the same table at process exit. */
+int ss_prof_shape_log(int on);
+int ss_prof_shape_dump(char* buf, int cap);
 int ss_prof_num_classes(void);
 const char* ss_prof_class_name(int cls);
 
@@ -274,7 +283,8 @@ int ss_debug_rtlin(int grid, int enable);
 /* A/B hook of the 64-channel vocoder-stage kernel (csrc/conv_c64.hip): 0 routes that stage's convs back to the stream-K kernel
  * with pre-activated twin tensors (round 3), 1 to it, -1 keeps the setting; 4 / 5 switch the Winograd F(2,3) form of those convs
  * (csrc/conv_c64w.hip) off / on without touching the first setting; 6 / 7 route the 128-channel stage's ResBlock convs to conv_sk2<128>
- * with twins / to the same Winograd kernel at 128 channels. */
+ * with twins / to the same Winograd kernel at 128 channels; 8 / 9 the same for the 256-channel stage (the kernel at CH = 256: two slab
+ * phases of 128 input channels, two column halves). */
 int ss_debug_conv_c64(int enable);
 /* The same for the 32-channel stage (csrc/conv_c32.hip): 0 = one fused launch per ResBlock (round 3), 1 = one launch per conv;
  * 4 / 5 = the Winograd form of those per-conv launches (csrc/conv_c64w.hip at 32 channels) off / on. */

@@ -59,13 +59,23 @@ __global__ void wino_pack_kernel(const float* __restrict__ W, float* __restrict_
 // pairs, so every wave keeps the 32-tile accumulator set, the 8-fragment ring and the register budget (256) of the 64-channel form, and
 // each SIMD still holds two waves that hide each other's fragment latency (a 64-tile accumulator set per wave made hipcc shuffle
 // accumulators between register classes inside the loop: 1300 moves per 2048 MFMAs, 200+ spills).
+// CH = 256 (round 5: the 256-channel stage, until then on conv_sk2<128> + twins): the 128-channel form run over TWO slab phases and TWO
+// column halves.  A 256-channel slab row is 1 KB -- a block with its halo does not fit the LDS -- so the contraction walks the input
+// channels in two halves of 128 (slab phase kh: stage channels [128 kh, 128 kh + 128) of the block's rows, contract them into the
+// SAME four accumulator sets, restage), and a workgroup produces 128 of the 256 output columns: workgroup w works column half
+// (w >> 3) & 1 -- a constant of the workgroup, so its weight rows and the ring prefetch across blocks never change -- and the two
+// workgroups that share a block (w and w ^ 8) sit on the same XCD (block w % 8 of the dispatch order), so the second reader of the
+// block's input rows hits that XCD's L2.  Per (block, column half) twice the MFMA work and twice the staging of the 128-channel form.
 template <bool LRELU, int DIL, int CH>
-__global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2 : 3) void conv_c64w_kernel(const GemmArgs p, const int groups, const int slab_rows) {
+__global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2 : 3) void conv_c64w_kernel(const GemmArgs p, const int groups, const int slab_rows) {
 #if __HIP_DEVICE_COMPILE__
   // (CH = 32: the k = 11 ResBlock convs of the 32-channel stage, three workgroups per CU: 2 column tiles, 16 MFMAs per sub-step)
-  constexpr int C = CH, LDA = CH + 4, CT = CH >= 64 ? 4 : CH / 16, CB = CH / 16, NSS = CB * 4, RING = 2 * CT, TPR = CH / 4;   // TPR threads stage one row
-  constexpr int NT = CH == 128 ? 512 : 256, RPP = NT / TPR;                 // rows per staging pass (16; 32 at 32 channels)
-  constexpr int NP = (CW_MAXROWS + RPP - 1) / RPP, NPC = NP < 20 ? NP : 20, BME = cw_bme(DIL), NPAIR = BME / 2;
+  constexpr int CS = CH == 256 ? 128 : CH;                                  // input channels of one slab phase
+  constexpr int KH = CH / CS;                                               // slab phases
+  constexpr int C = CH, LDA = CS + 4, CT = CH >= 64 ? 4 : CH / 16, CB = CS / 16, NSS = CB * 4, RING = 2 * CT, TPR = CS / 4;   // TPR threads stage one row
+  constexpr int NT = CH >= 128 ? 512 : 256, RPP = NT / TPR;                 // rows per staging pass (16; 32 at 32 channels)
+  // (CH = 256: the accumulators stay live across the second phase's staging -- 10 float4 in flight per thread, two passes)
+  constexpr int NP = (CW_MAXROWS + RPP - 1) / RPP, NPC = CH == 256 ? 10 : NP < 20 ? NP : 20, BME = cw_bme(DIL), NPAIR = BME / 2;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;                                                        // slab [slab_rows][68]
   int* s_blk = reinterpret_cast<int*>(smem + ((slab_rows * LDA + 3) & ~3));   // block prefix per segment
@@ -73,6 +83,8 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane((t >> 6) & 3);
   const int cs = CH <= 64 ? 0 : __builtin_amdgcn_readfirstlane(t >> 8);     // column set of this wave
+  const int colh = CH == 256 ? (int)((blockIdx.x >> 3) & 1) : 0;             // column half of this WORKGROUP (CH = 256)
+  const int col0 = colh * 128 + cs * 64;                                    // first output column of this wave
   const int r = lane & 15, g = lane >> 4;
   const int Kw = groups * 4 * C;                                           // row length of the transformed weight matrix
 
@@ -101,17 +113,19 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
   // ---- weight fragments: L2 -> registers.  Fragment (idx = group * 4 + component, channel block cc, column tile ct) ----
   const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, CW_NUM_RECORDS, 0x00020000);
   const int vo = (r * Kw + 4 * g) * 4;
-  auto wload = [&](int idx, int cc, int ct) -> f32x4 {
-    const int so = __builtin_amdgcn_readfirstlane((((cs * 4 + ct) * 16) * Kw + idx * C + cc * 16) * 4);
+  auto wload = [&](int idx, int cc, int ct, int kh) -> f32x4 {
+    const int so = __builtin_amdgcn_readfirstlane(((col0 + ct * 16) * Kw + idx * C + kh * CS + cc * 16) * 4);
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, vo, so, 0);
     return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
   };
 
-  int blk = blockIdx.x;
+  // CH = 256: workgroups 16 a + b and 16 a + 8 + b (b < 8) share block index 8 a + b and its stride (grid % 16 == 0, host)
+  int blk = CH == 256 ? (int)((blockIdx.x & 7) + 8 * (blockIdx.x >> 4)) : (int)blockIdx.x;
+  const int blk_stride = CH == 256 ? (int)(gridDim.x >> 1) : (int)gridDim.x;
   if (blk >= nblocks) return;
   f32x4 ring[RING];                            // sub-steps 0 and 1 of group 0: (cc 0, f 0), (cc 0, f 1)
 #pragma unroll
-  for (int q = 0; q < RING; ++q) ring[q] = wload(q / CT, 0, q % CT);
+  for (int q = 0; q < RING; ++q) ring[q] = wload(q / CT, 0, q % CT, 0);
 
   // this lane's two pairs (pair tile i = 0 / 1 of the wave): first row of pair p = 2 d (p / d) + p % d, the second is + d
   int toff[2];
@@ -124,12 +138,22 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
     toff[i] = 2 * DIL * (pc / DIL) + pc % DIL;
   }
 
-  for (; blk < nblocks; blk += gridDim.x) {
+  for (; blk < nblocks; blk += blk_stride) {
     locate(blk);
     const int cm0 = m0;
     const int m_hi = p.nseg > 0 ? seg_hi : min(seg_hi, p.M);
     const bool edge = (m0 - p.pad < seg_lo) || (m0 - p.pad + slab_rows > seg_hi);
-    __syncthreads();                                       // previous block's slab reads are done
+    f32x4 acc[4][2][CT];                                   // [component][pair tile][column tile]
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[f][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kh = 0; kh < KH; ++kh) {                       // slab phases (one, except CH = 256: two halves of the input channels)
+    const int kh_wrap = kh + 1 < KH ? kh + 1 : 0;          // phase of the fragments requested past this phase's last group
+    __syncthreads();                                       // previous slab's reads are done
     // ---- slab: global -> registers -> [zero padding, leaky-ReLU] -> LDS (as conv_c64.hip), 20 float4 per thread in flight at a time ----
 #pragma unroll 1
     for (int u0 = 0; u0 < NP; u0 += NPC) {
@@ -138,7 +162,7 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
       for (int u = 0; u < NPC; ++u) {
         const int rho = t / TPR + RPP * (u0 + u);
         const int gc = min(max(m0 - p.pad + rho, seg_lo), seg_hi - 1);
-        pre[u] = *reinterpret_cast<const f32x4*>(p.A + (size_t)gc * p.lda + (t % TPR) * 4);
+        pre[u] = *reinterpret_cast<const f32x4*>(p.A + (size_t)gc * p.lda + kh * CS + (t % TPR) * 4);
       }
       float* dst = sA + (t / TPR + RPP * u0) * LDA + (t % TPR) * 4;
 #pragma unroll
@@ -159,14 +183,6 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
       }
     }
     __syncthreads();
-
-    f32x4 acc[4][2][CT];                                   // [component][pair tile][column tile]
-#pragma unroll
-    for (int f = 0; f < 4; ++f)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < CT; ++j) acc[f][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // rows of component f (in units of d rows from the group's first input row): D_f = x[ja] (+/-) x[jb]
     //   f = 0: x0 - x2    f = 1: x1 + x2    f = 2: x2 - x1    f = 3: x1 - x3
@@ -195,7 +211,8 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
           const int q = ss * CT + j;                                    // fragment of this group; its ring slot is re-armed two sub-steps ahead
           wf[j] = ring[q % RING];
           const int s2 = ss + 2;
-          ring[q % RING] = wload((s2 < NSS ? grp : grp_next) * 4 + (s2 & 3), (s2 % NSS) >> 2, j);
+          ring[q % RING] = wload((s2 < NSS ? grp : grp_next) * 4 + (s2 & 3), (s2 % NSS) >> 2, j,
+                                 (s2 < NSS || grp + 1 < groups) ? kh : kh_wrap);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -211,6 +228,7 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
       pa0 = pn0;
       pa1 = pn1;
     }
+    }   // slab phases
 
     // ---- output transform + epilogue: lane holds 4 consecutive channels (4g .. 4g+3 of column tile j) of both rows of pair r ----
     int le = lane;
@@ -220,7 +238,7 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
 #pragma unroll
     for (int j = 0; j < CT; ++j) {
       bb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (p.bias) bb[j] = *reinterpret_cast<const f32x4*>(p.bias + cs * 64 + j * 16 + g_e * 4);
+      if (p.bias) bb[j] = *reinterpret_cast<const f32x4*>(p.bias + col0 + j * 16 + g_e * 4);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -231,15 +249,15 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
         f32x4 rr[CT], rr2[CT];
         if (p.R) {
 #pragma unroll
-          for (int j = 0; j < CT; ++j) rr[j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + cs * 64 + j * 16 + g_e * 4);
+          for (int j = 0; j < CT; ++j) rr[j] = *reinterpret_cast<const f32x4*>(p.R + (size_t)mc * p.ldr + col0 + j * 16 + g_e * 4);
         }
         if (p.R2) {
 #pragma unroll
-          for (int j = 0; j < CT; ++j) rr2[j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)mc * p.ldr2 + cs * 64 + j * 16 + g_e * 4);
+          for (int j = 0; j < CT; ++j) rr2[j] = *reinterpret_cast<const f32x4*>(p.R2 + (size_t)mc * p.ldr2 + col0 + j * 16 + g_e * 4);
         }
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
-          const int n = cs * 64 + j * 16 + g_e * 4;
+          const int n = col0 + j * 16 + g_e * 4;
           f32x4 v = h == 0 ? (acc[0][i][j] + acc[1][i][j]) + acc[2][i][j] : (acc[1][i][j] - acc[2][i][j]) - acc[3][i][j];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] += bb[j][e];
@@ -263,7 +281,7 @@ __global__ __launch_bounds__(CH == 128 ? 512 : 256, CH == 128 ? 1 : CH == 64 ? 2
           }
           if (pv[i] && m < m_hi) {
             *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + n) = v;
-            if (CH == 128 && p.C2) {                         // pre-activated twin for a consumer that cannot activate while staging (conv_sk2)
+            if (CH >= 128 && p.C2) {                         // pre-activated twin for a consumer that cannot activate while staging (conv_sk2)
               f32x4 w2;
 #pragma unroll
               for (int e = 0; e < 4; ++e) w2[e] = v[e] > 0.f ? v[e] : v[e] * p.c2_slope;
@@ -286,6 +304,11 @@ void conv_c64w_debug(int enable) { if (enable >= 0) g_c64w_on = enable ? 1 : 0; 
 bool conv_c64w_enabled() { return g_c64w_on != 0; }
 void conv_c128w_debug(int enable) { if (enable >= 0) g_c128w_on = enable ? 1 : 0; }
 bool conv_c128w_enabled() { return g_c128w_on != 0; }
+
+static int g_c256w_on = getenv("SS_CONV_C256_WINOGRAD") ? atoi(getenv("SS_CONV_C256_WINOGRAD")) : 1; // A/B knob: 0 = the 256-channel stage on conv_sk2<128> (pre-activated twins)
+static long long g_c256w_min_rows = getenv("SS_CONV_C256_MIN_ROWS") ? atoll(getenv("SS_CONV_C256_MIN_ROWS")) : 32768;  // >= a (block, column half) per CU
+void conv_c256w_debug(int enable) { if (enable >= 0) g_c256w_on = enable ? 1 : 0; }
+bool conv_c256w_enabled() { return g_c256w_on != 0; }
 
 static int cw_groups(const GemmArgs& a) { return (a.taps + 2) / 3; }
 static size_t cw_lds(const GemmArgs& a, int ch) {
@@ -318,6 +341,19 @@ bool conv_c128w_eligible(const GemmArgs& a) {
   return slab_rows <= CW_MAXROWS && cw_lds(a, 128) <= 160 * 1024;
 }
 
+// The 256-channel stage in the same form (two slab phases of 128 input channels, two column halves): all-or-nothing per stage like the
+// 128-channel one (model.hip probes every conv).
+bool conv_c256w_eligible(const GemmArgs& a) {
+  if (!g_c256w_on || !a.Wwino || !a.same_rows || a.stride != 1 || a.chunk || a.glu || a.ln_g || a.x3 || a.Cin != 256 || a.N != 256) return false;
+  if (a.lda != 256 || (a.ldc & 3) || (a.R && (a.ldr & 3)) || (a.R2 && (a.ldr2 & 3)) || (a.C2 && (a.ldc2 & 3))) return false;
+  if (a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.pad != a.dil * (a.taps - 1) / 2) return false;
+  if (a.nseg > CW_MAXSEG || a.M < g_c256w_min_rows || ((size_t)(a.M + a.pad + 512) * a.lda) * 4 >= 0x7ff00000ull) return false;
+  if ((size_t)256 * cw_groups(a) * 4 * 256 * 4 >= 0x7ff00000ull) return false;
+  if (!(a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) || !(a.act == ACT_NONE || a.act == ACT_LRELU)) return false;
+  const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
+  return slab_rows <= CW_MAXROWS && cw_lds(a, 128) <= 160 * 1024;
+}
+
 int launch_wino_pack(const float* W, float* WW, int C, int taps, hipStream_t stream) {
   const int groups = (taps + 2) / 3, n = C * groups * C;
   hipLaunchKernelGGL(wino_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, W, WW, C, taps, groups);
@@ -330,19 +366,23 @@ static int launch_cw_t(GemmArgs a, hipStream_t stream) {
   constexpr int BME = cw_bme(DIL);
   const int groups = cw_groups(a);
   const int slab_rows = BME + 3 * groups * DIL;
-  const size_t lds = cw_lds(a, CH);
-  SS_MAX_LDS_ONCE((&conv_c64w_kernel<LRELU, DIL, CH>), CH == 128 ? 160 * 1024 : 96 * 1024);
+  const size_t lds = cw_lds(a, CH == 256 ? 128 : CH);
+  SS_MAX_LDS_ONCE((&conv_c64w_kernel<LRELU, DIL, CH>), CH >= 128 ? 160 * 1024 : 96 * 1024);
   SkWorkspace* st = nullptr;                       // (only for the device's CU count, cached per context)
   int rc = sk_workspace_acquire(stream, &st);
   if (rc != SS_OK) return rc;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   const long long max_blocks = (long long)cdiv(a.M, BME) + nseg;      // upper bound (per-segment round-up)
-  const int grid = (int)std::min<long long>((CH == 128 ? 1ll : CH == 64 ? 2ll : 3ll) * st->cus, std::max<long long>(1, max_blocks));
+  int grid = (int)std::min<long long>((CH >= 128 ? 1ll : CH == 64 ? 2ll : 3ll) * st->cus, std::max<long long>(1, max_blocks));
+  if (CH == 256) {                                 // (block, column half) items: workgroups come in groups of 16 = 8 blocks x 2 halves
+    const long long want = std::min<long long>(st->cus, 2 * ((max_blocks + 7) / 8 * 8));
+    grid = (int)std::max<long long>(16, want / 16 * 16);
+  }
   ProfRec rec{}; bool prof = false;
-  rc = prof_begin(a, stream, CH == 64 ? 27 : CH == 128 ? 28 : 29, rec, prof);   // census: the conv's algorithmic (direct-form) FLOPs; the kernel issues 4 G / (2 k) of them
+  rc = prof_begin(a, stream, CH == 64 ? 27 : CH == 128 ? 28 : CH == 256 ? 30 : 29, rec, prof);   // census: the conv's algorithmic (direct-form) FLOPs; the kernel issues 4 G / (2 k) of them
   if (rc != SS_OK) return rc;
   a.W = a.Wwino;
-  hipLaunchKernelGGL((conv_c64w_kernel<LRELU, DIL, CH>), dim3(grid), dim3(CH == 128 ? 512 : 256), lds, stream, a, groups, slab_rows);
+  hipLaunchKernelGGL((conv_c64w_kernel<LRELU, DIL, CH>), dim3(grid), dim3(CH >= 128 ? 512 : 256), lds, stream, a, groups, slab_rows);
   SS_LAUNCH_CHECK();
   return prof_end(stream, rec, prof);
 }
@@ -378,6 +418,10 @@ int launch_conv_c32w(const GemmArgs& a, hipStream_t stream) {
 int launch_conv_c128w(const GemmArgs& a, hipStream_t stream) {
   if (!conv_c128w_eligible(a)) return SS_ERR_ARG;
   return launch_cw<128>(a, stream);
+}
+int launch_conv_c256w(const GemmArgs& a, hipStream_t stream) {
+  if (!conv_c256w_eligible(a)) return SS_ERR_ARG;
+  return launch_cw<256>(a, stream);
 }
 
 }  // namespace ss

@@ -78,15 +78,21 @@ void canon_debug_set(int mode);        // test hook: the calling thread's mode o
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 30;
+constexpr int kNumTileCfg = 31;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
 const char* prof_cfg_name(int cls);
 int prof_totals(int cls, double* flops, double* bytes, long long* launches);   // always-on census since library load
+int prof_read_issued(int cls, double* issued_flops_total);   // of the bracketed launches: FLOPs the kernel ISSUES as MFMAs (the Winograd forms issue 4 ceil(k/3) / (2 k) of the algorithmic count)
+// Per-shape dispatch table (which kernel class took which (N, taps, Cin, operands) shape): SS_SHAPE_LOG=<path> writes it at exit;
+// prof_shape_log(1) collects it from now on in-process, prof_shape_dump writes "class N taps Cin operands launches mean_rows
+// gflop_per_launch mbyte_per_launch" lines into buf (returns the bytes needed, buf may be null) -- bench.py's `dispatch` object.
+void prof_shape_log(int on);
+int prof_shape_dump(char* buf, int cap);
 
 // Event-profiler scope shared by the kernel launchers (gemm.hip, conv_sk.hip).
-struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int cls; };
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes, issued; int cls; };
 int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, bool& prof);
 int prof_end(hipStream_t stream, ProfRec& rec, bool prof);
 
@@ -165,6 +171,11 @@ bool conv_c128w_eligible(const GemmArgs& a);
 int launch_conv_c128w(const GemmArgs& a, hipStream_t stream);
 void conv_c128w_debug(int enable);
 bool conv_c128w_enabled();
+// ... at 256 channels (two slab phases of 128 input channels, two column halves; one workgroup per CU): the 256-channel stage's ResBlock convs
+bool conv_c256w_eligible(const GemmArgs& a);
+int launch_conv_c256w(const GemmArgs& a, hipStream_t stream);
+void conv_c256w_debug(int enable);
+bool conv_c256w_enabled();
 // ... and at 32 channels (three workgroups per CU): the per-conv launches of the 32-channel stage (k = 11)
 bool conv_c32w_eligible(const GemmArgs& a);       // call with conv_c32_eligible(a) already true
 int launch_conv_c32w(const GemmArgs& a, hipStream_t stream);

@@ -1029,7 +1029,7 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
   if (!w.missing.empty()) { sk_workspace_free(v->skws); delete v; return SS_ERR_MISSING_WEIGHT; }
   {
     // Winograd forms of the 32-, 64- and 128-channel stages' ResBlock convs (conv_c64w.hip), made once per context from the packed weights
-    auto wino_stage = [](int ch) { return ch == 32 || ch == 64 || ch == 128; };
+    auto wino_stage = [](int ch) { return ch == 32 || ch == 64 || ch == 128 || ch == 256; };
     size_t need = 0;
     int Cs = C0;
     for (int i = 0; i < cfg->n_up; ++i) {
@@ -1139,10 +1139,10 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
   // The 128-channel stage of a packed batch: its ResBlock convs in Winograd form on the slab kernel (conv_c64w.hip at 128 channels), which
   // activates while staging -- so the convs of that stage neither read nor write twins; only the up-conv that LEAVES the stage (on conv_sk2)
   // still reads one, written by the stage's last conv.  Taken only if every conv of the stage is eligible (there is no direct slab form).
-  const bool c128 = [&]() {
-    if (v->x3 || !conv_c128w_enabled()) return false;
+  auto wino_slab_stage = [&](int channels) {
+    if (v->x3 || !(channels == 128 ? conv_c128w_enabled() : conv_c256w_enabled())) return false;
     long long rows = Ft; int ch = c.upsample_initial_channel, stage = -1;
-    for (int i = 0; i < c.n_up && stage < 0; ++i) { rows *= c.upsample_rates[i]; ch /= 2; if (ch == 128) stage = i; }
+    for (int i = 0; i < c.n_up && stage < 0; ++i) { rows *= c.upsample_rates[i]; ch /= 2; if (ch == channels) stage = i; }
     if (stage < 0 || rows >= (1ll << 30)) return false;
     int sc = 1, gM = 0, gnseg = 0; const int* gsegs = nullptr;
     for (int i = 0; i <= stage; ++i) sc *= c.upsample_rates[i];
@@ -1152,16 +1152,20 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
         for (int which = 0; which < 2; ++which) {
           const int idx = (stage * c.n_res + j) * 3 + dd;
           GemmArgs probe;
-          probe.same_rows = 1; probe.Cin = probe.N = probe.lda = probe.ldc = probe.ldr = probe.ldr2 = probe.ldc2 = 128;
+          probe.same_rows = 1; probe.Cin = probe.N = probe.lda = probe.ldc = probe.ldr = probe.ldr2 = probe.ldc2 = channels;
           probe.taps = c.resblock_kernel_sizes[j]; probe.dil = which ? 1 : c.resblock_dilations[j][dd];
           probe.pad = probe.dil * (probe.taps - 1) / 2; probe.M = probe.in_len = gM; probe.nseg = gnseg; probe.in_act = ACT_LRELU;
           probe.Wwino = which ? v->rb_c2[idx].ww : v->rb_c1[idx].ww;
-          if (!conv_c128w_eligible(probe)) return false;
+          if (!(channels == 128 ? conv_c128w_eligible(probe) : conv_c256w_eligible(probe))) return false;
         }
     return true;
-  }();
+  };
+  // (round 5: the 256-channel stage the same way -- conv_c64w.hip at CH = 256: two slab phases of 128 input channels, two column halves)
+  const bool c128 = wino_slab_stage(128), c256 = wino_slab_stage(256);
   // does a ResBlock conv of this stage read a pre-activated twin?  (does the producer have to write one?)
-  auto preact = [c64, c128](int channels) { return channels >= 64 && !(c64 && channels == 64) && !(c128 && channels == 128); };
+  auto preact = [c64, c128, c256](int channels) {
+    return channels >= 64 && !(c64 && channels == 64) && !(c128 && channels == 128) && !(c256 && channels == 256);
+  };
   // the up-conv that leaves a stage runs on conv_sk2 for >= 128 channels (N = stride x C / 2) and on conv_c64 for the 64-channel stage
   auto up_preact = [c64](int channels) { return channels >= 64 && !(c64 && channels == 64); };
   auto mk = [v](const float* A, int Cin, const ConvW& cw, int Cout, int k, int dil, float* Cc, int ldc) {
@@ -1799,6 +1803,7 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
   DevBuf& wino_tmp = wino_tmps[(hipStream_t)stream];
   if ((conv_c64w_enabled() && N == 64 && Cin == 64 && taps >= 3 && conv_c64_eligible(a)) ||
       (conv_c128w_enabled() && N == 128 && Cin == 128 && taps >= 3 && a.same_rows && !glu) ||
+      (conv_c256w_enabled() && N == 256 && Cin == 256 && taps >= 3 && a.same_rows && !glu) ||
       (conv_c32w_enabled() && N == 32 && Cin == 32 && taps >= 3 && conv_c32_eligible(a))) {
     RET(wino_tmp.ensure((size_t)N * ((taps + 2) / 3) * 4 * N * sizeof(float)));
     RET(launch_wino_pack(dW, wino_tmp.f(), N, taps, (hipStream_t)stream));
@@ -1851,6 +1856,7 @@ extern "C" int ss_op_ln_linear(void* stream, const float* dX, int ldx, const flo
 extern "C" int ss_debug_conv_c64(int enable) {
   if (enable == 4 || enable == 5) { conv_c64w_debug(enable == 5); return SS_OK; }
   if (enable == 6 || enable == 7) { conv_c128w_debug(enable == 7); return SS_OK; }     // the 128-channel stage: conv_sk2<128> + twins / Winograd slab
+  if (enable == 8 || enable == 9) { conv_c256w_debug(enable == 9); return SS_OK; }     // the 256-channel stage: conv_sk2<128> + twins / Winograd slab (two phases)
   conv_c64_debug(enable);
   return SS_OK;
 }
@@ -1918,6 +1924,9 @@ extern "C" int ss_prof_totals(int cls, double* flops, double* bytes, int64_t* la
   if (launches) *launches = n;
   return rc;
 }
+extern "C" int ss_prof_read_issued(int cls, double* issued_flops) { return prof_read_issued(cls, issued_flops); }
+extern "C" int ss_prof_shape_log(int on) { prof_shape_log(on); return SS_OK; }
+extern "C" int ss_prof_shape_dump(char* buf, int cap) { return prof_shape_dump(buf, cap); }
 extern "C" int ss_prof_num_classes(void) { return kNumTileCfg; }
 extern "C" const char* ss_prof_class_name(int cls) { return prof_cfg_name(cls); }
 

@@ -76,6 +76,9 @@ SIGNATURES = {
     "ss_prof_reset": (_i, []),
     "ss_prof_read": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64), C.POINTER(C.c_double)]),
     "ss_prof_totals": (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "ss_prof_read_issued": (_i, [_i, C.POINTER(C.c_double)]),
+    "ss_prof_shape_log": (_i, [_i]),
+    "ss_prof_shape_dump": (_i, [C.c_char_p, _i]),
     "ss_prof_num_classes": (_i, []),
     "ss_prof_class_name": (C.c_char_p, [_i]),
     "ss_debug_force_tile": (_i, [_i, _i, _i]),

@@ -544,6 +544,42 @@ def test_conv_c128_winograd_kernel(lib, taps, dil, M, extras):
     assert e_win < 2.0 * e_dir + 1e-8, (float(e_dir), float(e_win))
 
 
+@pytest.mark.parametrize("taps,dil,M,extras", [(3, 1, 40000, True), (3, 5, 33001, False), (7, 3, 32768, True), (7, 5, 36003, True),
+                                               (11, 1, 35000, False), (11, 3, 33001, True), (11, 5, 34999, True)])
+def test_conv_c256_winograd_kernel(lib, taps, dil, M, extras):
+    """csrc/conv_c64w.hip at 256 channels (round 5: the 256-channel vocoder stage of a packed batch -- the 128-channel form over two slab
+    phases of 128 input channels and two column halves per block, workgroup pairs on one XCD): against torch float64, against the stream-K
+    kernel it replaces (ss_debug_conv_c64(8)), and as close to float64 as that direct form; the pre-activated twin is exercised by the
+    model-level tests (the up-conv that leaves the stage reads it)."""
+    from streamspeech_amd.weights import conv_tap_major
+    C = 256
+    x = rnd(M, C, seed=41)
+    w = rnd(C, C, taps, seed=42, scale=(C * taps) ** -0.5)
+    b = rnd(C, seed=43, scale=0.1)
+    R, R2 = (rnd(M, C, seed=44), rnd(M, C, seed=45)) if extras else (None, None)
+    pad = dil * (taps - 1) // 2
+    xin = F.leaky_relu(x, 0.1)
+    y = F.conv1d(F.pad(xin.t()[None].double(), (pad, pad)), w.double(), b.double(), dilation=dil)[0].t()
+    ref = ((R2.double() + (y + R.double())) / 3.0) if extras else y
+    kw = dict(taps=taps, dil=dil, pad=pad, in_act=3, slope=0.1, R=R, R2=R2, div=3.0 if extras else 0.0)
+    lib.ss_debug_conv_c64(9)
+    n0 = _class_launches_ops(lib, "conv_c256w<256,128>")
+    got = run_conv_gemm(lib, x, conv_tap_major(w), b, M, C, C, **kw)
+    assert _class_launches_ops(lib, "conv_c256w<256,128>") == n0 + 1, "the Winograd slab kernel must have taken the launch"
+    assert torch.isfinite(got).all()
+    assert (got.double() - ref).abs().max() < TOL, f"max err {(got.double() - ref).abs().max()}"
+    lib.ss_debug_conv_c64(8)
+    try:      # the stream-K kernel reads a pre-activated input
+        old = run_conv_gemm(lib, xin.contiguous(), conv_tap_major(w), b, M, C, C, **dict(kw, in_act=0))
+    finally:
+        lib.ss_debug_conv_c64(9)
+    assert _class_launches_ops(lib, "conv_c256w<256,128>") == n0 + 1
+    assert (got - old).abs().max() < 2e-5
+    e_dir = ((old.double() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()
+    e_win = ((got.double() - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()
+    assert e_win < 2.0 * e_dir + 1e-8, (float(e_dir), float(e_win))
+
+
 def _class_launches_ops(lib, name):
     for c in range(lib.ss_prof_num_classes()):
         if lib.ss_prof_class_name(c).decode() == name:

@@ -19,9 +19,9 @@ def P(t):
 
 
 def main():
-    M = int(sys.argv[1]) if len(sys.argv) > 1 else {128: 288000, 64: 576000, 32: 1152000, 16: 2304000}[CH]
+    M = int(sys.argv[1]) if len(sys.argv) > 1 else {256: 144000, 128: 288000, 64: 576000, 32: 1152000, 16: 2304000}[CH]
     lib = L.load()
-    dbg = {128: lambda on: lib.ss_debug_conv_c64(7 if on else 6), 64: lib.ss_debug_conv_c64, 32: lib.ss_debug_conv_c32, 16: lib.ss_debug_conv_c16}[CH]
+    dbg = {256: lambda on: lib.ss_debug_conv_c64(9 if on else 8), 128: lambda on: lib.ss_debug_conv_c64(7 if on else 6), 64: lib.ss_debug_conv_c64, 32: lib.ss_debug_conv_c32, 16: lib.ss_debug_conv_c16}[CH]
     g = torch.Generator(device="cuda").manual_seed(0)
     rn = lambda *s, sc=1.0: torch.randn(*s, device="cuda", generator=g) * sc     # noqa: E731
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
