@@ -30,6 +30,17 @@ namespace ss {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
 
+// Diagnostic build only (-DCW_TIMING=1, tools/cw_timing.py): thread 0 of every workgroup accumulates s_memtime cycles per phase.
+#ifndef CW_TIMING
+#define CW_TIMING 0
+#endif
+#if CW_TIMING
+__device__ unsigned long long g_cw_dbg[1024 * 8];
+#define CW_STAMP(k) do { if (t == 0) { const unsigned long long _n = __builtin_amdgcn_s_memtime(); cw_acc[k] += _n - cw_last; cw_last = _n; } } while (0)
+#else
+#define CW_STAMP(k) do { } while (0)
+#endif
+
 namespace {
 constexpr int CW_MAXSEG = 256;
 constexpr int CW_MAXROWS = 320;                // slab rows a thread's staging registers cover (20 float4 per thread at 64 channels, 40 at 128)
@@ -138,7 +149,13 @@ __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2
     toff[i] = 2 * DIL * (pc / DIL) + pc % DIL;
   }
 
+#if CW_TIMING
+  unsigned long long cw_acc[4] = {0, 0, 0, 0}, cw_last = __builtin_amdgcn_s_memtime(), cw_begin = cw_last, cw_blocks = 0;
+#endif
   for (; blk < nblocks; blk += blk_stride) {
+#if CW_TIMING
+    ++cw_blocks;
+#endif
     locate(blk);
     const int cm0 = m0;
     const int m_hi = p.nseg > 0 ? seg_hi : min(seg_hi, p.M);
@@ -154,6 +171,10 @@ __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2
     for (int kh = 0; kh < KH; ++kh) {                       // slab phases (one, except CH = 256: two halves of the input channels)
     const int kh_wrap = kh + 1 < KH ? kh + 1 : 0;          // phase of the fragments requested past this phase's last group
     __syncthreads();                                       // previous slab's reads are done
+    CW_STAMP(kh == 0 ? 3 : 1);                             // (phase 0: the wait for the other waves' epilogue counts as wait)
+    // (Requesting the first pass's loads BEFORE this barrier -- so that a wave that finished early overlaps the load latency with its
+    //  wait -- was built and measured: the time only moves from "staging" to "wait", the loads are bound by the burst of all CUs staging
+    //  at once, not by when they are issued: profiles/r05_cw_early_load_experiment.txt, bench -0.5 %.)
     // ---- slab: global -> registers -> [zero padding, leaky-ReLU] -> LDS (as conv_c64.hip), 20 float4 per thread in flight at a time ----
 #pragma unroll 1
     for (int u0 = 0; u0 < NP; u0 += NPC) {
@@ -183,6 +204,7 @@ __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2
       }
     }
     __syncthreads();
+    CW_STAMP(0);
 
     // rows of component f (in units of d rows from the group's first input row): D_f = x[ja] (+/-) x[jb]
     //   f = 0: x0 - x2    f = 1: x1 + x2    f = 2: x2 - x1    f = 3: x1 - x3
@@ -228,6 +250,7 @@ __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2
       pa0 = pn0;
       pa1 = pn1;
     }
+    CW_STAMP(1);
     }   // slab phases
 
     // ---- output transform + epilogue: lane holds 4 consecutive channels (4g .. 4g+3 of column tile j) of both rows of pair r ----
@@ -292,8 +315,27 @@ __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2
       }
     }
   }
+    CW_STAMP(2);
+  }
+#if CW_TIMING
+  if (t == 0) {
+    unsigned long long* d = g_cw_dbg + (size_t)(blockIdx.x & 1023) * 8;
+    d[0] = cw_acc[0]; d[1] = cw_acc[1]; d[2] = cw_acc[2]; d[3] = cw_acc[3]; d[4] = cw_blocks; d[5] = cw_begin; d[6] = __builtin_amdgcn_s_memtime(); d[7] = 1;
+  }
+#endif
 #endif
 }
+
+#if CW_TIMING
+// [wg][8] = staging, contraction, epilogue, wait-at-block-start cycles, blocks, t_begin, t_end, valid
+extern "C" int ss_debug_cw_timing(unsigned long long* h_out, int cap_wgs) {
+  const int n = cap_wgs < 1024 ? cap_wgs : 1024;
+  if (hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_cw_dbg), (size_t)n * 8 * sizeof(unsigned long long)) != hipSuccess) return -1;
+  static unsigned long long zeros[1024 * 8];
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cw_dbg), zeros, sizeof(zeros));
+  return n;
+}
+#endif
 
 // ---- host side ---------------------------------------------------------------------------------
 static int g_c64w_on = getenv("SS_CONV_C64_WINOGRAD") ? atoi(getenv("SS_CONV_C64_WINOGRAD")) : 1;   // A/B knob: 0 = every conv of the 64-channel stage on the direct kernel
