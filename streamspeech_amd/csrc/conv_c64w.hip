@@ -314,7 +314,6 @@ __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2
         }
       }
     }
-  }
     CW_STAMP(2);
   }
 #if CW_TIMING
