@@ -24,6 +24,7 @@
 #include "gemm.hpp"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace ss {
 
@@ -46,6 +47,12 @@ constexpr int CW_MAXSEG = 256;
 constexpr int CW_MAXROWS = 320;                // slab rows a thread's staging registers cover (20 float4 per thread at 64 channels, 40 at 128)
 [[maybe_unused]] constexpr int CW_NUM_RECORDS = 0x7ffffff0;
 constexpr int cw_bme(int dil) { return dil == 1 ? 256 : dil == 3 ? 252 : 240; }   // output rows per block: whole pairs, <= 128 pairs
+// Tap-group kinds (see the kernel): products per channel block; accumulator set / weight slot, rows and operation of the n-th product
+[[maybe_unused]] __host__ __device__ constexpr int cw_nc(int kind) { return kind == 0 ? 4 : kind == 1 ? 2 : 3; }
+[[maybe_unused]] __host__ __device__ constexpr int cw_slot(int kind, int n) { return kind == 0 ? n : kind == 1 ? (n == 0 ? 0 : 3) : (n == 2 ? 3 : n); }
+[[maybe_unused]] __host__ __device__ constexpr int cw_ja(int kind, int n) { return kind == 0 ? (n == 3 ? 1 : n) : kind == 1 ? n : (n == 0 ? 0 : 1); }
+[[maybe_unused]] __host__ __device__ constexpr int cw_jb(int kind, int n) { return kind == 0 ? (n == 2 ? 1 : n == 3 ? 3 : 2) : kind == 1 ? n : (n == 2 ? 2 : 1); }
+[[maybe_unused]] __host__ __device__ constexpr int cw_op(int kind, int n) { return kind == 0 ? (n == 1 ? 1 : -1) : kind == 1 ? 0 : (n == 1 ? 0 : -1); }   // -1: a - b, +1: a + b, 0: a
 }  // namespace
 
 // WW[co][(g * 4 + f) * C + ci] from W[co][tap * C + ci] (tap-major conv weights), taps beyond k are zero
@@ -58,10 +65,17 @@ __global__ void wino_pack_kernel(const float* __restrict__ W, float* __restrict_
     const float w1 = 3 * g + 1 < taps ? w[(size_t)(3 * g + 1) * C] : 0.f;
     const float w2 = 3 * g + 2 < taps ? w[(size_t)(3 * g + 2) * C] : 0.f;
     float* o = WW + (size_t)co * groups * 4 * C + (size_t)g * 4 * C + ci;
-    o[0] = w0;
-    o[C] = 0.5f * ((w0 + w1) + w2);
-    o[2 * C] = 0.5f * ((w0 - w1) + w2);
-    o[3 * C] = w2;
+    const int left = taps - 3 * g;               // taps of this group
+    if (left >= 3) {                             // F(2,3)
+      o[0] = w0;
+      o[C] = 0.5f * ((w0 + w1) + w2);
+      o[2 * C] = 0.5f * ((w0 - w1) + w2);
+      o[3 * C] = w2;
+    } else if (left == 2) {                      // F(2,2): slots 0, 1, 3 (kind 2 in the kernel)
+      o[0] = w0; o[C] = w0 + w1; o[2 * C] = 0.f; o[3 * C] = w1;
+    } else {                                     // one tap: slots 0 and 3 (kind 1): y[t] += w0 x0, y[t + d] -= (-w0) x1
+      o[0] = w0; o[C] = 0.f; o[2 * C] = 0.f; o[3 * C] = -w0;
+    }
   }
 }
 
@@ -77,13 +91,13 @@ __global__ void wino_pack_kernel(const float* __restrict__ W, float* __restrict_
 // (w >> 3) & 1 -- a constant of the workgroup, so its weight rows and the ring prefetch across blocks never change -- and the two
 // workgroups that share a block (w and w ^ 8) sit on the same XCD (block w % 8 of the dispatch order), so the second reader of the
 // block's input rows hits that XCD's L2.  Per (block, column half) twice the MFMA work and twice the staging of the 128-channel form.
-template <bool LRELU, int DIL, int CH>
+template <int DIL, int CH, int TAIL>
 __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2 : 3) void conv_c64w_kernel(const GemmArgs p, const int groups, const int slab_rows) {
 #if __HIP_DEVICE_COMPILE__
   // (CH = 32: the k = 11 ResBlock convs of the 32-channel stage, three workgroups per CU: 2 column tiles, 16 MFMAs per sub-step)
   constexpr int CS = CH == 256 ? 128 : CH;                                  // input channels of one slab phase
   constexpr int KH = CH / CS;                                               // slab phases
-  constexpr int C = CH, LDA = CS + 4, CT = CH >= 64 ? 4 : CH / 16, CB = CS / 16, NSS = CB * 4, RING = 2 * CT, TPR = CS / 4;   // TPR threads stage one row
+  constexpr int C = CH, LDA = CS + 4, CT = CH >= 64 ? 4 : CH / 16, CB = CS / 16, RING = 2 * CT, TPR = CS / 4;   // TPR threads stage one row
   constexpr int NT = CH >= 128 ? 512 : 256, RPP = NT / TPR;                 // rows per staging pass (16; 32 at 32 channels)
   // (CH = 256: the accumulators stay live across the second phase's staging -- 10 float4 in flight per thread, two passes)
   constexpr int NP = (CW_MAXROWS + RPP - 1) / RPP, NPC = CH == 256 ? 10 : NP < 20 ? NP : 20, BME = cw_bme(DIL), NPAIR = BME / 2;
@@ -111,7 +125,8 @@ __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2
   }
   __syncthreads();
   const int nblocks = s_blk[nseg];
-  const float slope = p.in_slope;
+  // (no input activation: slope 1 -- max(v, v * 1) = v exactly; one kernel for both, see the TAIL note below)
+  const float slope = p.in_act == ACT_LRELU ? p.in_slope : 1.0f;
 
   int seg = 0, seg_lo = 0, seg_hi = 0, m0 = 0;
   auto locate = [&](int blk) {                 // blocks ascend per workgroup
@@ -196,45 +211,57 @@ __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;
         }
-        if (LRELU) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
-        }
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], v[e] * slope);
         if (rho < slab_rows) *reinterpret_cast<f32x4*>(dst + u * RPP * LDA) = v;
       }
     }
     __syncthreads();
     CW_STAMP(0);
 
-    // rows of component f (in units of d rows from the group's first input row): D_f = x[ja] (+/-) x[jb]
-    //   f = 0: x0 - x2    f = 1: x1 + x2    f = 2: x2 - x1    f = 3: x1 - x3
+    // A tap group is one of three KINDS (rows in units of d from the group's first input row x0; products accumulate in the four
+    // accumulator sets m0..m3, the output transform is y[t] = m0 + m1 + m2, y[t + d] = m1 - m2 - m3 for every kind):
+    //   kind 0, three taps (F(2,3)): m0 += G0 (x0 - x2), m1 += G1 (x1 + x2), m2 += G2 (x2 - x1), m3 += G3 (x1 - x3)          4 products
+    //   kind 1, ONE tap left (k = 7): y[t] += w0 x0, y[t + d] += w0 x1   =>   m0 += w0 . x0,  m3 += (-w0) . x1                  2 products
+    //   kind 2, TWO taps left (k = 11): F(2,2):  m0 += w0 (x0 - x1),  m1 += (w0 + w1) x1,  m3 += w1 (x1 - x2)                  3 products
+    // (round 4 ran the incomplete last group as a zero-padded F(2,3): 4 products, one of them against an all-zero matrix at k = 11, two
+    //  redundant at k = 7 -- 12 -> 10 MFMA k-blocks per pair at k = 7, 16 -> 15 at k = 11; wino_pack_kernel writes the matching weights.)
+    // (tables as constexpr functions of (kind, n): cw_nc / cw_slot / cw_ja / cw_jb / cw_op above -- local arrays captured by the lambda
+    //  were indexed at run time, which put the accumulators into scratch)
     const float* pa0 = sA + toff[0] * LDA + 4 * g;         // + group * 3 d rows + j d rows + cc * 16
     const float* pa1 = sA + toff[1] * LDA + 4 * g;
     auto rd = [&](const float* base, int j, int cc) -> f32x4 { return *reinterpret_cast<const f32x4*>(base + j * DIL * LDA + cc * 16); };
-    auto xform = [&](int f, const f32x4 a, const f32x4 b) -> f32x4 { return f == 1 ? a + b : a - b; };
-    constexpr int JA[4] = {0, 1, 2, 1}, JB[4] = {2, 2, 1, 3};
-    f32x4 xa[2];
-    xa[0] = xform(0, rd(pa0, JA[0], 0), rd(pa0, JB[0], 0));
-    xa[1] = xform(0, rd(pa1, JA[0], 0), rd(pa1, JB[0], 0));
-#pragma unroll 1
-    for (int grp = 0; grp < groups; ++grp) {
-      const int grp_next = grp + 1 < groups ? grp + 1 : 0;              // after the last group: the next block's first fragments
-      const float* pn0 = grp + 1 < groups ? pa0 + 3 * DIL * LDA : pa0;  // (after the last group: a harmless re-read)
-      const float* pn1 = grp + 1 < groups ? pa1 + 3 * DIL * LDA : pa1;
+    auto xform = [&](int op, const f32x4 a, const f32x4 b) -> f32x4 { return op == 1 ? a + b : op == 0 ? a : a - b; };
+    f32x4 xa[2];                                           // (the first group of a phase is always a full one: taps >= 3)
+    xa[0] = xform(-1, rd(pa0, 0, 0), rd(pa0, 2, 0));
+    xa[1] = xform(-1, rd(pa1, 0, 0), rd(pa1, 2, 0));
+    // One tap group, fully unrolled over its sub-steps (channel block cc, product n).  kind_next: kind of the group that follows (the
+    // sub-step after this group's last one is that group's (cc 0, product 0); the fragments requested two sub-steps ahead are its
+    // products 0 and 1); pn0 / pn1, grp_next, kh_next: where that group's rows and weights are.
+    auto group = [&](auto KIND, const int grp, const int kind_next, const float* pn0, const float* pn1, const int grp_next, const int kh_next) __attribute__((always_inline)) {
+      constexpr int K = decltype(KIND)::value, NC = cw_nc(K), NS = CB * NC;
+      static_assert(NS % 2 == 0 && NS >= 2, "ring slots keep their parity across groups");
 #pragma unroll
-      for (int ss = 0; ss < NSS; ++ss) {                                // sub-step = (channel block cc, component f)
-        const int f = ss & 3;                                            // (channel block ss >> 2: already in xa and in the ring)
-        const int sn = (ss + 1) % NSS, ccn = sn >> 2, fn = sn & 3;       // the next sub-step's raw rows (next group after the last)
-        const f32x4 na0 = rd(ss < NSS - 1 ? pa0 : pn0, JA[fn], ccn), nb0 = rd(ss < NSS - 1 ? pa0 : pn0, JB[fn], ccn);
-        const f32x4 na1 = rd(ss < NSS - 1 ? pa1 : pn1, JA[fn], ccn), nb1 = rd(ss < NSS - 1 ? pa1 : pn1, JB[fn], ccn);
+      for (int ss = 0; ss < NS; ++ss) {
+        const int slot = cw_slot(K, ss % NC);
+        f32x4 na0, nb0, na1, nb1;
+        if (ss + 1 < NS) {
+          const int ccn = (ss + 1) / NC, nn = (ss + 1) % NC;
+          na0 = rd(pa0, cw_ja(K, nn), ccn); nb0 = rd(pa0, cw_jb(K, nn), ccn);
+          na1 = rd(pa1, cw_ja(K, nn), ccn); nb1 = rd(pa1, cw_jb(K, nn), ccn);
+        } else {                                           // product 0 of the next group: x0 - x2 | x0 | x0 - x1
+          const int jb = kind_next == 0 ? 2 : 1;
+          na0 = rd(pn0, 0, 0); nb0 = *reinterpret_cast<const f32x4*>(pn0 + jb * (DIL * LDA));
+          na1 = rd(pn1, 0, 0); nb1 = *reinterpret_cast<const f32x4*>(pn1 + jb * (DIL * LDA));
+        }
         f32x4 wf[CT];
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
-          const int q = ss * CT + j;                                    // fragment of this group; its ring slot is re-armed two sub-steps ahead
+          const int q = ss * CT + j;                       // fragment of this sub-step; its ring slot is re-armed two sub-steps ahead
           wf[j] = ring[q % RING];
           const int s2 = ss + 2;
-          ring[q % RING] = wload((s2 < NSS ? grp : grp_next) * 4 + (s2 & 3), (s2 % NSS) >> 2, j,
-                                 (s2 < NSS || grp + 1 < groups) ? kh : kh_wrap);
+          if (s2 < NS) ring[q % RING] = wload(grp * 4 + cw_slot(K, s2 % NC), s2 / NC, j, kh);
+          else ring[q % RING] = wload(grp_next * 4 + (s2 == NS ? 0 : (kind_next == 1 ? 3 : 1)), 0, j, kh_next);
         }
 #pragma unroll
         for (int e = 0; e < 4; ++e)
@@ -242,14 +269,33 @@ __global__ __launch_bounds__(CH >= 128 ? 512 : 256, CH >= 128 ? 1 : CH == 64 ? 2
           for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < CT; ++j)
-              acc[f][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xa[i][e], acc[f][i][j], 0, 0, 0);   // D = G_f . D_f^T
-        xa[0] = xform(fn, na0, nb0);
-        xa[1] = xform(fn, na1, nb1);
+              acc[slot][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[j][e], xa[i][e], acc[slot][i][j], 0, 0, 0);   // D = G . D^T
+        if (ss + 1 < NS) {
+          xa[0] = xform(cw_op(K, (ss + 1) % NC), na0, nb0);
+          xa[1] = xform(cw_op(K, (ss + 1) % NC), na1, nb1);
+        } else {
+          xa[0] = kind_next == 1 ? na0 : na0 - nb0;
+          xa[1] = kind_next == 1 ? na1 : na1 - nb1;
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
+    };
+    // TAIL (taps % 3) is a template argument: with both tail bodies behind run-time branches in one kernel hipcc spilled 280
+    // registers (each alone: none) -- the template argument LRELU of round 4 made room for it (36 instantiations instead of 72)
+    constexpr int tail = TAIL;
+    const int groups_full = groups - (tail ? 1 : 0);
+#pragma unroll 1
+    for (int grp = 0; grp < groups_full; ++grp) {
+      const bool more = grp + 1 < groups;                              // another group of this phase follows
+      const float* pn0 = more ? pa0 + 3 * DIL * LDA : pa0;             // (after the last group: a harmless re-read)
+      const float* pn1 = more ? pa1 + 3 * DIL * LDA : pa1;
+      // after the phase's last group: the next phase's / the next block's first fragments (a full group)
+      group(std::integral_constant<int, 0>{}, grp, (more && grp + 1 == groups_full) ? tail : 0, pn0, pn1, more ? grp + 1 : 0, more ? kh : kh_wrap);
       pa0 = pn0;
       pa1 = pn1;
     }
+    if constexpr (TAIL == 1) group(std::integral_constant<int, 1>{}, groups_full, 0, pa0, pa1, 0, kh_wrap);
+    if constexpr (TAIL == 2) group(std::integral_constant<int, 2>{}, groups_full, 0, pa0, pa1, 0, kh_wrap);
     CW_STAMP(1);
     }   // slab phases
 
@@ -402,13 +448,13 @@ int launch_wino_pack(const float* W, float* WW, int C, int taps, hipStream_t str
   return SS_OK;
 }
 
-template <bool LRELU, int DIL, int CH>
+template <int DIL, int CH, int TAIL>
 static int launch_cw_t(GemmArgs a, hipStream_t stream) {
   constexpr int BME = cw_bme(DIL);
   const int groups = cw_groups(a);
   const int slab_rows = BME + 3 * groups * DIL;
   const size_t lds = cw_lds(a, CH == 256 ? 128 : CH);
-  SS_MAX_LDS_ONCE((&conv_c64w_kernel<LRELU, DIL, CH>), CH >= 128 ? 160 * 1024 : 96 * 1024);
+  SS_MAX_LDS_ONCE((&conv_c64w_kernel<DIL, CH, TAIL>), CH >= 128 ? 160 * 1024 : 96 * 1024);
   SkWorkspace* st = nullptr;                       // (only for the device's CU count, cached per context)
   int rc = sk_workspace_acquire(stream, &st);
   if (rc != SS_OK) return rc;
@@ -423,18 +469,26 @@ static int launch_cw_t(GemmArgs a, hipStream_t stream) {
   rc = prof_begin(a, stream, CH == 64 ? 27 : CH == 128 ? 28 : CH == 256 ? 30 : 29, rec, prof);   // census: the conv's algorithmic (direct-form) FLOPs; the kernel issues 4 G / (2 k) of them
   if (rc != SS_OK) return rc;
   a.W = a.Wwino;
-  hipLaunchKernelGGL((conv_c64w_kernel<LRELU, DIL, CH>), dim3(grid), dim3(CH >= 128 ? 512 : 256), lds, stream, a, groups, slab_rows);
+  hipLaunchKernelGGL((conv_c64w_kernel<DIL, CH, TAIL>), dim3(grid), dim3(CH >= 128 ? 512 : 256), lds, stream, a, groups, slab_rows);
   SS_LAUNCH_CHECK();
   return prof_end(stream, rec, prof);
 }
 
 template <int CH>
 static int launch_cw(const GemmArgs& a, hipStream_t stream) {
-  const bool lr = a.in_act == ACT_LRELU;
-  switch (a.dil) {
-    case 1: return lr ? launch_cw_t<true, 1, CH>(a, stream) : launch_cw_t<false, 1, CH>(a, stream);
-    case 3: return lr ? launch_cw_t<true, 3, CH>(a, stream) : launch_cw_t<false, 3, CH>(a, stream);
-    default: return lr ? launch_cw_t<true, 5, CH>(a, stream) : launch_cw_t<false, 5, CH>(a, stream);
+  if (a.in_act != ACT_NONE && a.in_act != ACT_LRELU) return SS_ERR_ARG;
+  const int key = a.dil * 10 + a.taps % 3;
+  switch (key) {
+    case 10: return launch_cw_t<1, CH, 0>(a, stream);
+    case 11: return launch_cw_t<1, CH, 1>(a, stream);
+    case 12: return launch_cw_t<1, CH, 2>(a, stream);
+    case 30: return launch_cw_t<3, CH, 0>(a, stream);
+    case 31: return launch_cw_t<3, CH, 1>(a, stream);
+    case 32: return launch_cw_t<3, CH, 2>(a, stream);
+    case 50: return launch_cw_t<5, CH, 0>(a, stream);
+    case 51: return launch_cw_t<5, CH, 1>(a, stream);
+    case 52: return launch_cw_t<5, CH, 2>(a, stream);
+    default: return SS_ERR_ARG;
   }
 }
 

@@ -749,8 +749,9 @@ int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, boo
   else { SS_HIP_CHECK(hipEventCreate(&rec.e0)); SS_HIP_CHECK(hipEventCreate(&rec.e1)); }
   rec.cls = cls;
   algo_work(a, rec.flops, rec.bytes);
-  // Winograd F(2,3) classes (conv_c64w / conv_c128w / conv_c32w / conv_c256w): 4 ceil(k/3) MFMA k-blocks per output pair instead of 2 k
-  rec.issued = (cls >= 27 && cls <= 30 && a.taps >= 3) ? rec.flops * (4.0 * ((a.taps + 2) / 3)) / (2.0 * a.taps) : rec.flops;
+  // Winograd classes (conv_c64w / conv_c128w / conv_c32w / conv_c256w): 4 MFMA k-blocks per output pair and full tap group + 2 (3) for a
+  // last group of one (two) taps, instead of 2 k: 4 / 10 / 15 against 6 / 14 / 22 at k = 3 / 7 / 11
+  rec.issued = (cls >= 27 && cls <= 30 && a.taps >= 3) ? rec.flops * (4.0 * (a.taps / 3) + (a.taps % 3 ? a.taps % 3 + 1 : 0)) / (2.0 * a.taps) : rec.flops;
   SS_HIP_CHECK(hipEventRecord(rec.e0, stream));
   return SS_OK;
 }
