@@ -14,10 +14,8 @@
 
 namespace ss {
 
-static int g_attn_no_mfma = 0;   // test hook: route plain attention to the VALU kernel
-void attention_debug_no_mfma(int v) { g_attn_no_mfma = v; }
-static int g_attn_split = getenv("SS_ATTN_NO_SPLIT") && atoi(getenv("SS_ATTN_NO_SPLIT")) ? -1 : 0;   // test hook (attention_debug_split); SS_ATTN_NO_SPLIT=1: A/B knob
-void attention_debug_split(int v) { g_attn_split = v; }
+void attention_debug_no_mfma(int v) { dispatch_edit([v](Dispatch& d) { d.attn_no_mfma = v; }); }   // test hook: route plain attention to the VALU kernel
+void attention_debug_split(int v) { dispatch_edit([v](Dispatch& d) { d.attn_split = v; }); }   // test hook; SS_ATTN_NO_SPLIT=1: never split
 
 constexpr int QB = 16;     // query rows per workgroup
 constexpr int KT = 64;     // keys per tile
@@ -627,7 +625,7 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     SS_LAUNCH_CHECK();
     return SS_OK;
   }
-  if (!a.P && a.q0 == 0 && !g_attn_no_mfma && ((a.ldq | a.ldo) & 3) == 0) {
+  if (!a.P && a.q0 == 0 && !disp().attn_no_mfma && ((a.ldq | a.ldo) & 3) == 0) {
     hipLaunchKernelGGL(attention_mfma_kernel, dim3(cdiv(tq, MQ), a.H, gz), dim3(256), 0, stream, a);
     SS_LAUNCH_CHECK();
     return SS_OK;
@@ -636,11 +634,11 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
   if (a.P) {
     if ((a.nseg == 0 && a.q0 + a.Tq != a.Tk) || (a.ldp & 3) || !a.bias_u || !a.bias_v) return SS_ERR_ARG;
     if (a.nseg > 0 && a.p_tmax <= 0) return SS_ERR_ARG;
-    if (!g_attn_no_mfma && ((a.ldq | a.ldo) & 3) == 0 && a.k_mask_tail == 0 && !a.causal) {
+    if (!disp().attn_no_mfma && ((a.ldq | a.ldo) & 3) == 0 && a.k_mask_tail == 0 && !a.causal) {
       const int nqt = cdiv(tq, MQ), nkt = cdiv(a.Tk, KT);
       // key split: one utterance with few (query tile, head) pairs and more than one key tile
-      if (a.nseg == 0 && a.part && g_attn_split >= 0 && nkt >= 2 && nqt * a.H <= a.cnt_slots && nqt * a.H < 128) {
-        int tps = g_attn_split > 0 ? g_attn_split : cdiv(nkt, std::min(16, std::max(1, 256 / (nqt * a.H))));
+      if (a.nseg == 0 && a.part && disp().attn_split >= 0 && nkt >= 2 && nqt * a.H <= a.cnt_slots && nqt * a.H < 128) {
+        int tps = disp().attn_split > 0 ? disp().attn_split : cdiv(nkt, std::min(16, std::max(1, 256 / (nqt * a.H))));
         tps = std::max(tps, cdiv(nkt, 16));
         const int S = cdiv(nkt, tps);
         if (S >= 2 && nqt * a.H * S <= a.part_slots) {

@@ -8,6 +8,7 @@
 //    optional causal triu(-inf, 1) mask, softmax in fp32.
 #pragma once
 #include "common.hpp"
+#include "dispatch.hpp"
 
 namespace ss {
 

@@ -183,16 +183,15 @@ __global__ __launch_bounds__(256, 3) void conv_c16_kernel(const GemmArgs p, cons
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int g_c16_off = getenv("SS_NO_CONV_C16") && atoi(getenv("SS_NO_CONV_C16")) ? 1 : 0;   // A/B knob: the C = 16 stage as fused ResBlock launches (round 3)
-static long long g_c16_min_rows = getenv("SS_CONV_C16_MIN_ROWS") ? atoll(getenv("SS_CONV_C16_MIN_ROWS")) : 131072;
-void conv_c16_debug(int enable) { if (enable >= 0) g_c16_off = enable ? 0 : 1; }
-bool conv_c16_enabled() { return !g_c16_off; }
+// (A/B knobs SS_NO_CONV_C16 / SS_CONV_C16_MIN_ROWS and this hook: dispatch.hpp)
+void conv_c16_debug(int enable) { if (enable >= 0) dispatch_edit([enable](Dispatch& d) { d.c16_off = enable ? 0 : 1; }); }
+bool conv_c16_enabled() { return !disp().c16_off; }
 
 bool conv_c16_eligible(const GemmArgs& a) {
-  return !g_c16_off && a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && !a.x3 && a.Cin == C1_C && a.N == C1_C &&
+  return !disp().c16_off && a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && !a.x3 && a.Cin == C1_C && a.N == C1_C &&
          a.lda == C1_C && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && (!a.R2 || (a.ldr2 & 3) == 0) && (!a.C2 || (a.ldc2 & 3) == 0) &&
          (a.taps == 3 || a.taps == 7 || a.taps == 11) && a.dil >= 1 && (a.taps - 1) * a.dil <= C1_MAXHALO && a.pad >= 0 &&
-         a.pad <= (a.taps - 1) * a.dil && a.nseg <= C1_MAXSEG && a.M >= g_c16_min_rows &&
+         a.pad <= (a.taps - 1) * a.dil && a.nseg <= C1_MAXSEG && a.M >= disp().c16_min_rows &&
          ((size_t)(a.M + a.pad + 512) * a.lda) * 4 < 0x7ff00000ull &&
          (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) &&
          (a.act == ACT_NONE || a.act == ACT_LRELU);

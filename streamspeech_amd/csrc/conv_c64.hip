@@ -252,16 +252,15 @@ __global__ __launch_bounds__(256, 2) void conv_c64_kernel(const GemmArgs p, cons
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int g_c64_off = getenv("SS_NO_CONV_C64") && atoi(getenv("SS_NO_CONV_C64")) ? 1 : 0;   // A/B knob: the C = 64 stage on conv_sk2<64> as in round 3
-static long long g_c64_min_rows = getenv("SS_CONV_C64_MIN_ROWS") ? atoll(getenv("SS_CONV_C64_MIN_ROWS")) : 32768;   // >= half a block per CU
-void conv_c64_debug(int enable) { if (enable >= 0) g_c64_off = enable ? 0 : 1; }
-bool conv_c64_enabled() { return !g_c64_off; }
+// (A/B knobs SS_NO_CONV_C64 / SS_CONV_C64_MIN_ROWS and this hook: dispatch.hpp)
+void conv_c64_debug(int enable) { if (enable >= 0) dispatch_edit([enable](Dispatch& d) { d.c64_off = enable ? 0 : 1; }); }
+bool conv_c64_enabled() { return !disp().c64_off; }
 
 bool conv_c64_eligible(const GemmArgs& a) {
-  return !g_c64_off && a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && !a.x3 && a.Cin == C6_C && a.N == C6_C &&
+  return !disp().c64_off && a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && !a.x3 && a.Cin == C6_C && a.N == C6_C &&
          a.lda == C6_C && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && (!a.R2 || (a.ldr2 & 3) == 0) && (!a.C2 || (a.ldc2 & 3) == 0) &&
          a.taps >= 1 && a.dil >= 1 && (a.taps - 1) * a.dil <= C6_MAXHALO && a.pad >= 0 && a.pad <= (a.taps - 1) * a.dil &&
-         a.nseg <= C6_MAXSEG && a.M >= g_c64_min_rows && ((size_t)(a.M + a.pad + 512) * a.lda) * 4 < 0x7ff00000ull &&
+         a.nseg <= C6_MAXSEG && a.M >= disp().c64_min_rows && ((size_t)(a.M + a.pad + 512) * a.lda) * 4 < 0x7ff00000ull &&
          (size_t)a.taps * C6_C * C6_C * 4 < 0x7ff00000ull && (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) &&
          (a.act == ACT_NONE || a.act == ACT_LRELU);
 }

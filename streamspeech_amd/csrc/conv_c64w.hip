@@ -383,19 +383,14 @@ extern "C" int ss_debug_cw_timing(unsigned long long* h_out, int cap_wgs) {
 #endif
 
 // ---- host side ---------------------------------------------------------------------------------
-static int g_c64w_on = getenv("SS_CONV_C64_WINOGRAD") ? atoi(getenv("SS_CONV_C64_WINOGRAD")) : 1;   // A/B knob: 0 = every conv of the 64-channel stage on the direct kernel
-static int g_c128w_on = getenv("SS_CONV_C128_WINOGRAD") ? atoi(getenv("SS_CONV_C128_WINOGRAD")) : 1; // A/B knob: 0 = the 128-channel stage on conv_sk2<128> (pre-activated twins)
-static int g_c64w_min_k = getenv("SS_CONV_C64_WINOGRAD_MIN_K") ? atoi(getenv("SS_CONV_C64_WINOGRAD_MIN_K")) : 3;
-static long long g_c128w_min_rows = getenv("SS_CONV_C128_MIN_ROWS") ? atoll(getenv("SS_CONV_C128_MIN_ROWS")) : 65536;   // >= a block per CU
-void conv_c64w_debug(int enable) { if (enable >= 0) g_c64w_on = enable ? 1 : 0; }
-bool conv_c64w_enabled() { return g_c64w_on != 0; }
-void conv_c128w_debug(int enable) { if (enable >= 0) g_c128w_on = enable ? 1 : 0; }
-bool conv_c128w_enabled() { return g_c128w_on != 0; }
+// (A/B knobs SS_CONV_C64 / C128 / C256 / C32_WINOGRAD, ..._MIN_K, ..._MIN_ROWS and these hooks: dispatch.hpp)
+void conv_c64w_debug(int enable) { if (enable >= 0) dispatch_edit([enable](Dispatch& d) { d.c64w_on = enable ? 1 : 0; }); }
+bool conv_c64w_enabled() { return disp().c64w_on != 0; }
+void conv_c128w_debug(int enable) { if (enable >= 0) dispatch_edit([enable](Dispatch& d) { d.c128w_on = enable ? 1 : 0; }); }
+bool conv_c128w_enabled() { return disp().c128w_on != 0; }
 
-static int g_c256w_on = getenv("SS_CONV_C256_WINOGRAD") ? atoi(getenv("SS_CONV_C256_WINOGRAD")) : 1; // A/B knob: 0 = the 256-channel stage on conv_sk2<128> (pre-activated twins)
-static long long g_c256w_min_rows = getenv("SS_CONV_C256_MIN_ROWS") ? atoll(getenv("SS_CONV_C256_MIN_ROWS")) : 32768;  // >= a (block, column half) per CU
-void conv_c256w_debug(int enable) { if (enable >= 0) g_c256w_on = enable ? 1 : 0; }
-bool conv_c256w_enabled() { return g_c256w_on != 0; }
+void conv_c256w_debug(int enable) { if (enable >= 0) dispatch_edit([enable](Dispatch& d) { d.c256w_on = enable ? 1 : 0; }); }
+bool conv_c256w_enabled() { return disp().c256w_on != 0; }
 
 static int cw_groups(const GemmArgs& a) { return (a.taps + 2) / 3; }
 static size_t cw_lds(const GemmArgs& a, int ch) {
@@ -406,7 +401,7 @@ static size_t cw_lds(const GemmArgs& a, int ch) {
 // the launches conv_c64.hip takes (checked by the caller: conv_c64_eligible) that also have transformed weights, a "same" geometry the
 // pairing covers and a slab two of which fit a CU
 bool conv_c64w_eligible(const GemmArgs& a) {
-  if (!g_c64w_on || !a.Wwino || a.taps < g_c64w_min_k || a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.C2) return false;
+  if (!disp().c64w_on || !a.Wwino || a.taps < disp().c64w_min_k || a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.C2) return false;
   if (a.pad != a.dil * (a.taps - 1) / 2) return false;
   // k = 7 at dilation 5: 1.17x fewer MFMAs against a 45-row halo on 240-row blocks -- measured slower than the direct form (283 vs 272 us)
   static const int allow_k7d5 = getenv("SS_CONV_C64_WINOGRAD_K7D5") ? atoi(getenv("SS_CONV_C64_WINOGRAD_K7D5")) : 0;
@@ -419,10 +414,10 @@ bool conv_c64w_eligible(const GemmArgs& a) {
 // block (one workgroup per CU: the slab is 137-158 KB).  There is no direct slab kernel at this width (measured slower than conv_sk2<128>:
 // profiles/r04_c128_bench.txt), so the stage takes this path only if ALL its convs are eligible (model.hip asks with a probe).
 bool conv_c128w_eligible(const GemmArgs& a) {
-  if (!g_c128w_on || !a.Wwino || !a.same_rows || a.stride != 1 || a.chunk || a.glu || a.ln_g || a.x3 || a.Cin != 128 || a.N != 128) return false;
+  if (!disp().c128w_on || !a.Wwino || !a.same_rows || a.stride != 1 || a.chunk || a.glu || a.ln_g || a.x3 || a.Cin != 128 || a.N != 128) return false;
   if (a.lda != 128 || (a.ldc & 3) || (a.R && (a.ldr & 3)) || (a.R2 && (a.ldr2 & 3)) || (a.C2 && (a.ldc2 & 3))) return false;
   if (a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.pad != a.dil * (a.taps - 1) / 2) return false;
-  if (a.nseg > CW_MAXSEG || a.M < g_c128w_min_rows || ((size_t)(a.M + a.pad + 512) * a.lda) * 4 >= 0x7ff00000ull) return false;
+  if (a.nseg > CW_MAXSEG || a.M < disp().c128w_min_rows || ((size_t)(a.M + a.pad + 512) * a.lda) * 4 >= 0x7ff00000ull) return false;
   if (!(a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) || !(a.act == ACT_NONE || a.act == ACT_LRELU)) return false;
   const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
   return slab_rows <= CW_MAXROWS && cw_lds(a, 128) <= 160 * 1024;
@@ -431,10 +426,10 @@ bool conv_c128w_eligible(const GemmArgs& a) {
 // The 256-channel stage in the same form (two slab phases of 128 input channels, two column halves): all-or-nothing per stage like the
 // 128-channel one (model.hip probes every conv).
 bool conv_c256w_eligible(const GemmArgs& a) {
-  if (!g_c256w_on || !a.Wwino || !a.same_rows || a.stride != 1 || a.chunk || a.glu || a.ln_g || a.x3 || a.Cin != 256 || a.N != 256) return false;
+  if (!disp().c256w_on || !a.Wwino || !a.same_rows || a.stride != 1 || a.chunk || a.glu || a.ln_g || a.x3 || a.Cin != 256 || a.N != 256) return false;
   if (a.lda != 256 || (a.ldc & 3) || (a.R && (a.ldr & 3)) || (a.R2 && (a.ldr2 & 3)) || (a.C2 && (a.ldc2 & 3))) return false;
   if (a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.pad != a.dil * (a.taps - 1) / 2) return false;
-  if (a.nseg > CW_MAXSEG || a.M < g_c256w_min_rows || ((size_t)(a.M + a.pad + 512) * a.lda) * 4 >= 0x7ff00000ull) return false;
+  if (a.nseg > CW_MAXSEG || a.M < disp().c256w_min_rows || ((size_t)(a.M + a.pad + 512) * a.lda) * 4 >= 0x7ff00000ull) return false;
   if ((size_t)256 * cw_groups(a) * 4 * 256 * 4 >= 0x7ff00000ull) return false;
   if (!(a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) || !(a.act == ACT_NONE || a.act == ACT_LRELU)) return false;
   const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
@@ -497,11 +492,10 @@ int launch_conv_c64w(const GemmArgs& a, hipStream_t stream) {
   return launch_cw<64>(a, stream);
 }
 // The 32-channel stage's per-conv launches (model.hip: k >= 11) -- the convs conv_c32.hip takes, with transformed weights
-static int g_c32w_on = getenv("SS_CONV_C32_WINOGRAD") ? atoi(getenv("SS_CONV_C32_WINOGRAD")) : 1;
-void conv_c32w_debug(int enable) { if (enable >= 0) g_c32w_on = enable ? 1 : 0; }
-bool conv_c32w_enabled() { return g_c32w_on != 0; }
+void conv_c32w_debug(int enable) { if (enable >= 0) dispatch_edit([enable](Dispatch& d) { d.c32w_on = enable ? 1 : 0; }); }
+bool conv_c32w_enabled() { return disp().c32w_on != 0; }
 bool conv_c32w_eligible(const GemmArgs& a) {                 // call with conv_c32_eligible(a) already true
-  if (!g_c32w_on || !a.Wwino || a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.C2) return false;
+  if (!disp().c32w_on || !a.Wwino || a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.C2) return false;
   if (a.pad != a.dil * (a.taps - 1) / 2) return false;
   const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
   return slab_rows <= CW_MAXROWS && 3 * cw_lds(a, 32) <= 158 * 1024;

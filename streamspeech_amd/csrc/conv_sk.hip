@@ -405,9 +405,9 @@ __global__ __launch_bounds__(256, 2) void conv_sk_kernel(const GemmArgs p, const
 
 // ---- host side ---------------------------------------------------------------------------------
 // Workspace, ticket counters and flags belong to the calling execution context (SkWorkspace, gemm.hpp).
-static int g_sk_groups = 0;   // XCD tile grouping: measured neutral on time and -6 % on L2 misses (profiles/r01_sk_sweep.txt), so off;
+// (XCD tile grouping: measured neutral on time and -6 % on L2 misses (profiles/r01_sk_sweep.txt), so off: Dispatch::sk_groups)
                               // tools: debug_force_tile(1, 8, g) switches it on
-void conv_sk_set_groups(int on) { g_sk_groups = on; }
+void conv_sk_set_groups(int on) { dispatch_edit([on](Dispatch& d) { d.sk_groups = on; }); }
 
 bool conv_sk_eligible(const GemmArgs& a) {
   return a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && a.Cin % SK_BK == 0 && (a.lda & 3) == 0 &&
@@ -438,7 +438,7 @@ static int launch_sk(const GemmArgs& a, hipStream_t stream, int g_force) {
   // data-parallel special case: when the tile count itself nearly fills the resident grid, one tile per
   // workgroup needs no fix-up at all (U/G = nk exactly)
   if (g_force <= 0 && tiles <= G && 4 * tiles >= 3 * G) G = tiles;
-  const int NG = (g_sk_groups && G >= 64 && tiles >= 64) ? 8 : 1;
+  const int NG = (disp().sk_groups && G >= 64 && tiles >= 64) ? 8 : 1;
   if (NG > 1) G -= G % NG;
   SkArgs q;
   q.ws = st->ws; q.sync = st->sync1;

@@ -389,19 +389,20 @@ __global__ __launch_bounds__(256, WMT <= 2 ? 2 : 1) void ffn_fused_kernel(const 
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int g_ffn_force_g = 0;                         // tests / tuning: fixed grid (ss_debug_ffn_grid)
-void ffn_fused_debug_grid(int g) { g_ffn_force_g = g; }
+void ffn_fused_debug_grid(int g) { dispatch_edit([g](Dispatch& d) { d.ffn_force_g = g; }); }   // tests / tuning: fixed grid
 
-static int g_ffn_wm = getenv("SS_FFN_WM") ? atoi(getenv("SS_FFN_WM")) : 3;   // MFMA row tiles per wave (4: 64-row tiles, 3: 48-row tiles)
-static int g_ffn_wm_forced = getenv("SS_FFN_WM") ? 1 : 0;                    // the pack-invariant form picks its own unless forced
-void ffn_fused_debug_rows(int wm) { if (wm >= 1 && wm <= 4) { g_ffn_wm = wm; g_ffn_wm_forced = 1; } else if (wm == 0) { g_ffn_wm = 3; g_ffn_wm_forced = 0; } }
+// (16-row MFMA tiles per wave: Dispatch::ffn_wm, SS_FFN_WM; the pack-invariant form picks its own unless forced)
+void ffn_fused_debug_rows(int wm) {
+  dispatch_edit([wm](Dispatch& d) { if (wm >= 1 && wm <= 4) { d.ffn_wm = wm; d.ffn_wm_forced = 1; } else if (wm == 0) { d.ffn_wm = 3; d.ffn_wm_forced = 0; } });
+}
 
 // relative cost of a row at tile height 16 h (h = 1..4), SS_FFN_COST="c1,c2,c3,c4" overrides (tuning)
-static double g_ffn_cost[5] = {0.0, 1.45, 1.12, 1.0, 1.04};
-[[maybe_unused]] static const int g_ffn_cost_init = [] {
+struct FfnCost { double c[5]; };
+static const FfnCost g_ffn_cost = [] {
+  FfnCost k{{0.0, 1.88, 1.07, 1.0, 1.02}};     // us per 16 rows and round at 16- / 32- / 48- / 64-row tiles, relative (121 / 137 / 193 / 262 us per round: profiles/r05_ffn_canon_bench.txt)
   const char* e = getenv("SS_FFN_COST");
-  if (e) sscanf(e, "%lf,%lf,%lf,%lf", &g_ffn_cost[1], &g_ffn_cost[2], &g_ffn_cost[3], &g_ffn_cost[4]);
-  return 0;
+  if (e) sscanf(e, "%lf,%lf,%lf,%lf", &k.c[1], &k.c[2], &k.c[3], &k.c[4]);
+  return k;
 }();
 
 bool ffn_fused_eligible(int D, int F, int act, int M, int ldx, int ldy) {
@@ -421,7 +422,7 @@ static int launch_ffn_t(FfnKArgs a, int D, const float* ln2_g, hipStream_t strea
   const long long U = (long long)tiles * (a.F / FF_UN);
   if (a.canon) {
     // pack-invariant form: whole tiles per workgroup; two resident workgroups per CU at 16- / 32-row tiles (128 accumulator registers)
-    long long G = g_ffn_force_g > 0 ? g_ffn_force_g : (long long)st->cus * (WMT <= 2 ? 2 : 1);
+    long long G = disp().ffn_force_g > 0 ? disp().ffn_force_g : (long long)st->cus * (WMT <= 2 ? 2 : 1);
     if (G > tiles) G = tiles;
     if (G < 1) G = 1;
     a.G = (int)G; a.ws = st->ws; a.cnt = st->sync3; a.zero = 0;
@@ -438,9 +439,9 @@ static int launch_ffn_t(FfnKArgs a, int D, const float* ln2_g, hipStream_t strea
   }
   // One workgroup per CU.  A tile is shared by at most ~8 workgroups (each parks a partial that the tile's last arrival reads
   // back: beyond that the finisher's serial read is the kernel's tail), and every workgroup gets at least 4 units (one per wave).
-  long long G = g_ffn_force_g > 0 ? g_ffn_force_g : st->cus;
+  long long G = disp().ffn_force_g > 0 ? disp().ffn_force_g : st->cus;
   if (G > st->cus) G = st->cus;                       // slots: the context's workspace holds 2 x cus partials of 64 KB (two per workgroup)
-  if (g_ffn_force_g <= 0 && G > 8LL * tiles) G = 8LL * tiles;
+  if (disp().ffn_force_g <= 0 && G > 8LL * tiles) G = 8LL * tiles;
   if (G > U / 4) G = U / 4;
   if (G < 1) G = 1;
   a.G = (int)G; a.ws = st->ws; a.cnt = st->sync3; a.zero = 0;
@@ -463,14 +464,14 @@ int launch_ffn_fused(const float* X, int ldx, float* Y, int ldy, const float* ln
   FfnKArgs a;
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.ln_g = ln_g; a.ln_b = ln_b; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
   a.ln2_g = ln2_g; a.ln2_b = ln2_g ? ln2_b : nullptr; a.alpha = alpha; a.M = M; a.F = F; a.canon = canon ? 1 : 0;
-  int wm = g_ffn_wm;
-  if (canon && !g_ffn_wm_forced) {
+  int wm = disp().ffn_wm;
+  if (canon && !disp().ffn_wm_forced) {
     // Tile height of the pack-invariant form (a row's bits do not depend on it): the one whose tiles go over the CUs in the fewest
     // rows per CU, weighted by what a row costs at that height (fewer MFMAs per weight fragment at low heights; tools/ffn_bench.py)
     SkWorkspace* st = nullptr;
     int rc = sk_workspace_acquire(stream, &st);
     if (rc != SS_OK) return rc;
-    const double cost[5] = {0.0, g_ffn_cost[1], g_ffn_cost[2], g_ffn_cost[3], g_ffn_cost[4]};
+    const double* cost = g_ffn_cost.c;
     double best = 1e300;
     for (int h = 1; h <= 4; ++h) {
       const long long tiles = cdiv(M, 16 * h);

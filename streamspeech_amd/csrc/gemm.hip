@@ -633,12 +633,12 @@ static const char* kTileNames[kNumTileCfg] = {
     // whole-ResBlock launches of the narrow vocoder stages (resblock.hip) and the fused encoder FFN (ffn.hip): kernels of their own,
     // booked under their own names (round 3 booked resblock_fused under conv_slab<..>: VERDICT r3 "mislabelled second kernel")
     "resblock_fused<32>", "resblock_fused<16>", "ffn_fused<256,2048>", "rt_linear<48,256>", "conv_c64<256,64>", "conv_c32<256,32>", "conv_c16<256,16>", "conv_c64w<256,64>", "conv_c128w<256,128>", "conv_c32w<256,32>", "conv_c256w<256,128>"};
-static int g_prof_mask = 0;
+static std::atomic<int> g_prof_mask{0};     // event brackets per class: written by ss_prof_enable between regions, read by every launch
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_pool;
 static std::mutex g_prof_mu;
 
-void prof_enable(int cls_mask) { g_prof_mask = cls_mask; }
+void prof_enable(int cls_mask) { g_prof_mask.store(cls_mask, std::memory_order_relaxed); }
 const char* prof_cfg_name(int cls) { return (cls >= 0 && cls < kNumTileCfg) ? kTileNames[cls] : "?"; }
 void prof_reset() {
   for (auto& r : g_prof_recs) g_prof_pool.push_back({r.e0, r.e1});
@@ -742,7 +742,7 @@ int prof_begin(const GemmArgs& a, hipStream_t stream, int cls, ProfRec& rec, boo
       z.launches += 1; z.rows += a.M; z.flops += fl; z.bytes += by;
     }
   }
-  prof = (g_prof_mask >> cls) & 1;
+  prof = (g_prof_mask.load(std::memory_order_relaxed) >> cls) & 1;
   if (!prof) return SS_OK;
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_pool.empty()) { rec.e0 = g_prof_pool.back().first; rec.e1 = g_prof_pool.back().second; g_prof_pool.pop_back(); }
@@ -814,8 +814,7 @@ static int launch_smallm(const GemmArgs& a, hipStream_t stream, int cls) {
   return prof_end(stream, rec, prof);
 }
 
-static int g_force_bm = 0, g_force_bn = 0, g_force_ks = 0;
-static double g_sk_min_flops = getenv("SS_SK_MIN_GFLOP") ? 1e9 * atof(getenv("SS_SK_MIN_GFLOP")) : 4e9;   // below this the small-tile kernels win (tools/conv_bench.py sk; SS_SK_MIN_GFLOP: tuning knob)
+// (Dispatch::sk_min_flops, SS_SK_MIN_GFLOP: below this the small-tile kernels win -- tools/conv_bench.py sk)
 // ---- stream-K workspaces (see gemm.hpp) -----------------------------------------------------------
 constexpr size_t SKW_SYNC_BYTES = (16 + 1024) * sizeof(unsigned) + 256;      // >= both kernels' flag tables
 static std::mutex g_skw_mu;
@@ -843,8 +842,52 @@ void sk_workspace_free(SkWorkspace* w) {
   if (w->dbg) (void)hipFree(w->dbg);
   delete w;
 }
-SkScope::SkScope(SkWorkspace* w) : prev(t_skw) { t_skw = w; }
-SkScope::~SkScope() { t_skw = prev; }
+// ---- dispatch settings (dispatch.hpp) ---------------------------------------------------------------
+namespace {
+std::mutex g_disp_mu;
+std::atomic<unsigned> g_disp_gen{1};
+Dispatch env_defaults() {
+  Dispatch d;
+  auto I = [](const char* k, int dflt) { const char* e = getenv(k); return e ? atoi(e) : dflt; };
+  auto L = [](const char* k, long long dflt) { const char* e = getenv(k); return e ? atoll(e) : dflt; };
+  d.attn_split = I("SS_ATTN_NO_SPLIT", 0) ? -1 : 0;
+  d.c16_off = I("SS_NO_CONV_C16", 0) ? 1 : 0; d.c32_off = I("SS_NO_CONV_C32", 0) ? 1 : 0; d.c64_off = I("SS_NO_CONV_C64", 0) ? 1 : 0;
+  d.c16_min_rows = L("SS_CONV_C16_MIN_ROWS", d.c16_min_rows); d.c32_min_rows = L("SS_CONV_C32_MIN_ROWS", d.c32_min_rows);
+  d.c64_min_rows = L("SS_CONV_C64_MIN_ROWS", d.c64_min_rows);
+  d.c64w_on = I("SS_CONV_C64_WINOGRAD", 1); d.c128w_on = I("SS_CONV_C128_WINOGRAD", 1); d.c256w_on = I("SS_CONV_C256_WINOGRAD", 1);
+  d.c32w_on = I("SS_CONV_C32_WINOGRAD", 1); d.c64w_min_k = I("SS_CONV_C64_WINOGRAD_MIN_K", 3);
+  d.c128w_min_rows = L("SS_CONV_C128_MIN_ROWS", d.c128w_min_rows); d.c256w_min_rows = L("SS_CONV_C256_MIN_ROWS", d.c256w_min_rows);
+  if (getenv("SS_FFN_WM")) { d.ffn_wm = I("SS_FFN_WM", 3); d.ffn_wm_forced = 1; }
+  d.ffn_fusion = I("SS_NO_FFN_FUSION", 0) ? 0 : 1; d.ffn_min_rows = I("SS_FFN_MIN_ROWS", d.ffn_min_rows);
+  if (getenv("SS_SK_MIN_GFLOP")) d.sk_min_flops = 1e9 * atof(getenv("SS_SK_MIN_GFLOP"));
+  d.no_resblock_fusion = I("SS_NO_RESBLOCK_FUSION", 0); d.no_pair_fusion = I("SS_NO_PAIR_FUSION", 0);
+  d.rt_off = I("SS_NO_RTLIN", 0) ? 1 : 0; d.rt_min_rows = I("SS_RTLIN_MIN_ROWS", d.rt_min_rows); d.rt_min_units = L("SS_RTLIN_MIN_UNITS", d.rt_min_units);
+  return d;
+}
+Dispatch& process_settings() { static Dispatch d = env_defaults(); return d; }      // (callers hold g_disp_mu)
+thread_local const Dispatch* t_disp = nullptr;
+thread_local CtxDispatch t_disp_own;          // launches outside any context (ss_op_* unit-test entry points)
+}  // namespace
+void dispatch_edit(const std::function<void(Dispatch&)>& fn) {
+  std::lock_guard<std::mutex> lk(g_disp_mu);
+  fn(process_settings());
+  g_disp_gen.fetch_add(1, std::memory_order_release);
+}
+const Dispatch* CtxDispatch::refresh() {
+  const unsigned now = g_disp_gen.load(std::memory_order_acquire);
+  if (gen != now) {
+    std::lock_guard<std::mutex> lk(g_disp_mu);
+    d = process_settings();
+    gen = g_disp_gen.load(std::memory_order_relaxed);
+  }
+  return &d;
+}
+const Dispatch& disp() { return t_disp ? *t_disp : *t_disp_own.refresh(); }
+DispatchScope::DispatchScope(const Dispatch* d) : prev(t_disp) { t_disp = d; }
+DispatchScope::~DispatchScope() { t_disp = prev; }
+
+SkScope::SkScope(SkWorkspace* w) : prev(t_skw), prev_disp(t_disp) { t_skw = w; t_disp = w ? w->disp.refresh() : nullptr; }
+SkScope::~SkScope() { t_skw = prev; t_disp = prev_disp; }
 
 int sk_workspace_acquire(hipStream_t stream, SkWorkspace** out) {
   *out = nullptr;
@@ -889,8 +932,10 @@ int sk_workspace_error_count() {
   return total;
 }
 
-void debug_force_tile(int bm, int bn, int ks) { g_force_bm = bm; g_force_bn = bn; g_force_ks = ks; conv_sk_set_groups(bm == 1 && bn == 8); }
-bool debug_tile_forced() { return g_force_bm != 0; }
+void debug_force_tile(int bm, int bn, int ks) {
+  dispatch_edit([=](Dispatch& d) { d.force_bm = bm; d.force_bn = bn; d.force_ks = ks; d.sk_groups = (bm == 1 && bn == 8); });
+}
+bool debug_tile_forced() { return disp().force_bm != 0; }
 
 static thread_local int t_canon = CANON_NONE;
 CanonScope::CanonScope(int mode) : prev(t_canon) { t_canon = mode; }
@@ -923,7 +968,7 @@ static int launch_canon(const GemmArgs& a, hipStream_t stream) {
   // ---- CANON_SEQ: one accumulator chain per output element ----
   if (rtlin_shape_ok(a) && (a.ln_g || rtlin_eligible(a))) return launch_rtlin(a, stream);
   if (a.ln_g) return SS_ERR_ARG;            // LayerNorm prologue: the row-tile kernel only (K = 256); callers normalise first otherwise
-  if (conv_sk2_eligible(a) && !a.x3 && 2.0 * (double)a.M * a.N * a.taps * a.Cin >= g_sk_min_flops) {
+  if (conv_sk2_eligible(a) && !a.x3 && 2.0 * (double)a.M * a.N * a.taps * a.Cin >= disp().sk_min_flops) {
     // stream-K cut on WHOLE tiles: worth it when the tiles fill the CUs in (nearly) whole rounds
     const long long tiles = (long long)cdiv(a.M, 256) * (a.N / (a.N % 128 == 0 ? 128 : 64));
     const long long cus = 256, rounds = (tiles + cus - 1) / cus;
@@ -939,7 +984,7 @@ static int launch_canon(const GemmArgs& a, hipStream_t stream) {
 }
 
 bool smallm_eligible(const GemmArgs& a) {
-  if (g_force_bm > 1) return false;
+  if (disp().force_bm > 1) return false;
   const int M = a.nseg > 0 ? a.max_seg_out : a.M;
   // GLU (the conformer conv module's pointwise conv 1): only in its plain form -- no activation, scale or residual on top
   const bool glu_ok = !a.glu || (a.N % 32 == 0 && a.act == ACT_NONE && a.alpha == 1.f && !a.R);
@@ -966,9 +1011,9 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   const bool k32 = (a.Cin % 32) == 0;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   if (a.canon == CANON_NONE) a.canon = t_canon;
-  if (a.canon != CANON_NONE && !g_force_bm) return launch_canon(a, stream);
+  if (a.canon != CANON_NONE && !disp().force_bm) return launch_canon(a, stream);
   // a forced tile (tuning hook) keeps M <= 4 launches off the GEMV -- except when the caller asked for ln_out, which only the GEMV writes
-  if ((!g_force_bm || a.ln_out) && gemv_eligible(a)) return launch_gemv(a, stream);
+  if ((!disp().force_bm || a.ln_out) && gemv_eligible(a)) return launch_gemv(a, stream);
   if (a.ln_out) return SS_ERR_ARG;      // only the GEMV form publishes the normalised rows
   if (smallm_eligible(a)) {
     if (a.glu) return launch_smallm<2, 2, true>(a, stream, 13);   // value / gate tiles side by side in one workgroup
@@ -978,22 +1023,22 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
     return launch_smallm<1, 4>(a, stream, 14);
   }
   // 64-channel vocoder stage of a packed batch: input slab in LDS once, W fragments from L2 (conv_c64.hip)
-  if (!g_force_bm && conv_c64_eligible(a)) return conv_c64w_eligible(a) ? launch_conv_c64w(a, stream) : launch_conv_c64(a, stream);
-  if (!g_force_bm && conv_c128w_eligible(a)) return launch_conv_c128w(a, stream);
-  if (!g_force_bm && conv_c256w_eligible(a)) return launch_conv_c256w(a, stream);
-  if (!g_force_bm && conv_c32_eligible(a)) return conv_c32w_eligible(a) ? launch_conv_c32w(a, stream) : launch_conv_c32(a, stream);
-  if (!g_force_bm && conv_c16_eligible(a)) return launch_conv_c16(a, stream);
+  if (!disp().force_bm && conv_c64_eligible(a)) return conv_c64w_eligible(a) ? launch_conv_c64w(a, stream) : launch_conv_c64(a, stream);
+  if (!disp().force_bm && conv_c128w_eligible(a)) return launch_conv_c128w(a, stream);
+  if (!disp().force_bm && conv_c256w_eligible(a)) return launch_conv_c256w(a, stream);
+  if (!disp().force_bm && conv_c32_eligible(a)) return conv_c32w_eligible(a) ? launch_conv_c32w(a, stream) : launch_conv_c32(a, stream);
+  if (!disp().force_bm && conv_c16_eligible(a)) return launch_conv_c16(a, stream);
   // K = 256 linears of packed batches (encoder projections, CTC heads, cross K|V): row tile in LDS, W fragments from L2 (rtlin.hip)
-  if (!g_force_bm && rtlin_eligible(a)) return launch_rtlin(a, stream);
+  if (!disp().force_bm && rtlin_eligible(a)) return launch_rtlin(a, stream);
   if (a.ln_g) return SS_ERR_ARG;  // LayerNorm fusion exists only on the small-M and row-tile paths
-  if (g_force_bm == 1 && conv_sk_eligible(a)) return launch_conv_sk(a, stream, g_force_ks);   // tuning hook: stream-K, grid = ks (0 = auto)
-  if (g_force_bm == 4 && conv_sk2_eligible(a)) return launch_conv_sk2(a, stream, g_force_ks);  // tuning hook: 2nd-generation stream-K
-  if (g_force_bm == 5 && conv_sk2_eligible(a)) { GemmArgs b = a; b.x3 = 1; return launch_conv_sk2(b, stream, g_force_ks); }  // ... its split-bf16 variant (tests, tools/sk2_bench.py)
+  if (disp().force_bm == 1 && conv_sk_eligible(a)) return launch_conv_sk(a, stream, disp().force_ks);   // tuning hook: stream-K, grid = ks (0 = auto)
+  if (disp().force_bm == 4 && conv_sk2_eligible(a)) return launch_conv_sk2(a, stream, disp().force_ks);  // tuning hook: 2nd-generation stream-K
+  if (disp().force_bm == 5 && conv_sk2_eligible(a)) { GemmArgs b = a; b.x3 = 1; return launch_conv_sk2(b, stream, disp().force_ks); }  // ... its split-bf16 variant (tests, tools/sk2_bench.py)
   // Big "same" convs / linears (packed vocoder batches, unit-decoder FFN): persistent stream-K
   // 128-wide tiles, 95-110 TFLOP/s against 75-90 for the 32x64 kernel (profiles/r01_sk_sweep.txt).
   // They need enough k-steps per workgroup to amortise the fix-up + epilogue: >= 12 at BN = 128;
   // at BN = 64 (half the MFMA work per k-step) only the k >= 7 convs qualify.
-  if (!g_force_bm && conv_sk_eligible(a) && 2.0 * (double)a.M * a.N * a.taps * a.Cin >= g_sk_min_flops) {
+  if (!disp().force_bm && conv_sk_eligible(a) && 2.0 * (double)a.M * a.N * a.taps * a.Cin >= disp().sk_min_flops) {
     const long long nk = (long long)a.taps * (a.Cin / 32);
     const bool wide = a.N % 128 == 0;
     const long long units = (long long)cdiv(a.M, 128) * (a.N / (wide ? 128 : 64)) * nk;
@@ -1003,8 +1048,8 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
     if (!no_sk2 && conv_sk2_eligible(a) && (wide ? units >= min_units : a.taps * a.Cin >= sk2_min_k64)) return launch_conv_sk2(a, stream);
     if (wide ? units >= min_units : a.taps * a.Cin >= 448) return launch_conv_sk(a, stream);
   }
-  if (g_force_bm && a.N > 32 && k32) {   // tuning hook (tools/conv_bench.py): ks = KS*10 + PD
-    const int f = g_force_bm * 10000 + (g_force_bn % 100) * 100 + g_force_ks;   // 128x128 -> bn code 28... see cases
+  if (disp().force_bm && a.N > 32 && k32) {   // tuning hook (tools/conv_bench.py): ks = KS*10 + PD
+    const int f = disp().force_bm * 10000 + (disp().force_bn % 100) * 100 + disp().force_ks;   // 128x128 -> bn code 28... see cases
     switch (f) {
 #define SS_CASE(BM_, BN_, KS_, PD_, CLS_) case BM_ * 10000 + BN_ * 100 + KS_ * 10 + PD_: return launch_cfg<BM_, BN_, 32, 2, 2, KS_, PD_>(a, stream, CLS_);
       SS_CASE(64, 64, 1, 1, 7) SS_CASE(64, 64, 1, 2, 7) SS_CASE(64, 64, 1, 3, 7)
@@ -1020,7 +1065,7 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
     }
   }
   // narrow vocoder stages: weights + input slab in LDS, one HBM pass (conv_slab.hip)
-  if (g_force_bm != 2 && conv_slab_eligible(a) && a.M >= 2048) return launch_conv_slab(a, stream);
+  if (disp().force_bm != 2 && conv_slab_eligible(a) && a.M >= 2048) return launch_conv_slab(a, stream);
   if (a.N <= 16) return launch_cfg_ks<128, 16, 16, 4, 1, 2>(a, stream, 0, (long)cdiv(M, 128) * nseg);
   if (a.N <= 32 && !a.glu) {
     const long tl = (long)cdiv(M, 128) * nseg;

@@ -10,6 +10,7 @@
 // closed form of the reference ChunkCausalConv1d (chunk_unity/modules/chunk_causal_conv1d.py:39-68).
 #pragma once
 #include "common.hpp"
+#include "dispatch.hpp"
 
 namespace ss {
 
@@ -110,13 +111,15 @@ struct SkWorkspace {
   unsigned base1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, epoch1 = 0;
   unsigned base2 = 0, epoch2 = 0;
   unsigned long long* dbg = nullptr;   // diagnostic builds only
+  CtxDispatch disp;                    // this context's private copy of the dispatch settings (dispatch.hpp); SkScope makes it the thread's disp()
 };
 SkWorkspace* sk_workspace_new();
 void sk_workspace_free(SkWorkspace* w);
-struct SkScope {                       // RAII: the calling thread's stream-K launches use `w` until the scope ends
-  explicit SkScope(SkWorkspace* w);
+struct SkScope {                       // RAII: the calling thread's stream-K launches use `w`, and its launchers read `w`'s dispatch
+  explicit SkScope(SkWorkspace* w);    // settings (refreshed here, at the start of an entry point, if the process settings moved), until the scope ends
   ~SkScope();
   SkWorkspace* prev;
+  const Dispatch* prev_disp;
 };
 // the workspace a launch on `stream` should use (scoped one, else the fallback entry), device memory allocated; nullptr + rc on failure
 int sk_workspace_acquire(hipStream_t stream, SkWorkspace** out);

@@ -130,8 +130,6 @@ int ln_linear(hipStream_t s, const float* x, int M, const LN& ln, const Lin& l, 
 
 }  // namespace
 
-static int g_ffn_fusion = getenv("SS_NO_FFN_FUSION") && atoi(getenv("SS_NO_FFN_FUSION")) ? 0 : 1;   // A/B knob: encoder FFNs of packed batches as one launch each (ffn.hip)
-static int g_ffn_min_rows = getenv("SS_FFN_MIN_ROWS") ? atoi(getenv("SS_FFN_MIN_ROWS")) : 1000;      // below: the two-launch form (too few row tiles to fill the chip)
 static const int g_pack_invariant_default = getenv("SS_PACK_INVARIANT") ? atoi(getenv("SS_PACK_INVARIANT")) : 1;   // A/B knob: default of ss_model_set_pack_invariant for new contexts
 
 // =================================================================================================
@@ -1113,8 +1111,6 @@ extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
 // HBM-bound late stages (C < 64) the extra write would cost more than the VALU, so the activation
 // stays on the consumer's A-fragment path there.
 // -------------------------------------------------------------------------------------------------
-static int g_no_resblock_fusion = getenv("SS_NO_RESBLOCK_FUSION") ? atoi(getenv("SS_NO_RESBLOCK_FUSION")) : 0;   // test hook / env knob (ss_debug_force_tile(6, ...)): narrow-stage ResBlocks as separate pair / conv launches
-static int g_no_pair_fusion = getenv("SS_NO_PAIR_FUSION") ? atoi(getenv("SS_NO_PAIR_FUSION")) : 0;   // test hook / env knob (ss_debug_force_tile(3, ...)): run the narrow-stage pairs as two launches
 struct GenBufs { float *bx, *bt, *br, *bs, *bxa, *bra, *bsa, *br2; };
 
 template <class ConvFn, class StageFn, class GeomFn>
@@ -1208,12 +1204,14 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
       // pair / two-launch forms below, which stay as the A/B and fallback path
       // conv_c32.hip: at k = 11 (MFMA-bound) six separate convs beat the fused ResBlock launch -- no halo recompute: 107 vs 86
       // TFLOP/s in the pipeline; at k = 3 / 7 the fused launch wins (92-98 vs 56-93: the separate convs are HBM-bound there)
-      static const int c32_min_k = getenv("SS_CONV_C32_MIN_K") ? atoi(getenv("SS_CONV_C32_MIN_K")) : 11;
+      // (round 5: from k = 7 -- a 7-tap conv is 10 instead of 12 MFMA k-blocks per pair since the one-tap tail group: 6243 vs 6200 x RT,
+      //  k >= 3: 6221; tools/jobs/r05_m.sh)
+      static const int c32_min_k = getenv("SS_CONV_C32_MIN_K") ? atoi(getenv("SS_CONV_C32_MIN_K")) : 7;
       // conv_c16.hip: the same split at 16 channels (weight matrix in registers): +0.5 %; the round-1 slab kernel (weights in LDS) conv by
       // conv measures -0.3 % against the fused launch, profiles/r04_c16_bench.txt + tools/jobs/r04_o.sh / r04_p.sh
       static const int c16_min_k = getenv("SS_CONV_C16_MIN_K") ? atoi(getenv("SS_CONV_C16_MIN_K")) : 11;
       const bool per_conv = (c32 && C == 32 && kr >= c32_min_k) || (c16 && C == 16 && kr >= c16_min_k);
-      if (!pa && !per_conv && !g_no_resblock_fusion && resblock_fused_eligible(C, kr, c.resblock_dilations[j], C, C, gnseg, gM)) {
+      if (!pa && !per_conv && !disp().no_resblock_fusion && resblock_fused_eligible(C, kr, c.resblock_dilations[j], C, C, gnseg, gM)) {
         const float *W1[3], *B1[3], *W2[3], *B2[3];
         for (int dd = 0; dd < 3; ++dd) {
           const int idx = (i * c.n_res + j) * 3 + dd;
@@ -1223,7 +1221,7 @@ static int hifigan_stack(const ss_vocoder* v, hipStream_t s, ConvFn&& conv, Stag
                                   j == c.n_res - 1 ? (float)c.n_res : 0.f, C, kr, gM, 0.1f, gsegs, gnseg, s));
         continue;
       }
-      const bool fuse = !pa && !per_conv && !g_no_pair_fusion && kr == 3 &&
+      const bool fuse = !pa && !per_conv && !disp().no_pair_fusion && kr == 3 &&
                         conv_pair_eligible(C, kr, c.resblock_dilations[j][2], C, C, gnseg, gM);
       const float* cur = b.bs;
       for (int dd = 0; dd < 3; ++dd) {
@@ -1446,7 +1444,7 @@ extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const 
     // macaron FFN: x += 0.5 * W2 SiLU(W1 LN(x)); packed batches: ONE launch (ffn.hip), the [rows, 2048] hidden tile stays on chip
     // (pack-invariant contexts: ALWAYS the fused launch in its whole-tile form -- the two-launch form sums the 2048 hidden terms in
     //  another order, and which of the two runs must not depend on the row count)
-    const bool fuse_ffn = (canon || (g_ffn_fusion && M2 >= g_ffn_min_rows)) && ffn_fused_eligible(d, f, ACT_SILU, M2, d, d) &&
+    const bool fuse_ffn = (canon || (disp().ffn_fusion && M2 >= disp().ffn_min_rows)) && ffn_fused_eligible(d, f, ACT_SILU, M2, d, d) &&
                           e.ffn1_w1.b && e.ffn1_w2.b && e.ffn2_w1.b && e.ffn2_w2.b;
     if (fuse_ffn) {
       RET(launch_ffn_fused(x, d, x, d, e.ffn1_ln.g, e.ffn1_ln.b, e.ffn1_w1.w, e.ffn1_w1.b, e.ffn1_w2.w, e.ffn1_w2.b, 0.5f, nullptr,
@@ -1875,7 +1873,7 @@ extern "C" int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable) {
   if (grid < 0 || row_tiles_per_wave < 0 || row_tiles_per_wave > 4) return SS_ERR_ARG;
   ffn_fused_debug_grid(grid);
   ffn_fused_debug_rows(row_tiles_per_wave);
-  if (enable >= 0) g_ffn_fusion = enable ? 1 : 0;
+  if (enable >= 0) dispatch_edit([enable](Dispatch& d) { d.ffn_fusion = enable ? 1 : 0; });
   return SS_OK;
 }
 
@@ -1936,8 +1934,8 @@ extern "C" int ss_debug_force_tile(int bm, int bn, int ks) {
   // 32 / 64 / 128 a forced tile of the LDS-tiled kernel (tools/conv_bench.py); anything else is a caller's mistake.
   // (Round 3 had booked BOTH the conv_sk2 hook and the ResBlock A/B on 4, so (4, 0, G) never reached the stream-K launcher.)
   if (!(bm >= 0 && bm <= 6) && bm != 32 && bm != 64 && bm != 128) return SS_ERR_ARG;
-  if (bm == 6 || bm == 0) g_no_resblock_fusion = (bm == 6);        // bm = 6: narrow-stage ResBlocks as separate launches (A/B of resblock.hip)
-  if (bm == 3 || bm == 0) g_no_pair_fusion = (bm == 3);            // bm = 3: narrow-stage resblock pairs as two launches (A/B of the fused kernel)
+  if (bm == 6 || bm == 0) dispatch_edit([bm](Dispatch& d) { d.no_resblock_fusion = (bm == 6); });        // bm = 6: narrow-stage ResBlocks as separate launches (A/B of resblock.hip)
+  if (bm == 3 || bm == 0) dispatch_edit([bm](Dispatch& d) { d.no_pair_fusion = (bm == 3); });            // bm = 3: narrow-stage resblock pairs as two launches (A/B of the fused kernel)
   debug_force_tile((bm == 3 || bm == 6) ? 0 : bm, bn, ks);
   return SS_OK;
 }

@@ -244,15 +244,12 @@ __global__ __launch_bounds__(256, 3) void rt_linear_kernel(const RtArgs p) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
-static int g_rt_off = getenv("SS_NO_RTLIN") && atoi(getenv("SS_NO_RTLIN")) ? 1 : 0;   // A/B knob: K = 256 linears on the LDS-tiled kernel as in round 3
-static int g_rt_min_rows = getenv("SS_RTLIN_MIN_ROWS") ? atoi(getenv("SS_RTLIN_MIN_ROWS")) : 193;   // below: the no-LDS small-M kernel
 // Smallest launch, in 192-MFMA units (a GLU unit counts twice), that goes to this kernel: every workgroup pays a row-tile prologue
 // (48 KB into LDS, ~2.5 us), so with few units per tile and workgroup -- N = 256 at any row count, N = 512 / 768 below ~4000 rows --
 // the 32 x 32 / 32 x 64 tiles win (profiles/r04_rtlin_bench.txt: attn_out 4200 rows 11.7 vs 14.8 us; qkv 33.1 vs 25.9; CTC head
 // 156 vs 109 us = 0.75 of the FP32-MFMA peak).
-static long long g_rt_min_units = getenv("SS_RTLIN_MIN_UNITS") ? atoll(getenv("SS_RTLIN_MIN_UNITS")) : 4000;
-static int g_rt_force_g = 0;
-void rtlin_debug(int grid, int enable) { g_rt_force_g = grid; if (enable >= 0) g_rt_off = enable ? 0 : 1; }
+// (Dispatch::rt_min_units, SS_RTLIN_MIN_UNITS; SS_NO_RTLIN / SS_RTLIN_MIN_ROWS: the A/B knobs -- dispatch.hpp)
+void rtlin_debug(int grid, int enable) { dispatch_edit([grid, enable](Dispatch& d) { d.rt_force_g = grid; if (enable >= 0) d.rt_off = enable ? 0 : 1; }); }
 
 bool rtlin_shape_ok(const GemmArgs& a) {
   const int M = a.M;
@@ -265,11 +262,11 @@ bool rtlin_shape_ok(const GemmArgs& a) {
 }
 
 bool rtlin_eligible(const GemmArgs& a) {
-  if (g_rt_off) return false;
+  if (disp().rt_off) return false;
   const int M = a.M;
-  return rtlin_shape_ok(a) && M >= g_rt_min_rows &&
-         (g_rt_force_g > 0 || a.N >= 2048 ||                      // >= 128 units per row tile: the prologue is noise at any row count
-          (long long)cdiv(M, RT_BM) * (a.N / 16) >= g_rt_min_units);      // (N / 16: a GLU unit is 32 weight rows)
+  return rtlin_shape_ok(a) && M >= disp().rt_min_rows &&
+         (disp().rt_force_g > 0 || a.N >= 2048 ||                      // >= 128 units per row tile: the prologue is noise at any row count
+          (long long)cdiv(M, RT_BM) * (a.N / 16) >= disp().rt_min_units);      // (N / 16: a GLU unit is 32 weight rows)
 }
 
 int launch_rtlin(const GemmArgs& a, hipStream_t stream) {
@@ -290,8 +287,8 @@ int launch_rtlin(const GemmArgs& a, hipStream_t stream) {
   // (measured: one per CU unless a workgroup would hold >= 64 units -- the vocabulary heads -- where three per CU gain 3-9 %)
   static const int per_cu_env = getenv("SS_RTLIN_WG_PER_CU") ? atoi(getenv("SS_RTLIN_WG_PER_CU")) : 0;
   const int per_cu = per_cu_env > 0 ? per_cu_env : (U >= 64LL * cus ? 3 : 1);
-  long long G = g_rt_force_g > 0 ? g_rt_force_g : (long long)cus * per_cu;      // at least 4 units (one per wave) each
-  if (g_rt_force_g <= 0 && G > U / 4) G = U / 4;
+  long long G = disp().rt_force_g > 0 ? disp().rt_force_g : (long long)cus * per_cu;      // at least 4 units (one per wave) each
+  if (disp().rt_force_g <= 0 && G > U / 4) G = U / 4;
   if (G > U) G = U;
   if (G < 1) G = 1;
   q.G = (int)G;

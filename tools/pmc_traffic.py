@@ -42,7 +42,7 @@ CLASSES = [("void ss::conv_sk2_kernel", "conv_sk2<256,128,32>"), ("void ss::conv
            ("void ss::conv_gemm_kernel<32, 64, 32", "conv_gemm<32,64,32,2,2>"), ("void ss::conv_gemm_kernel<32, 32, 32", "conv_gemm<32,32,32,2,2>"),
            ("void ss::conv_gemm_kernel<128, 32, 32", "conv_gemm<128,32,32,4,1>"), ("void ss::conv_gemm_kernel<128, 16, 16", "conv_gemm<128,16,16,4,1>"),
            ("void ss::smallm_gemm_kernel<4, 1", "smallm_gemm<4,1>"), ("void ss::ffn_fused_kernel", "ffn_fused<256,2048>"),
-           ("void ss::rt_linear_kernel", "rt_linear<48,256>"), ("void ss::conv_c64_kernel", "conv_c64<256,64>"), ("void ss::conv_c64w_kernel", "conv_c64w<256,64>"), ("void ss::conv_c64w_kernel", "conv_c128w<256,128>"), ("void ss::conv_c64w_kernel", "conv_c32w<256,32>"), ("void ss::conv_c32_kernel", "conv_c32<256,32>"), ("void ss::conv_c16_kernel", "conv_c16<256,16>")]
+           ("void ss::rt_linear_kernel", "rt_linear<48,256>"), ("void ss::conv_c64_kernel", "conv_c64<256,64>"), ("void ss::conv_c64w_kernel", "conv_c64w<256,64>"), ("void ss::conv_c64w_kernel", "conv_c128w<256,128>"), ("void ss::conv_c64w_kernel", "conv_c32w<256,32>"), ("void ss::conv_c64w_kernel", "conv_c256w<256,128>"), ("void ss::conv_c32_kernel", "conv_c32<256,32>"), ("void ss::conv_c16_kernel", "conv_c16<256,16>")]
 
 
 def read(path, counter):
@@ -72,8 +72,15 @@ def main():
             x3 = cls.startswith("conv_sk2_bf16x3")
             ks = [k for k in ks if (re.search(r"conv_sk2_kernel<\d+, (true|false), true>", k) is not None) == x3]
         if prefix.endswith("conv_c64w_kernel"):   # one kernel template, two census classes: the channel count is its third template argument
-            want = "128" if cls.startswith("conv_c128w") else "32" if cls.startswith("conv_c32w") else "64"
-            ks = [k for k in ks if re.search(r"conv_c64w_kernel<(true|false), \d+, (\d+)>", k) and re.search(r"conv_c64w_kernel<(true|false), \d+, (\d+)>", k).group(2) == want]
+            want = "256" if cls.startswith("conv_c256w") else "128" if cls.startswith("conv_c128w") else "32" if cls.startswith("conv_c32w") else "64"
+
+            def channels(k):     # conv_c64w_kernel<DIL, CH, TAIL> (round 5) | <LRELU, DIL, CH> (round 4)
+                m = re.search(r"conv_c64w_kernel<(\d+), (\d+), (\d+)>", k)
+                if m:
+                    return m.group(2)
+                m = re.search(r"conv_c64w_kernel<(?:true|false), \d+, (\d+)>", k)
+                return m.group(1) if m else None
+            ks = [k for k in ks if channels(k) == want]
         return ks
 
     for prefix, cls in CLASSES:

@@ -4,15 +4,19 @@ the profile saw).  A class whose time share is far above its FLOP share is the o
     python tools/share_table.py <kernel_stats.csv> <bench.json> > table.md"""
 import csv
 import json
+import re
 import sys
 
 # profiler class (bench.py process_census key) -> kernel-name prefixes of the profile
 CLASSES = [("conv_sk2<256,128,32>", ["void ss::conv_sk2_kernel"]),
            ("conv_sk<128,BN,32>", ["void ss::conv_sk_kernel"]),
            ("conv_c64<256,64>", ["void ss::conv_c64_kernel"]),
-           ("conv_c64w<256,64>", ["void ss::conv_c64w_kernel<true, 1, 64", "void ss::conv_c64w_kernel<true, 3, 64", "void ss::conv_c64w_kernel<true, 5, 64", "void ss::conv_c64w_kernel<false, 1, 64", "void ss::conv_c64w_kernel<false, 3, 64", "void ss::conv_c64w_kernel<false, 5, 64"]),
-           ("conv_c32w<256,32>", ["void ss::conv_c64w_kernel<true, 1, 32", "void ss::conv_c64w_kernel<true, 3, 32", "void ss::conv_c64w_kernel<true, 5, 32", "void ss::conv_c64w_kernel<false, 1, 32", "void ss::conv_c64w_kernel<false, 3, 32", "void ss::conv_c64w_kernel<false, 5, 32"]),
-           ("conv_c128w<256,128>", ["void ss::conv_c64w_kernel<true, 1, 128", "void ss::conv_c64w_kernel<true, 3, 128", "void ss::conv_c64w_kernel<true, 5, 128", "void ss::conv_c64w_kernel<false, 1, 128", "void ss::conv_c64w_kernel<false, 3, 128", "void ss::conv_c64w_kernel<false, 5, 128"]),
+           # one kernel template (csrc/conv_c64w.hip), four census classes: the channel count is its SECOND template argument
+           # (conv_c64w_kernel<DIL, CH, TAIL> since round 5; <LRELU, DIL, CH> in round 4: "re:" entries are regular expressions)
+           ("conv_c64w<256,64>", [r"re:void ss::conv_c64w_kernel<(?:\d+, 64, \d+|(?:true|false), \d+, 64)>"]),
+           ("conv_c32w<256,32>", [r"re:void ss::conv_c64w_kernel<(?:\d+, 32, \d+|(?:true|false), \d+, 32)>"]),
+           ("conv_c128w<256,128>", [r"re:void ss::conv_c64w_kernel<(?:\d+, 128, \d+|(?:true|false), \d+, 128)>"]),
+           ("conv_c256w<256,128>", [r"re:void ss::conv_c64w_kernel<\d+, 256, \d+>"]),
            ("conv_c32<256,32>", ["void ss::conv_c32_kernel"]),
            ("conv_c16<256,16>", ["void ss::conv_c16_kernel"]),
            ("resblock_fused<32>", ["void ss::resblock_fused_kernel<32"]),
@@ -40,7 +44,7 @@ def main():
     print("|---|---|---|---|---|---|---|---|")
     seen = 0.0
     for cls, prefixes in CLASSES:
-        rs = [r for r in rows if any(r["Name"].startswith(p) for p in prefixes)]
+        rs = [r for r in rows if any(re.match(p[3:], r["Name"]) if p.startswith("re:") else r["Name"].startswith(p) for p in prefixes)]
         if not rs or cls not in census:
             continue
         ns = sum(float(r["TotalDurationNs"]) for r in rs)
