@@ -272,9 +272,10 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
   float* logits = t2u_out + (size_t)Nn * D;
   int32_t* idx_scratch = reinterpret_cast<int32_t*>(logits + (size_t)U * V);
   // tables: t2u self {off,n,off,n}; unit self {25off,25n,25off,25n}; unit cross {25off,25n,off,n}; rows {25off,25n}
-  std::vector<int> tab(14 * B);
+  std::vector<int> tab(14 * B + Nn);            // + the packed row -> row of d_feats map of the gather below
   for (int b = 0; b < B; ++b) {
     const int o = on.off[b], n = h_n[b];
+    for (int r = 0; r < n; ++r) tab[14 * B + o + r] = b * feat_rows + r;
     int* a = &tab[4 * b]; a[0] = o; a[1] = n; a[2] = o; a[3] = n;
     int* u = &tab[4 * B + 4 * b]; u[0] = o * up; u[1] = n * up; u[2] = o * up; u[3] = n * up;
     int* x2 = &tab[8 * B + 4 * b]; x2[0] = o * up; x2[1] = n * up; x2[2] = o; x2[3] = n;
@@ -283,10 +284,11 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
   RET(m->seg_buf.ensure(tab.size() * sizeof(int)));
   int* dt = (int*)m->seg_buf.p;
   RET(upload(s, dt, tab));
-  // gather the decoder states of each utterance into packed rows
+  // gather the decoder states of each utterance into packed rows: ONE launch (round 4 issued B device-to-device copies per pack --
+  // 2975 __amd_rocclr_copyBuffer launches, 1 % of the one-stream kernel time and 64 more dependent launches per pack)
   for (int b = 0; b < B; ++b)
-    SS_HIP_CHECK(hipMemcpyAsync(x + (size_t)on.off[b] * D, d_feats + (size_t)b * feat_rows * D,
-                                (size_t)h_n[b] * D * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (h_n[b] > feat_rows) return SS_ERR_CAPACITY;
+  RET(launch_gather_rows(dt + 14 * B, d_feats, D, x, Nn, s, B * feat_rows));
   for (int l = 0; l < c.t2u_layers; ++l) {
     AttnArgs at;
     at.Q = selfbuf; at.ldq = 3 * D; at.K = selfbuf + D; at.V = selfbuf + 2 * D; at.ldk = at.ldv = 3 * D;

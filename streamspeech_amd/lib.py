@@ -115,6 +115,11 @@ def load():
         raise StreamSpeechHipError(
             f"{LIB_PATH} not found: build it with streamspeech_amd/csrc/build.sh "
             "(or __graft_entry__.build()).  There is no CPU fallback for the product path.")
+    # torch FIRST: its wheel carries its own HIP runtime; libstreamspeech_hip.so must bind to the runtime torch initialised (device
+    # memory, streams and events cross the boundary), not bring up /opt/rocm's copy before torch loads -- a process that dlopen-ed this
+    # library and only then imported torch (`__graft_entry__.build()` followed by `smoke()` in one process) got "no ROCm-capable device"
+    # from hipMalloc inside ss_model_create (profiles/r05_smoke_load_order.log).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:

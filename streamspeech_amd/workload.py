@@ -59,13 +59,13 @@ def run_batch(model, voc, pcm_packed, utts, detail: bool = False):
     test at the benchmarked configuration call THIS function): PCM in HBM -> fbank+CMVN -> chunk-Conformer
     -> CTC x2 -> lock-step AR MT greedy (n_mt tokens, forced eos) -> T2U + NAR unit decoder + CTC collapse
     -> unit sequence resized to K -> unit HiFi-GAN with the workload's durations.  Each utterance keeps its
-    B = 1 arithmetic (streamspeech_amd/csrc/model.hip ss_batch_*) -- per element the same operands in the same exact-f32
-    fmaf chains, but not always in the same ORDER: a GEMM routed to the stream-K kernels splits its k-range where the
-    workgroup ranges fall, which depends on the packed row count, so a row's partial sums are associated differently in a
-    pack than alone (differences ~1e-6 relative; fixed for a given pack: runs are bit-reproducible).  Layers that
-    feed an argmax (unit-decoder FFN / projections, encoder FFN2) are among them, so an exact tie-level flip between
-    batchings is possible in principle; tests/test_bench_config_gpu.py and tests/test_multilingual_gpu.py hold the ids of
-    192 packed utterances identical to the B = 1 oracle.  With detail=True every intermediate the
+    B = 1 arithmetic (streamspeech_amd/csrc/batch.hip ss_batch_*), and since round 5 PACK-INVARIANTLY so: every stage upstream of
+    an arg-max sums an utterance's products in an order that is a function of that utterance alone (one accumulator chain per GEMM
+    output element whatever the packed row count, whole-tile fused FFN, fixed LayerNorm / attention / decode forms:
+    ss_model_set_pack_invariant, default on), so its logits are bit-identical alone, in this pack and in any other
+    (tests/test_pack_invariance_gpu.py, tests/test_margin_gpu.py); tests/test_bench_config_gpu.py and tests/test_multilingual_gpu.py
+    hold the ids of 192 packed utterances identical to the B = 1 oracle (a row the float32 oracle itself cannot decide is
+    adjudicated in float64, oracle/adjudicate.py).  The vocoder (float output) keeps its stream-K / Winograd forms.  With detail=True every intermediate the
     parity test compares is returned as well (raw argmax ids, features); the launches are the same."""
     from .pipeline import units_from_tokens
     cfg = model.cfg

@@ -117,7 +117,7 @@ def main():
                     c["traffic_over_algorithmic"] = None
                     c["traffic_over_algorithmic_refused"] = (f"raw ratio {ratio:.3f}; " + ("launch counts differ between the counter pass and the census"
                                                              if not c["join_ok"] else "below 1: the counters cannot see less than the compulsory bytes"))
-    top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_mbytes_per_launch_corrected"] * kv[1]["launches"])[:16])
+    top = dict(sorted(kernels.items(), key=lambda kv: -kv[1]["hbm_mbytes_per_launch_corrected"] * kv[1]["launches"])[:64])
     json.dump({"note": sys.argv[4] if len(sys.argv) > 4 else "", "csrc_sha16": csrc_sha16(), "csrc_files_sha16": csrc_file_sha16(), "classes": classes, "kernels": top},
               open(sys.argv[3], "w"), indent=1)
     print(json.dumps(classes, indent=1))
