@@ -52,7 +52,8 @@ def main():
                 ph = 100.0 * d[:, :4].mean(axis=0) / span
                 groups = (taps + 2) // 3
                 cs = 128 if CH == 256 else CH
-                mfma = groups * (cs // 16) * 4 * (CH // cs) * 32 * (32 if CH >= 64 else 16)     # sub-steps x MFMAs x 32 cycles, per wave and block
+                prods = 4 * (taps // 3) + (taps % 3 + 1 if taps % 3 else 0)                     # products per channel block: 4 per full tap group, 2 / 3 for a one- / two-tap tail
+                mfma = prods * (cs // 16) * (CH // cs) * 32 * (32 if CH >= 64 else 16)           # sub-steps x MFMAs x 32 cycles, per wave and block
                 per_blk = d[:, 1].sum() / d[:, 4].sum()
                 print(f"{CH:3d} {taps:4d} {dil:3d} {'c2+R' if conv2 else 'c1  '} | {us:8.1f} {span / (us * 1e3):5.2f} | {ph[0]:6.1f} {ph[1]:6.1f} {ph[2]:6.1f} {ph[3]:6.1f} | "
                       f"{d[:, 4].mean():5.1f} | {per_blk:9.0f} / {mfma:8d} = {per_blk / mfma:5.2f} (x2 waves per SIMD: {per_blk / (2 * mfma):4.2f})", flush=True)
