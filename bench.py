@@ -869,7 +869,10 @@ def main():
                 from tools.pmc_traffic import csrc_file_sha16, csrc_sha16
                 then, now = pm.get("csrc_files_sha16") or {}, csrc_file_sha16()
                 changed = sorted(f for f in set(then) | set(now) if then.get(f) != now.get(f)) if then else None
-                dominant = ("conv_sk2.hip", "gemm.hpp", "gemm.hip", "common.hpp")   # kernel, its argument block, dispatch + workspace
+                kfile = ("conv_c64w.hip" if name.startswith(("conv_c64w", "conv_c128w", "conv_c256w", "conv_c32w")) else
+                         name.split("<")[0].replace("conv_gemm", "gemm").replace("smallm_gemm", "gemm").replace("rt_linear", "rtlin").replace("ffn_fused", "ffn")
+                         .replace("resblock_fused", "resblock") + ".hip")
+                dominant = (kfile, "gemm.hpp", "gemm.hip", "common.hpp", "dispatch.hpp")   # the class's kernel, its argument block, dispatch + workspace
                 traffic_detail = {"measured_by": "a separate rocprofv3 --pmc run of an earlier process (NOT this run)",
                                   "pmc_run_kernel_sources_sha16": pm.get("csrc_sha16"), "this_build_kernel_sources_sha16": csrc_sha16(),
                                   "same_kernel_sources": pm.get("csrc_sha16") == csrc_sha16(),

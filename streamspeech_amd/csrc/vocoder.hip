@@ -399,6 +399,7 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
     GemmArgs a;
     a.A = A; a.lda = Cin; a.W = cw.w; a.bias = cw.b; a.C = Cc; a.ldc = Cout; a.N = Cout; a.Cin = Cin; a.taps = k;
     a.pad = (k - 1) / 2; a.act = act; a.segs = dk; a.nseg = B; a.max_seg_out = ok.mx; a.M = Kt; a.in_len = Kt;
+    a.canon = CANON_SEQ;      // durations are integers (round(exp(.) - 1)): the predictor's convs must not change their summation order with the pack
     return launch_conv_gemm(a, s);
   };
   if (!forced && dur_prediction) {

@@ -170,3 +170,23 @@ def test_every_argmax_stage_is_bitwise_pack_invariant(hip_model):
         for k in ("enc", "asr", "st", "mt", "unit"):
             assert torch.equal(alone[k], pack[i][k]), f"utterance {i}: {k} differs between a pack of one and a pack of eight"
         assert alone["tok"] == pack[i]["tok"]
+
+
+def test_predicted_durations_do_not_depend_on_the_pack(hip_vocoder):
+    """a14 (agent/tts/codehifigan.py:56-95): durations are integers, round(exp(log-duration) - 1) clamped to >= 1 -- like an id, a
+    duration must not depend on what an utterance is batched with.  The batched duration predictor's convs are one-chain launches."""
+    import numpy as np
+    rng = np.random.default_rng(7)
+    codes = [[int(x) for x in rng.integers(0, 1000, size=n)] for n in (180, 37, 1, 555, 64, 90, 12, 300)]
+    _, dur, _ = hip_vocoder.batch_forward(codes, dur_prediction=True)
+    dur = dur.cpu().tolist()
+    off = np.cumsum([0] + [len(c) for c in codes])
+    for b in (0, 2, 3, 6):
+        _, d1, _ = hip_vocoder.batch_forward([codes[b]], dur_prediction=True)
+        assert d1.cpu().tolist() == dur[off[b]:off[b + 1]], f"utterance {b}: predicted durations differ alone vs in a pack of eight"
+    perm = [3, 0, 7]
+    _, d2, _ = hip_vocoder.batch_forward([codes[i] for i in perm], dur_prediction=True)
+    d2 = d2.cpu().tolist()
+    o2 = np.cumsum([0] + [len(codes[i]) for i in perm])
+    for j, i in enumerate(perm):
+        assert d2[o2[j]:o2[j + 1]] == dur[off[i]:off[i + 1]]
