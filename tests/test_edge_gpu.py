@@ -1,5 +1,7 @@
 """Edge cases of the hot path on the GPU: empty / minimal / maximal / ragged inputs and the error
 conventions of the C ABI (codes -> StreamSpeechHipError), as the reference's call sites exercise them."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -83,6 +85,44 @@ def test_single_unit_and_extreme_ragged_vocoder_batch(hip_vocoder, synth_weights
         one, _ = hip_vocoder.forward(torch.tensor(c, dtype=torch.int32, device="cuda:0"), True)
         assert wavs[b].shape == one.shape
         assert float(torch.sqrt(torch.mean((wavs[b] - one) ** 2))) < 1e-5
+
+
+def test_one_frame_utterances_inside_a_pack_at_winograd_scale(hip_vocoder, synth_weights):
+    """Segments SHORTER than a Winograd pair's reach (1, 2, 3 frames: 5 / 10 / 15 rows at the 256-channel stage, where a dilation-5 pair is
+    rows t and t + 5) inside a pack big enough for every stage to take its Winograd slab kernel (>= 32768 rows at the 256-channel stage):
+    the masked pair rows, the zero padding at both utterance edges inside one block and the neighbours' rows must not leak -- each
+    utterance against its own single-utterance forward (direct-form kernels) and the shortest ones against the CPU oracle."""
+    from oracle import streamspeech_oracle as O
+    from streamspeech_amd import lib as L
+    lib = L.load()
+    _, vcfg, _, vsd = synth_weights
+    sizes = [1, 700, 2, 1400, 3, 900, 1, 1200, 5, 800, 1000, 37]
+    codes = [[int(c) for c in synth.uniform(6, f"edge/w{i}", (k,), 0, 1000)] for i, k in enumerate(sizes)]
+    durs = [[1 + (j % 3 == 2) for j in range(len(c))] for c in codes]
+    assert sum(sum(d) for d in durs) * 5 >= 32768
+
+    def launches(name):
+        for c in range(lib.ss_prof_num_classes()):
+            if lib.ss_prof_class_name(c).decode() == name:
+                n = C.c_int64()
+                lib.ss_prof_totals(c, None, None, C.byref(n))
+                return n.value
+        raise KeyError(name)
+
+    before = {k: launches(k) for k in ("conv_c256w<256,128>", "conv_c128w<256,128>", "conv_c64w<256,64>")}
+    wavs, dur, K = hip_vocoder.batch_forward(codes, True, forced_dur=durs)
+    for k, n0 in before.items():
+        assert launches(k) > n0, f"{k} must have taken the pack's ResBlock convs"
+    for b, c in enumerate(codes):
+        fd = torch.tensor(durs[b], dtype=torch.int32, device="cuda:0")
+        one, _ = hip_vocoder.forward(torch.tensor(c, dtype=torch.int32, device="cuda:0"), True, forced_dur=fd)
+        assert wavs[b].shape == one.shape == (320 * sum(durs[b]),)
+        assert torch.isfinite(wavs[b]).all()
+        rms = float(torch.sqrt(torch.mean((wavs[b] - one) ** 2)))
+        assert rms < 1e-5, f"utterance {b} ({len(c)} units): packed vs alone rms {rms}"
+        if len(c) <= 5:
+            rw, _ = O.vocoder_forward(vsd, c, vcfg, True, forced_dur=durs[b])
+            assert float(torch.sqrt(torch.mean((wavs[b].cpu() - rw) ** 2))) < 1e-3
 
 
 def test_ragged_batch_one_second_next_to_fifteen(hip_model):
