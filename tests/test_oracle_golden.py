@@ -201,11 +201,11 @@ def test_float64_oracle_mode_matches_the_reference_modules_in_double(synth_weigh
         mine = O.encoder_forward(sd64, fb, cfg)
         assert ref.dtype == mine.dtype == torch.float64
         err = float((ref - mine).abs().max())
-        assert err < 2e-6, err                     # (the reference builds its sinusoid table in the input's dtype, the oracle casts the float32 table)
+        assert err < 1e-10, err                    # observed 6e-15: the same arithmetic, operation by operation
         head = ref_build.build_ctc_head(sd, cfg, "source_unigram").double()
         logits_ref = head(ref[:, None, :])["encoder_out"][:, 0]
         logits = O.ctc_head(sd64, mine, "source_unigram", cfg)[3]
-        assert float((logits_ref - logits).abs().max()) < 2e-5 * 1e-1 + 10 * err
+        assert float((logits_ref - logits).abs().max()) < 1e-9
         # and float32 sits ~2^-20 x max|logit| from it: the size of the bar the adjudication uses
         l32 = O.ctc_head(O.SD(sd), O.encoder_forward(O.SD(sd), fb, cfg), "source_unigram", cfg)[3]
         d = float((l32.double() - logits).abs().max())
