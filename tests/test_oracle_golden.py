@@ -211,3 +211,25 @@ def test_float64_oracle_mode_matches_the_reference_modules_in_double(synth_weigh
         d = float((l32.double() - logits).abs().max())
         scale = float(logits.abs().max())
         assert 0.1 * scale * 2.0 ** -20 < d < 16 * scale * 2.0 ** -20, (d, scale)
+        # the unit-decoder side of the adjudicator (MT decoder states -> T2U encoder -> CTC unit decoder) in double as well.
+        # fairseq's MultiheadAttention rounds its softmax to float32 whatever the module dtype (fairseq/utils.py:514-518), so the
+        # reference modules in double still carry ~2e-7 of float32 there; the adjudicator must not, so for this comparison the
+        # cast is lifted from the reference (observed without the lift: 2.3e-7 on the MT states; with it: below 1e-12).
+        import fairseq.utils as fu
+        import torch.nn.functional as F
+        toks = [cfg.eos] + [int(t) for t in synth.uniform(33, "f64/mt_tokens", (7,), 4, cfg.tgt_vocab)]
+        keep = fu.softmax
+        fu.softmax = lambda x, dim, onnx_trace=False: F.softmax(x, dim=dim)
+        try:
+            mt = ref_build.build_mt_decoder(sd, cfg).double()
+            feats_ref = mt(torch.tensor([toks]), encoder_out={"encoder_out": [ref[:, None]], "encoder_padding_mask": []}, features_only=True)[0][0]
+            t2u_ref = ref_build.build_t2u_encoder(sd, cfg).double()(feats_ref[:, None], None)["encoder_out"][0][:, 0]
+            ul_ref, _ = ref_build.build_unit_decoder(sd, cfg).double()(None, encoder_out={"encoder_out": [t2u_ref[:, None]], "encoder_padding_mask": []})
+        finally:
+            fu.softmax = keep
+        feats = O.mt_decoder_features(sd64, toks, mine, cfg)
+        assert feats.dtype == torch.float64 and float((feats_ref - feats).abs().max()) < 1e-9
+        t2u = O.t2u_encoder(sd64, feats, cfg)
+        assert float((t2u_ref - t2u).abs().max()) < 1e-9
+        ul = O.unit_decoder_logits(sd64, t2u, cfg)
+        assert ul.dtype == torch.float64 and float((ul_ref[0] - ul).abs().max()) < 1e-8
