@@ -8,11 +8,13 @@
    --master-addr 127.0.0.1 --master-port <free>` with the same arguments, rank 0 prints the one JSON line, the exit code
    is the launcher's.  `--dry-plan` runs the plan + barrier + reductions of that path on CPU over gloo, no GPU.)
 
-A "step" is one pass of the whole HIP hot path over one ragged batch of --batch (64) synthetic
+A "step" is one pass of the whole HIP hot path over one ragged batch of --batch (128) synthetic
 utterances, each with B = 1 arithmetic (streamspeech_amd/workload.py): PCM already in HBM ->
 fbank+CMVN -> chunk-Conformer -> CTC x2 -> AR MT greedy decode -> T2U + NAR unit decoder -> CTC
-collapse -> unit HiFi-GAN -> waveform in HBM.  The default K = 16 steps is BASELINE.json's
-1024-utterance set (rounds 1-3 packed 32 per batch; 64 measured +4 % on the same utterances, profiles/r04_batch_sweep.txt); with --batch 1 a step is one utterance through the single-utterance entry points.
+collapse -> unit HiFi-GAN -> waveform in HBM.  The default K = 8 steps is BASELINE.json's
+1024-utterance set (rounds 1-3 packed 32 per batch, round 4 and most of round 5 64; ids do not depend on the pack since round 5 --
+tests/test_pack_invariance_gpu.py -- and 128 measures +3.3 % on the same build, profiles/r05_pack_sweep.txt: launches twice as long,
+half as many lock-step decode launches); with --batch 1 a step is one utterance through the single-utterance entry points.
 value = total audio seconds / wall seconds over all ranks (RTFx; higher is better); the line also
 carries utterances/sec, the roofline of the dominant kernel (HIP events recorded on the launch
 stream inside the timed region) and the CPU oracle timed on this box's host cores (rank 0, N=1).
@@ -615,7 +617,7 @@ def dry_plan(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16, help="timed steps per GPU (one step = one ragged batch of --batch utterances)")
+    ap.add_argument("--steps", type=int, default=8, help="timed steps per GPU (one step = one ragged batch of --batch utterances)")
     ap.add_argument("--warmup", type=int, default=3, help="untimed warm-up steps per GPU before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the optional second line (same batches, split-bf16 vocoder convs)")
@@ -630,7 +632,7 @@ def main():
                     help="concurrent HIP streams per GPU (own scratch context each)")
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the single-stream latency measurement")
     ap.add_argument("--no-soak", action="store_true", help="skip the >= 100-step sustained passes after the timed region")
-    ap.add_argument("--batch", type=int, default=64,
+    ap.add_argument("--batch", type=int, default=128,
                     help="utterances packed per ragged batch (1 = the one-utterance-at-a-time entry points)")
     ap.add_argument("--mode", choices=("offline", "streaming"), default="offline",
                     help="offline: the headline metric (default, what the driver runs); streaming: BASELINE.json configs[2] -- the "
@@ -695,7 +697,7 @@ def main():
     mine, groups = workload.bench_plan(Ksteps, Bsz, rank, world, bucket=not args.no_length_bucketing, warm=Wn, strong=strong)
     K = sum(len(g) for g in groups)          # timed utterances on this rank
     steps_here = len(groups)                 # timed steps on this rank (= --steps unless --scaling strong)
-    Kpool = len(mine) - Wn                   # distinct synthetic utterances on this rank (cycled beyond 2048)
+    Kpool = len(mine) - Wn                   # distinct synthetic utterances on this rank (cycled beyond 4096)
     pcms = [torch.from_numpy(synth.synth_pcm(1234 + u.idx, u.n_samples)).to(dev) for u in mine]
     timed_ids = [i for g in groups for i in g]
     torch.cuda.synchronize()
@@ -758,6 +760,7 @@ def main():
     # each with its own HIP stream and its own scratch/KV-cache context over the shared weights
     S = max(1, args.streams)
     import threading
+    hbm_free0, hbm_total = torch.cuda.mem_get_info(dev)     # before any scratch context has grown (weights + the packed PCM are resident)
     ctxs = [(model, voc)] + [(model.new_context(), voc.new_context()) for _ in range(S - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     # one work item per timed step: the utterances of the ragged batch + their packed PCM (built before the timed region)
@@ -839,6 +842,10 @@ def main():
     if errors:
         raise errors[0]
 
+    hbm_free1, _ = torch.cuda.mem_get_info(dev)
+    hbm = {"total_gb": round(hbm_total / 2 ** 30, 1), "in_use_after_the_timed_region_gb": round((hbm_total - hbm_free1) / 2 ** 30, 1),
+           "scratch_per_context_gb": round((hbm_free0 - hbm_free1) / S / 2 ** 30, 2), "contexts": S,
+           "note": "a scratch context (model + vocoder) keeps the activations of the largest pack it has run; it never shrinks"}
     audio = sum(mine[i].seconds for i in timed_ids)
     per_rank = dp.gather_per_rank(dist, wall, audio, float(K), device=dev, placement=placement)
     wall, audio, nutt = dp.reduce_stats(dist, wall, audio, float(K), device=dev)
@@ -899,12 +906,16 @@ def main():
             return {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(ach / PEAK_HBM_GBS, 4), **common}
         ach = fl / (ms * 1e-3) / 1e12
-        if name.startswith(("conv_c64w", "conv_c128w", "conv_c32w")):
-            # Winograd F(2,3) forms (csrc/conv_c64w.hip, 64 and 128 channels): the census counts the conv's ALGORITHMIC (direct-form) FLOPs, as for every
-            # class; the kernel issues only 4 ceil(k/3) / (2 k) of them as MFMAs (2/3 at k = 3, 6/7 at k = 7, 8/11 at k = 11), so
-            # `frac` here can pass the rate the matrix cores sustain on the direct form -- it is not their busy fraction
-            common["note"] = ("Winograd F(2,3): algorithmic (direct-form) FLOPs over time; the MFMAs issued are 2/3 (k = 3), 6/7 (k = 7), "
-                              "8/11 (k = 11) of them")
+        if name.startswith(("conv_c64w", "conv_c128w", "conv_c256w", "conv_c32w")):
+            # Winograd F(2,3) forms (csrc/conv_c64w.hip, 32 ... 256 channels): the census counts the conv's ALGORITHMIC (direct-form) FLOPs, as for
+            # every class; the kernel issues only (4 (k div 3) + [0, 2, 3][k mod 3]) / (2 k) of them as MFMAs (4/6 at k = 3, 10/14 at k = 7, 15/22 at
+            # k = 11), so `frac` can pass 1 -- it is not the matrix cores' busy fraction; `frac_issued` (the library's count of issued MFMA FLOPs) is
+            iss = C.c_double()
+            lib.ss_prof_read_issued(c, C.byref(iss))
+            common["issued_mfma_tflops"] = round(iss.value / (ms * 1e-3) / 1e12, 3)
+            common["frac_issued"] = round(iss.value / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+            common["note"] = ("Winograd F(2,3) with F(2,1) / F(2,2) tail groups: `frac` = algorithmic (direct-form) FLOPs over time against the FP32-MFMA peak; "
+                              "the MFMAs issued are 4/6 (k = 3), 10/14 (k = 7), 15/22 (k = 11) of them = `frac_issued`, the matrix cores' busy fraction")
         return {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), **common}
 
@@ -997,10 +1008,11 @@ def main():
     # bf16(x) + bf16(x - bf16(x)) (ss_vocoder_set_bf16x3; f32 accumulation, everything else -- every argmax stage, the
     # duration predictor, the narrow vocoder stages -- stays f32).  Untimed for `value`; tests/test_bf16x3_gpu.py holds
     # its parity bars (durations identical, waveform RMS <= 1e-3 vs the FP32 oracle).
-    def region_pass(pick=None):
+    def region_pass(pick=None, lanes=1):
         """All timed batches once more over the same S streams (untimed for `value`); pick(wi, i) -> (model, vocoder)
-        context for work item i on worker wi (default: the worker's own fr-en context)."""
-        nxt, errs = [0], []
+        context for work item i on worker wi (default: the worker's own fr-en context).  lanes > 1: work item i belongs to lane
+        i % lanes and worker wi serves lane wi % lanes only (one queue per lane)."""
+        nxt, errs = list(range(lanes)), []
 
         def w2(wi):
             try:
@@ -1008,8 +1020,8 @@ def main():
                 with torch.cuda.stream(streams[wi]):
                     while True:
                         with lock:
-                            i = nxt[0]
-                            nxt[0] += 1
+                            i = nxt[wi % lanes]
+                            nxt[wi % lanes] += lanes
                         if i >= len(work):
                             break
                         m, v = ctxs[wi] if pick is None else pick(wi, i)
@@ -1081,38 +1093,54 @@ def main():
     # batches dealt round-robin over the languages inside the same S-stream region (untimed for `value`); parity of exactly
     # this arrangement against the oracle: tests/test_multilingual_gpu.py.
     multilingual = None
-    if world == 1 and Bsz > 1 and work and not args.no_multilingual:
+    ml_extra = max(0, min(3, S) - 1) * -(-S // 3)            # (language, stream) contexts beyond the S timed ones
+    ml_fits = torch.cuda.mem_get_info(dev)[0] > 1.15 * ml_extra * (hbm_free0 - hbm_free1) / S
+    if world == 1 and Bsz > 1 and work and not args.no_multilingual and not ml_fits:
+        multilingual = {"value": None, "skipped": f"{ml_extra} more scratch contexts of {hbm['scratch_per_context_gb']} GB do not fit in the free HBM"}
+    if world == 1 and Bsz > 1 and work and not args.no_multilingual and ml_fits:
         golden = os.path.join(ROOT, "tests", "golden")
-        per_lang = {"fr": ctxs}
+        order = ("fr", "es", "de")
+        # A scratch context holds the activations of the largest pack it has seen (~12 GB at 128 utterances of up to 15 s); 3 x S of
+        # them do not fit beside the S timed ones.  Each stream therefore serves ONE language (stream wi: language wi % 3, i.e. 3 / 3 / 2
+        # streams at S = 8) and batch i is of language i % 3: S contexts in use, the batches of a language queue on its streams.
+        lanes = min(len(order), S)
+        per_lang = {"fr": {wi: ctxs[wi] for wi in range(S) if wi % lanes == 0}}
         weights_mb = 4e-6 * (model.blob.numel() + voc.blob.numel())
-        for seed, lang in ((1, "es"), (2, "de")):
+        for li, (seed, lang) in enumerate(((1, "es"), (2, "de")), start=1):
+            if li >= lanes:
+                break
             g = np.load(os.path.join(golden, f"gcmvn_{lang}-en.npz"))      # configs/{es,de}-en/gcmvn.npz of the reference
             m = HipModel(synth.make_model_state_dict(seed, cfg), cfg, device=dev, cmvn_mean=g["mean"], cmvn_std=g["std"])
             v = HipVocoder(synth.make_vocoder_state_dict(seed, vcfg), vcfg, device=dev)
             weights_mb += 4e-6 * (m.blob.numel() + v.blob.numel())
-            per_lang[lang] = [(m, v)] + [(m.new_context(), v.new_context()) for _ in range(S - 1)]
-        order = ("fr", "es", "de")
+            mine_wi = [wi for wi in range(S) if wi % lanes == li]
+            per_lang[lang] = {wi: ((m, v) if k == 0 else (m.new_context(), v.new_context())) for k, wi in enumerate(mine_wi)}
+        order = order[:lanes]
         big = max(work, key=lambda w: w[1].numel())
         # the workload pins the MT length by max_new_tokens; a random es/de model may emit </s> earlier than the forced
         # position, which run_batch reports -- min_len pins it (ss_batch_mt_greedy bans </s> before min_len)
         for lang in order[1:]:
-            for wi, (m, v) in enumerate(per_lang[lang]):
+            for wi, (m, v) in per_lang[lang].items():
                 with torch.cuda.stream(streams[wi]):
                     run_batch(m, v, big[1], big[0])
         torch.cuda.synchronize()
-        pick = lambda wi, i: per_lang[order[i % 3]][wi]   # noqa: E731
-        region_pass(pick)                                  # warm pass over every (language, stream) context
-        dt_ml = min(region_pass(pick), region_pass(pick))
-        dt_1 = min(region_pass(), region_pass())           # the single-language set measured the same way, same moment
+        pick = lambda wi, i: per_lang[order[i % lanes]][wi]   # noqa: E731   (worker wi only draws items of lane wi % lanes)
+        region_pass(pick, lanes)                           # warm pass over every (language, stream) context
+        dt_ml = min(region_pass(pick, lanes), region_pass(pick, lanes))
+        dt_1 = min(region_pass(None, lanes), region_pass(None, lanes))   # the single-language set through the same queues, same moment
         multilingual = {"value": round(audio / dt_ml, 2), "unit": "x real-time (audio s / wall s)", "utterances_per_sec": round(nutt / dt_ml, 3),
                         "ms_per_step": round(1e3 * dt_ml / max(1, len(work)), 3), "languages": list(order),
-                        "weights_mb": round(weights_mb, 1), "contexts": 3 * S,
+                        "weights_mb": round(weights_mb, 1), "contexts": sum(len(x) for x in per_lang.values()),
+                        "streams_per_language": {lang: len(per_lang[lang]) for lang in order},
                         "single_language_same_method": {"value": round(audio / dt_1, 2), "ms_per_step": round(1e3 * dt_1 / max(1, len(work)), 3)},
                         "multilingual_over_single": round(dt_1 / dt_ml, 4),
                         "note": "BASELINE.json configs[4]: three weight sets (seeds 0/1/2 of the same architecture, es/de with the reference's "
-                                "gcmvn statistics) resident together, the same timed batches dealt round-robin over the languages on the same "
-                                "streams; best of two passes after one warm pass, next to the single-language set timed the same way"}
-        del per_lang["es"], per_lang["de"]
+                                "gcmvn statistics) resident together; batch i is of language i % 3 and runs on one of that language's streams "
+                                "(stream wi serves language wi % 3: a scratch context per (language, stream) pair for all 3 x S pairs does not fit "
+                                "in HBM at 128-utterance packs); best of two passes after one warm pass, next to the single-language set timed "
+                                "through the same per-lane queues"}
+        for lang in order[1:]:
+            del per_lang[lang]
         torch.cuda.empty_cache()
 
     # Strict configs[1] form: ONE utterance per call (the single-utterance entry points, no ragged packs),
@@ -1182,6 +1210,7 @@ def main():
             "roofline": roofline,
             "roofline_family": roofline_family,
             "soak": soak,
+            "hbm": hbm,
             "dispatch": dispatch,
             "bf16x3": bf16x3_line,
             "multilingual": multilingual,

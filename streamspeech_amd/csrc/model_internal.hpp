@@ -59,7 +59,7 @@ struct DevBuf {
   int ensure(size_t need) {
     if (need <= bytes) return SS_OK;
     if (p) { SS_HIP_CHECK(hipDeviceSynchronize()); SS_HIP_CHECK(hipFree(p)); p = nullptr; bytes = 0; }
-    size_t cap = need + need / 4 + 4096;
+    size_t cap = need + std::min(need / 4, (size_t)256 << 20) + 4096;   // growth slack: a quarter, at most 256 MB (a pack's activations run to 12 GB)
     SS_HIP_CHECK(hipMalloc(&p, cap));
     bytes = cap;
     return SS_OK;

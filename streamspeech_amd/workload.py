@@ -89,7 +89,7 @@ def run_batch(model, voc, pcm_packed, utts, detail: bool = False):
 
 
 def bench_plan(steps: int, batch: int, rank: int = 0, world: int = 1, bucket: bool = True, warm: int = 3,
-               pool_cap: int = 2048, strong: bool = False):
+               pool_cap: int = 4096, strong: bool = False):
     """The utterance set and ragged-batch grouping of `bench.py --steps steps --batch batch` on one rank.
     -> (mine, groups): `mine` = this rank's utterances (the `warm` single-utterance warm-ups first), `groups`
     = the timed steps as lists of indices into `mine`, in dispatch order.  Weak scaling (default): every rank gets

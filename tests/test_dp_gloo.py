@@ -95,7 +95,7 @@ def test_bench_gpus_2_as_typed_self_launches_its_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--dry-plan"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--batch", "64", "--dry-plan"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.splitlines()            # the bench line and NOTHING else on stdout (library banners go to stderr)
@@ -106,7 +106,7 @@ def test_bench_gpus_2_as_typed_self_launches_its_ranks():
     assert out["stand_in_wall_max_s"] == 1.001                    # MAX over ranks picked rank 1's
     assert out["planned_utterances"] == 512 and out["comm"]["results_ok"] and out["comm"]["world"] == 2
     # strong scaling: the one fixed set splits over the ranks
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--dry-plan", "--scaling", "strong"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--batch", "64", "--dry-plan", "--scaling", "strong"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
@@ -143,7 +143,7 @@ def test_bench_gpus_8_dry_plan_balances_audio_and_prints_one_line():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 8 and out["dry_plan"] and out["scaling"] == "weak"
     audio = [p["audio_s"] for p in out["per_rank"]]
-    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and all(p["utterances"] == 20 * 64 for p in out["per_rank"])
+    assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and all(p["utterances"] == 20 * 128 for p in out["per_rank"])
     mean = sum(audio) / 8
     assert max(abs(a - mean) for a in audio) / mean < 0.01, audio
     assert all("numa_node" in p and p["pinned_to_numa_node"] is False for p in out["per_rank"])     # dry plan never pins
