@@ -586,8 +586,9 @@ def dry_plan(args, rank, world):
     dist = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
         with _stdout_to_stderr():
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=180))    # a rendezvous that cannot complete fails, it does not wait 30 min
             dist.barrier()
     Ksteps, Bsz = max(1, args.steps), max(1, args.batch)
     mine, groups = workload.bench_plan(Ksteps, Bsz, rank, world, bucket=not args.no_length_bucketing, warm=3, strong=args.scaling == "strong")

@@ -25,6 +25,10 @@ def pytest_configure(config):
         pass
     if not config.option.durations:
         config.option.durations = 10          # always print the ten slowest tests
+    # no test may hang the suite: with pytest-timeout present (it is in this image) a test that passes SS_TEST_TIMEOUT seconds (default
+    # 900; the slowest GPU test takes ~2 min, the slowest CPU test ~15 s) fails instead
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = float(os.environ.get("SS_TEST_TIMEOUT", "900"))
 
 
 @pytest.fixture(scope="session")

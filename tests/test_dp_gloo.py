@@ -16,6 +16,23 @@ def _free_port():
         return s.getsockname()[1]
 
 
+
+def _run_cli(cmd, env, timeout):
+    """subprocess.run(capture_output=True, timeout=...) that cannot hang: the command runs in its own process group, and on a
+    time-out the WHOLE group is killed (a launcher killed alone leaves its ranks holding the pipes, and communicate() then waits
+    for ever)."""
+    import signal
+    import subprocess
+    p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, err = p.communicate(timeout=timeout)
+    except subprocess.TimeoutExpired:
+        os.killpg(p.pid, signal.SIGKILL)
+        out, err = p.communicate()
+        raise AssertionError(f"timed out after {timeout} s: {' '.join(cmd)}\n{err[-2000:]}")
+    return subprocess.CompletedProcess(cmd, p.returncode, out, err)
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -95,8 +112,7 @@ def test_bench_gpus_2_as_typed_self_launches_its_ranks():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--batch", "64", "--dry-plan"],
-                       env=env, capture_output=True, text=True, timeout=600)
+    r = _run_cli([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--batch", "64", "--dry-plan"], env, 240)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.splitlines()            # the bench line and NOTHING else on stdout (library banners go to stderr)
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
@@ -106,8 +122,7 @@ def test_bench_gpus_2_as_typed_self_launches_its_ranks():
     assert out["stand_in_wall_max_s"] == 1.001                    # MAX over ranks picked rank 1's
     assert out["planned_utterances"] == 512 and out["comm"]["results_ok"] and out["comm"]["world"] == 2
     # strong scaling: the one fixed set splits over the ranks
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--batch", "64", "--dry-plan", "--scaling", "strong"],
-                       env=env, capture_output=True, text=True, timeout=600)
+    r = _run_cli([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--batch", "64", "--dry-plan", "--scaling", "strong"], env, 240)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
     assert out["planned_utterances"] == 256 and out["steps_per_gpu"] == 2
@@ -120,8 +135,7 @@ def test_bench_failing_rank_gives_nonzero_exit():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["SS_BENCH_DRY_FAIL_RANK"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--dry-plan"],
-                       env=env, capture_output=True, text=True, timeout=600)
+    r = _run_cli([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--dry-plan"], env, 240)
     assert r.returncode != 0
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
 
@@ -135,8 +149,7 @@ def test_bench_gpus_8_dry_plan_balances_audio_and_prints_one_line():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     env["OMP_NUM_THREADS"] = "1"
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-plan"],
-                       env=env, capture_output=True, text=True, timeout=900)
+    r = _run_cli([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5", "--dry-plan"], env, 300)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.splitlines()
     assert len(lines) == 1 and lines[0].startswith("{"), r.stdout
