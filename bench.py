@@ -1094,29 +1094,32 @@ def main():
     # batches dealt round-robin over the languages inside the same S-stream region (untimed for `value`); parity of exactly
     # this arrangement against the oracle: tests/test_multilingual_gpu.py.
     multilingual = None
-    ml_extra = max(0, min(3, S) - 1) * -(-S // 3)            # (language, stream) contexts beyond the S timed ones
-    ml_fits = torch.cuda.mem_get_info(dev)[0] > 1.15 * ml_extra * (hbm_free0 - hbm_free1) / S
-    if world == 1 and Bsz > 1 and work and not args.no_multilingual and not ml_fits:
+    # configs[4] needs scratch contexts beyond the S timed ones: a (language, stream) pair each when 2 x S more fit (every stream serves every
+    # language: rounds 1-4, packs of 64); otherwise each stream serves ONE language (stream wi: language wi % 3, i.e. 3 / 3 / 2 streams at
+    # S = 8, batch i of language i % 3 queued on its language's streams): 2 x ceil(S / 3) more contexts; otherwise the leg is skipped.
+    per_ctx = (hbm_free0 - hbm_free1) / S
+    free_now = torch.cuda.mem_get_info(dev)[0]
+    if free_now > 1.15 * 2 * S * per_ctx:
+        lanes, ml_extra = 1, 2 * S
+    elif S >= 3 and free_now > 1.15 * 2 * -(-S // 3) * per_ctx:
+        lanes, ml_extra = 3, 2 * -(-S // 3)
+    else:
+        lanes, ml_extra = 0, 2 * -(-S // 3)
+    want_ml = world == 1 and Bsz > 1 and work and not args.no_multilingual
+    if want_ml and not lanes:
         multilingual = {"value": None, "skipped": f"{ml_extra} more scratch contexts of {hbm['scratch_per_context_gb']} GB do not fit in the free HBM"}
-    if world == 1 and Bsz > 1 and work and not args.no_multilingual and ml_fits:
+    if want_ml and lanes:
         golden = os.path.join(ROOT, "tests", "golden")
         order = ("fr", "es", "de")
-        # A scratch context holds the activations of the largest pack it has seen (~12 GB at 128 utterances of up to 15 s); 3 x S of
-        # them do not fit beside the S timed ones.  Each stream therefore serves ONE language (stream wi: language wi % 3, i.e. 3 / 3 / 2
-        # streams at S = 8) and batch i is of language i % 3: S contexts in use, the batches of a language queue on its streams.
-        lanes = min(len(order), S)
         per_lang = {"fr": {wi: ctxs[wi] for wi in range(S) if wi % lanes == 0}}
         weights_mb = 4e-6 * (model.blob.numel() + voc.blob.numel())
         for li, (seed, lang) in enumerate(((1, "es"), (2, "de")), start=1):
-            if li >= lanes:
-                break
             g = np.load(os.path.join(golden, f"gcmvn_{lang}-en.npz"))      # configs/{es,de}-en/gcmvn.npz of the reference
             m = HipModel(synth.make_model_state_dict(seed, cfg), cfg, device=dev, cmvn_mean=g["mean"], cmvn_std=g["std"])
             v = HipVocoder(synth.make_vocoder_state_dict(seed, vcfg), vcfg, device=dev)
             weights_mb += 4e-6 * (m.blob.numel() + v.blob.numel())
-            mine_wi = [wi for wi in range(S) if wi % lanes == li]
+            mine_wi = [wi for wi in range(S) if wi % lanes == li % lanes]
             per_lang[lang] = {wi: ((m, v) if k == 0 else (m.new_context(), v.new_context())) for k, wi in enumerate(mine_wi)}
-        order = order[:lanes]
         big = max(work, key=lambda w: w[1].numel())
         # the workload pins the MT length by max_new_tokens; a random es/de model may emit </s> earlier than the forced
         # position, which run_batch reports -- min_len pins it (ss_batch_mt_greedy bans </s> before min_len)
@@ -1125,7 +1128,7 @@ def main():
                 with torch.cuda.stream(streams[wi]):
                     run_batch(m, v, big[1], big[0])
         torch.cuda.synchronize()
-        pick = lambda wi, i: per_lang[order[i % lanes]][wi]   # noqa: E731   (worker wi only draws items of lane wi % lanes)
+        pick = lambda wi, i: per_lang[order[i % 3]][wi]   # noqa: E731   (lanes = 3: worker wi only draws items i with i % 3 == wi % 3)
         region_pass(pick, lanes)                           # warm pass over every (language, stream) context
         dt_ml = min(region_pass(pick, lanes), region_pass(pick, lanes))
         dt_1 = min(region_pass(None, lanes), region_pass(None, lanes))   # the single-language set through the same queues, same moment
@@ -1136,10 +1139,11 @@ def main():
                         "single_language_same_method": {"value": round(audio / dt_1, 2), "ms_per_step": round(1e3 * dt_1 / max(1, len(work)), 3)},
                         "multilingual_over_single": round(dt_1 / dt_ml, 4),
                         "note": "BASELINE.json configs[4]: three weight sets (seeds 0/1/2 of the same architecture, es/de with the reference's "
-                                "gcmvn statistics) resident together; batch i is of language i % 3 and runs on one of that language's streams "
-                                "(stream wi serves language wi % 3: a scratch context per (language, stream) pair for all 3 x S pairs does not fit "
-                                "in HBM at 128-utterance packs); best of two passes after one warm pass, next to the single-language set timed "
-                                "through the same per-lane queues"}
+                                "gcmvn statistics) resident together; batch i is of language i % 3" +
+                                (" and runs on one of that language's streams (stream wi serves language wi % 3: a scratch context per "
+                                 "(language, stream) pair for all 3 x S pairs does not fit in HBM at this pack size)" if lanes == 3 else
+                                 " on whichever stream takes it (a scratch context per (language, stream) pair)") +
+                                "; best of two passes after one warm pass, next to the single-language set timed through the same queues"}
         for lang in order[1:]:
             del per_lang[lang]
         torch.cuda.empty_cache()
