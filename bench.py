@@ -234,7 +234,7 @@ def oracle_check(sd, cfg, model, sample, dev):
     return {"utterances": len(sample), "argmax_rows_compared": rows_total, "ids_identical_to_float32_oracle": identical,
             "near_tie_rows": len(lines), "adjudicated_in_float64": lines,
             "rule": "strict ids; a differing row must be a float64 top-2 exchange with gap < 2^-20 x max|logit| (oracle/adjudicate.py); "
-                    "the measured configuration at full size (192 utterances of 3 packs of 64, ~120 k rows): tests/test_bench_config_gpu.py"}
+                    "the measured configuration at full size (320 utterances of 8 packs of 128 in flight, ~250 k rows): tests/test_bench_config_gpu.py"}
 
 
 def census(lib):

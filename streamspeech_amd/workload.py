@@ -64,7 +64,7 @@ def run_batch(model, voc, pcm_packed, utts, detail: bool = False):
     output element whatever the packed row count, whole-tile fused FFN, fixed LayerNorm / attention / decode forms:
     ss_model_set_pack_invariant, default on), so its logits are bit-identical alone, in this pack and in any other
     (tests/test_pack_invariance_gpu.py, tests/test_margin_gpu.py); tests/test_bench_config_gpu.py and tests/test_multilingual_gpu.py
-    hold the ids of 192 packed utterances identical to the B = 1 oracle (a row the float32 oracle itself cannot decide is
+    hold the ids of 320 packed utterances (packs of 128, the measured configuration) identical to the B = 1 oracle (a row the float32 oracle itself cannot decide is
     adjudicated in float64, oracle/adjudicate.py).  The vocoder (float output) keeps its stream-K / Winograd forms.  With detail=True every intermediate the
     parity test compares is returned as well (raw argmax ids, features); the launches are the same."""
     from .pipeline import units_from_tokens
