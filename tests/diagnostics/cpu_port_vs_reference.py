@@ -2,7 +2,7 @@
 times, because /root/reference does not exist there) against the REFERENCE's own modules (oracle/ref_build.py: the classes of
 /root/reference executed in place) on the same inputs, threads and protocol (2 warm-ups, 5 timed passes, median per stage)
 -- BASELINE.md §3 / SURVEY.md §8d.  Runs in the build container only.
-    python tools/cpu_port_vs_reference.py profiles/r03_cpu_port_vs_reference.json"""
+    python tests/diagnostics/cpu_port_vs_reference.py profiles/r03_cpu_port_vs_reference.json"""
 import json
 import os
 import sys
@@ -11,7 +11,7 @@ import time
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import kaldi_fbank as K                                  # noqa: E402
 from oracle import ref_agent, ref_build                              # noqa: E402

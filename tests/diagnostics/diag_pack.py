@@ -1,13 +1,13 @@
 """Diagnosis: for the packs the bench-config test checks, find every utterance whose ASR / ST CTC ids differ between the
 ragged pack, the single-utterance HIP entry points and the CPU oracle, and print the top-1 / top-2 margin at the frames
-that differ (a near tie of the seeded random weights vs a defect).  Usage: python tools/diag_pack.py [steps] [batch]"""
+that differ (a near tie of the seeded random weights vs a defect).  Usage: python tests/diagnostics/diag_pack.py [steps] [batch]"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import streamspeech_oracle as O  # noqa: E402  (diagnosis tool, not the product path)
 from streamspeech_amd import synth, workload  # noqa: E402
