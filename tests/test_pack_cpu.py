@@ -127,6 +127,37 @@ def test_product_path_fails_loudly_without_gpu():
         HipModel({}, ModelConfig())
 
 
+def test_nothing_but_the_checkers_imports_the_oracle():
+    """oracle/ is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's CPU-baseline legs may import it -- the product
+    package, the tools and the job scripts must not (a product path that routes through the oracle would void every parity claim)."""
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b|from\s+\.+oracle\b)", re.M)
+    offenders = []
+    for top in ("streamspeech_amd", "tools", "fairseq_user_dir"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for f in files:
+                if f.endswith(".py") and pat.search(open(os.path.join(dirpath, f)).read()):
+                    offenders.append(os.path.relpath(os.path.join(dirpath, f), ROOT))
+    assert not offenders, offenders
+    # bench.py: every oracle import sits inside a function of the CPU-baseline legs
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    allowed = ("cpu_baseline", "oracle_check", "streaming_measure")
+    func = None
+    for line in src.splitlines():
+        m = re.match(r"def\s+(\w+)", line)
+        if m:
+            func = m.group(1)
+        if pat.search(line):
+            assert line.startswith(" ") and func in allowed, (func, line)
+    # __graft_entry__: only smoke()
+    func = None
+    for line in open(os.path.join(ROOT, "__graft_entry__.py")).read().splitlines():
+        m = re.match(r"def\s+(\w+)", line)
+        if m:
+            func = m.group(1)
+        if pat.search(line):
+            assert func == "smoke", (func, line)
+
+
 def test_debug_force_tile_rejects_unknown_codes():
     """an unrecognised `bm` used to be stored as a forced tile and silently disabled the small-M / GEMV kernels."""
     from streamspeech_amd import lib as L
