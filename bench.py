@@ -11,8 +11,9 @@
 A "step" is one pass of the whole HIP hot path over one ragged batch of --batch (128) synthetic
 utterances, each with B = 1 arithmetic (streamspeech_amd/workload.py): PCM already in HBM ->
 fbank+CMVN -> chunk-Conformer -> CTC x2 -> AR MT greedy decode -> T2U + NAR unit decoder -> CTC
-collapse -> unit HiFi-GAN -> waveform in HBM.  The default K = 8 steps is BASELINE.json's
-1024-utterance set (rounds 1-3 packed 32 per batch, round 4 and most of round 5 64; ids do not depend on the pack since round 5 --
+collapse -> unit HiFi-GAN -> waveform in HBM.  The default K = 16 steps is twice BASELINE.json's
+1024-utterance set -- two batches per stream: with one (K = 8) the region is as long as the longest pack alone, 5811x
+(rounds 1-3 packed 32 per batch, round 4 and most of round 5 64; ids do not depend on the pack since round 5 --
 tests/test_pack_invariance_gpu.py -- and 128 measures +3.3 % on the same build, profiles/r05_pack_sweep.txt: launches twice as long,
 half as many lock-step decode launches); with --batch 1 a step is one utterance through the single-utterance entry points.
 value = total audio seconds / wall seconds over all ranks (RTFx; higher is better); the line also
@@ -618,7 +619,7 @@ def dry_plan(args, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8, help="timed steps per GPU (one step = one ragged batch of --batch utterances)")
+    ap.add_argument("--steps", type=int, default=16, help="timed steps per GPU (one step = one ragged batch of --batch utterances)")
     ap.add_argument("--warmup", type=int, default=3, help="untimed warm-up steps per GPU before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the optional second line (same batches, split-bf16 vocoder convs)")
