@@ -39,6 +39,10 @@ from streamspeech_amd.config import ModelConfig, VocoderConfig  # noqa: E402
 from streamspeech_amd.engine import HipModel, HipVocoder   # noqa: E402
 from streamspeech_amd.pipeline import mt_greedy, units_from_tokens  # noqa: E402
 
+METRIC = "real-time factor (RTFx = audio seconds / wall seconds) + utterances/sec, offline S2ST fr-en"
+WORKLOAD = ("offline S2ST fr-en, B=1 semantics per utterance (ragged no-padding batches), synthetic CVSS-C-shaped utterances "
+            "(LogNormal(ln 4.5 s, 0.45) clipped to [1,15] s, seed 1234), full fbank+encoder+CTC+AR-MT+T2U+NAR-unit+vocoder HIP path, "
+            "random-init weights of the streamspeech.offline.fr-en architecture")
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0          # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured copy)
 
@@ -263,7 +267,7 @@ def _agent_args(segment_ms, **over):
     return a
 
 
-def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=None, cpu_utts=0, long_seconds=()):
+def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=None, cpu_utts=0, long_seconds=(), configurations=None):
     """BASELINE.json configs[2]: the drop-in SimulEval agent (streamspeech_amd/agent.py) fed `segment_ms` chunks of synthetic
     CVSS-C-shaped utterances, one at a time -- with the incremental encoder + receptive-field vocoder tail (default)
     and with the reference's full recompute at every policy() call (agent :425-435, 686-689, 748-751).  With `cpu_sd`
@@ -309,6 +313,8 @@ def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=No
     # then the reference's full recompute per call, and the default with the launch-per-op decode step (A/B of mt_step.hip)
     for name, over in (("incremental", {}), ("full_recompute", {"full_recompute_encoder": True, "vocoder_context_units": 0}),
                        ("incremental_launch_per_op_mt", {"mt_step_workgroups": 0})):
+        if configurations is not None and name not in configurations:
+            continue
         agent = StreamSpeechS2STAgent(_agent_args(segment_ms, **over), model=StreamSpeechModel.from_engine(model), vocoder=VocSurface(voc))
         SE.run_utterance(agent, pcms[0], segment_ms)                      # warm-up utterance
         n0 = census_launches()
@@ -334,7 +340,8 @@ def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=No
     out["value"] = out["incremental"]["rtfx_compute"]
     out["unit"] = "x real-time (audio s / policy() compute s, one utterance at a time)"
     out["higher_is_better"] = True
-    out["incremental_speedup_over_full_recompute"] = round(out["full_recompute"]["compute_s"] / out["incremental"]["compute_s"], 3)
+    if "full_recompute" in out:
+        out["incremental_speedup_over_full_recompute"] = round(out["full_recompute"]["compute_s"] / out["incremental"]["compute_s"], 3)
 
     if cpu_sd is not None and cpu_utts > 0:
         # the reference's per-chunk full recompute on the host cores: same agent class, oracle engine (kind "port")
@@ -425,7 +432,34 @@ def long_prefix_sweep(model, voc, cfg, segment_ms, seconds):
 def streaming_mode(args, model, voc, lib, cfg, sd, vsd, vcfg):
     out = streaming_measure(model, voc, lib, cfg, args.segment_ms, args.utterances,
                             cpu_sd=None if args.no_cpu_baseline else (sd, vsd, vcfg), cpu_utts=4, long_seconds=(15, 30))
-    _emit(out)
+    emit_streaming(out)
+
+
+def emit_streaming(out):
+    """--mode streaming: the full report to the sidecar / stderr, a compact line (< LINE_BYTE_CAP) to stdout."""
+    path = detail_path()
+    try:
+        json.dump(out, open(path, "w"), indent=1)
+    except OSError:
+        path = None
+    print("bench.py full result: " + json.dumps(out), file=sys.stderr, flush=True)
+    line = {k: out.get(k) for k in ("metric", "mode", "value", "unit", "higher_is_better", "n_gpus", "dtype", "data", "segment_ms",
+                                    "incremental_speedup_over_full_recompute")}
+    line["config"] = {"workload": out["config"]["workload"]}
+    for name in ("incremental", "full_recompute", "incremental_launch_per_op_mt"):
+        v = out.get(name)
+        if v:
+            line[name] = {**{k: v[k] for k in ("rtfx_compute", "utterances", "policy_calls", "ms_per_policy_call_mean", "ms_per_policy_call_p95",
+                                               "gemm_class_launches_per_policy_call", "RTF_CA", "StartOffset_CA_ms", "EndOffset_CA_ms") if k in v},
+                          "ms_per_read_call_mean": v["calls_by_kind"]["ms_per_read_call_mean"],
+                          "ms_per_write_call_mean": v["calls_by_kind"]["ms_per_write_call_mean"],
+                          "ms_per_source_finished_call_mean": v["calls_by_kind"]["ms_per_source_finished_call_mean"]}
+    cb = out.get("cpu_baseline")
+    line["cpu_baseline"] = None if not cb else {k: cb[k] for k in ("value", "unit", "cores", "kind", "ms_per_policy_call_mean", "RTF_CA")}
+    if out.get("long_prefix_sweep"):
+        line["long_prefix_speedup_total"] = {str(r["source_s"]): r["speedup_total"] for r in out["long_prefix_sweep"]}
+    line["detail"] = path and os.path.relpath(path, ROOT)
+    _emit(line)
 
 
 def _pmc_file():
@@ -459,6 +493,100 @@ def _emit(obj):
         _REAL_STDOUT.flush()
     else:
         print(line, flush=True)
+
+
+LINE_BYTE_CAP = 6000      # the driver could not parse a 21-KB line; the contract line stays under 6 KB, the rest is a sidecar
+ROOFLINE_KEYS = ("kernel", "bound", "achieved", "peak", "unit", "frac", "frac_issued", "launches", "avg_launch_us", "algo_gflop_per_launch",
+                 "algo_mbytes_per_launch", "traffic", "traffic_over_algorithmic", "mfma_util_pct")
+
+
+def _pick(d, keys):
+    return None if not d else {k: d[k] for k in keys if k in d}
+
+
+def compact_line(full):
+    """The ONE stdout line of the bench contract, built from the full result dict: the contract keys, `roofline` and `cpu_baseline` as
+    plain numbers, and one number per optional leg.  Everything else (dispatch table, process census, traffic detail, the streaming
+    reports, notes) lives in the sidecar (`detail_path()`) and on stderr.  Never longer than LINE_BYTE_CAP bytes: optional keys are
+    dropped (and named in `dropped`) before the cap is passed -- tests/test_bench_line_cpu.py holds the bound for N = 1 and N = 8."""
+    cfgd = full.get("config") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "utterances_per_sec",
+                                     "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    line["config"] = {k: cfgd[k] for k in ("workload", "utterances_per_ragged_batch", "concurrent_streams_per_gpu", "utterances_per_gpu",
+                                           "audio_seconds_per_gpu", "parallelism") if k in cfgd}
+    if full.get("dry_plan"):
+        line["dry_plan"] = True
+        for k in ("steps_per_gpu", "utterances_per_step", "planned_audio_seconds", "planned_utterances", "stand_in_wall_max_s", "self_launched"):
+            line[k] = full.get(k)
+    r = full.get("roofline")
+    if r:
+        rr = _pick(r, ROOFLINE_KEYS)
+        td = r.get("traffic_detail") or {}
+        rr.setdefault("mfma_util_pct", td.get("mfma_util_pct"))
+        rr["traffic_same_kernel_sources"] = td.get("same_kernel_sources")
+        rr["measured_on"] = "one-stream replay of the timed batches" if "replay" in str(r.get("measured_on", "")) else "timed region"
+        line["roofline"] = rr
+    else:
+        line["roofline"] = None
+    fam = full.get("roofline_family")
+    if fam:
+        line["roofline_family"] = _pick(fam, ("achieved", "frac", "frac_issued", "launches"))
+    cb = full.get("cpu_baseline")
+    if cb:
+        oc = cb.get("oracle_check") or {}
+        line["cpu_baseline"] = {"value": cb.get("value"), "unit": "x real-time", "cores": cb.get("cores"), "kind": cb.get("kind"),
+                                "sample": f"{len(cb.get('per_utterance') or [])} utterances (short / median / long) of the same workload, "
+                                          "median of timed passes",
+                                "oracle_check": _pick(oc, ("utterances", "argmax_rows_compared", "ids_identical_to_float32_oracle", "near_tie_rows"))}
+    else:
+        line["cpu_baseline"] = None
+    line["near_tie_rows"] = full.get("near_tie_rows")
+    pi = full.get("pack_invariance")
+    line["pack_invariance"] = None if not pi else {"alone_equals_in_pack_bitwise": pi.get("alone_equals_in_pack_bitwise")}
+    line["per_rank"] = [{k: p[k] for k in ("rank", "wall_s", "audio_s", "utterances")} for p in (full.get("per_rank") or [])]
+    rc = full.get("rccl") or full.get("comm")
+    line["rccl"] = None if not rc else ({"error": str(rc["error"])[:120]} if "error" in rc else _pick(rc, ("backend", "world", "results_ok", "barrier_us")))
+    for k in ("streaming_320ms", "multilingual", "soak", "bf16x3"):
+        v = full.get(k)
+        if v:
+            line[k] = v.get("value") if not v.get("skipped") else None
+    st = full.get("streaming_320ms")
+    if st and st.get("incremental"):
+        line["streaming_320ms_read_call_ms"] = (st["incremental"].get("calls_by_kind") or {}).get("ms_per_read_call_mean")
+        line["streaming_320ms_launches_per_call"] = st["incremental"].get("gemm_class_launches_per_policy_call")
+    hb = full.get("hbm")
+    if hb:
+        line["hbm_in_use_gb"] = hb.get("in_use_after_the_timed_region_gb")
+    line["stream_k_spin_timeouts"] = full.get("stream_k_spin_timeouts")
+    line["detail"] = full.get("detail_file")
+    dropped = []
+    for k in ("detail", "hbm_in_use_gb", "streaming_320ms_launches_per_call", "streaming_320ms_read_call_ms", "bf16x3", "roofline_family",
+              "stream_k_spin_timeouts", "soak", "multilingual", "streaming_320ms", "pack_invariance", "per_rank"):
+        if len(json.dumps(line)) < LINE_BYTE_CAP:
+            break
+        if k in line:
+            del line[k]
+            dropped.append(k)
+            line["dropped"] = dropped
+    return line
+
+
+def detail_path():
+    return os.environ.get("SS_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+
+
+def emit_result(full):
+    """Sidecar + stderr get the full result; stdout gets compact_line(full)."""
+    path = detail_path()
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        full["detail_file"] = os.path.relpath(path, ROOT) if path.startswith(ROOT) else path
+    except OSError as e:
+        full["detail_file"] = None
+        print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
+    print("bench.py full result: " + json.dumps(full), file=sys.stderr, flush=True)
+    _emit(compact_line(full))
 
 
 class _stdout_to_stderr:
@@ -605,12 +733,17 @@ def dry_plan(args, rank, world):
     wall_max, audio_tot, nutt = dp.reduce_stats(dist, wall, audio, float(len(timed_ids)))
     comm = comm_probe(dist, "cpu", reps=5) if dist is not None else None
     if rank == 0:
-        _emit(({"metric": "real-time factor (RTFx = audio seconds / wall seconds) + utterances/sec, offline S2ST fr-en",
-                          "dry_plan": True, "value": None, "unit": "x real-time", "n_gpus": world, "steps": Ksteps, "warmup": max(0, args.warmup),
-                          "scaling": args.scaling, "steps_per_gpu": len(groups), "utterances_per_step": Bsz,
-                          "planned_audio_seconds": round(audio_tot, 2), "planned_utterances": int(nutt),
-                          "stand_in_wall_max_s": wall_max, "per_rank": per_rank, "comm": comm,
-                          "self_launched": bool(os.environ.get("SS_BENCH_SELF_LAUNCHED"))}))
+        full = {"metric": METRIC, "dry_plan": True, "value": None, "unit": "x real-time", "n_gpus": world, "steps": Ksteps, "warmup": max(0, args.warmup),
+                "ms_per_step": None, "utterances_per_sec": None, "higher_is_better": True, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "scaling": args.scaling, "steps_per_gpu": len(groups), "utterances_per_step": Bsz,
+                "config": {"workload": WORKLOAD, "utterances_per_ragged_batch": Bsz, "parallelism": f"utterance-dp{world}"},
+                "planned_audio_seconds": round(audio_tot, 2), "planned_utterances": int(nutt),
+                "stand_in_wall_max_s": wall_max, "per_rank": per_rank, "comm": comm,
+                "self_launched": bool(os.environ.get("SS_BENCH_SELF_LAUNCHED"))}
+        if os.environ.get("SS_BENCH_DRY_DETAIL") == "1":
+            emit_result(full)                   # tests: the sidecar path of the real run
+        else:
+            _emit(compact_line(full))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -622,9 +755,12 @@ def main():
     ap.add_argument("--steps", type=int, default=16, help="timed steps per GPU (one step = one ragged batch of --batch utterances)")
     ap.add_argument("--warmup", type=int, default=3, help="untimed warm-up steps per GPU before the timed region")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-bf16x3-line", action="store_true", help="skip the optional second line (same batches, split-bf16 vocoder convs)")
+    ap.add_argument("--bf16x3-line", action="store_true", help="also run the optional split-bf16 vocoder-conv leg (same batches; never the headline)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the dominant kernel with HIP events")
-    ap.add_argument("--no-bracket-ab", action="store_true", help="skip the event-bracket on / off A/B of the timed region (five more region passes)")
+    ap.add_argument("--bracket-ab", action="store_true", help="also run the event-bracket on / off A/B of the timed region (five more region passes)")
+    ap.add_argument("--full", action="store_true",
+                    help="every optional leg at its long form (bracket A/B, bf16x3, 8-stream batch-1 pass, launch-per-op latency A/B, streaming: three "
+                         "agent configurations + CPU leg + long-prefix sweep); the default keeps the command under about a minute")
     ap.add_argument("--no-multilingual", action="store_true", help="skip the configs[4] sub-object (fr/es/de weight sets resident together)")
     ap.add_argument("--no-streaming-line", action="store_true", help="skip the configs[2] sub-object (320-ms agent policy() loop + its CPU baseline)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
@@ -648,6 +784,11 @@ def main():
     ap.add_argument("--rccl-probe", action="store_true", help="internal: world-of-one RCCL initialisation + the DP collectives, one JSON object")
     ap.add_argument("--no-rccl-probe", action="store_true", help="skip the RCCL probe of the N = 1 line")
     args = ap.parse_args()
+    if args.full:
+        args.bracket_ab = args.bf16x3_line = True
+    args.no_bracket_ab, args.no_bf16x3_line = not args.bracket_ab, not args.bf16x3_line
+    t_process = time.perf_counter()
+    legs = {}                                  # seconds per leg of this command (sidecar)
     if args.rccl_probe:
         _claim_stdout()
         return rccl_probe_main()
@@ -690,6 +831,7 @@ def main():
     model = HipModel(sd, cfg, device=dev)
     voc = HipVocoder(vsd, vcfg, device=dev)
     lib = L.load()
+    legs["setup_weights_and_contexts"] = round(time.perf_counter() - t_process, 2)
     if args.mode == "streaming":
         return streaming_mode(args, model, voc, lib, cfg, sd, vsd, vcfg)
 
@@ -746,7 +888,7 @@ def main():
     single_rtfx = sum(mine[i].seconds for i in lat_idx) / (single_ms * 1e-3 * nlat)
     pmt_after = int(getattr(model, "persistent_mt", 0))      # 0 if the persistent step timed out and the context fell back
     single_ms_lpo = None
-    if not args.no_latency_pass and hasattr(model, "set_persistent_mt_step"):
+    if args.full and not args.no_latency_pass and hasattr(model, "set_persistent_mt_step"):
         model.set_persistent_mt_step(0)
         run_utterance(model, voc, pcms[lat_idx[0]], mine[lat_idx[0]])
         torch.cuda.synchronize()
@@ -761,6 +903,8 @@ def main():
     # S concurrent utterance streams: worker threads (ctypes releases the GIL inside the C ABI),
     # each with its own HIP stream and its own scratch/KV-cache context over the shared weights
     S = max(1, args.streams)
+    legs["warmups_and_latency_pass"] = round(time.perf_counter() - t_process - legs["setup_weights_and_contexts"], 2)
+    t_leg = time.perf_counter()
     import threading
     hbm_free0, hbm_total = torch.cuda.mem_get_info(dev)     # before any scratch context has grown (weights + the packed PCM are resident)
     ctxs = [(model, voc)] + [(model.new_context(), voc.new_context()) for _ in range(S - 1)]
@@ -840,6 +984,8 @@ def main():
         dist.barrier()
     wall = time.perf_counter() - t0
     t1_mono_ns = time.monotonic_ns()
+    legs["context_warmups_and_timed_region"] = round(time.perf_counter() - t_leg, 2)
+    t_leg = time.perf_counter()
     lib.ss_prof_enable(0)
     if errors:
         raise errors[0]
@@ -1005,6 +1151,9 @@ def main():
     elif roofline:
         roofline["measured_on"] = "the timed region itself (one stream); HIP events on the launch stream around every launch"
 
+    legs["one_stream_replay_for_the_roofline"] = round(time.perf_counter() - t_leg, 2)
+    t_leg = time.perf_counter()
+
     # Optional SECOND line, never the headline (`value` above is the exact-f32 path): the same timed batches on the same S
     # streams with the C >= 64 vocoder convs contracted by three bf16 MFMAs per k-slice on operands split into
     # bf16(x) + bf16(x - bf16(x)) (ss_vocoder_set_bf16x3; f32 accumulation, everything else -- every argmax stage, the
@@ -1062,34 +1211,42 @@ def main():
     # Sustained figure inside the driver's own line (the timed region is ~1 s): the same region repeated until >= 100
     # more steps have run, one wall clock around all of them (untimed for `value`).
     soak = None
-    if world == 1 and Bsz > 1 and S > 1 and work and not args.no_soak:
-        reps = max(1, -(-100 // len(work)))
-        dts = [region_pass() for _ in range(reps)]
-        soak = {"steps": reps * len(work), "value": round(reps * audio / sum(dts), 2), "unit": "x real-time", "ms_per_step": round(1e3 * sum(dts) / (reps * len(work)), 3),
-                "utterances": int(reps * nutt), "gpu_seconds": round(sum(dts), 3), "per_pass_value": [round(audio / d, 1) for d in dts],
-                "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),
-                "note": f"the timed region's {len(work)} batches x {reps} passes on the same {S} streams right after the timed region"}
+    try:
+        if world == 1 and Bsz > 1 and S > 1 and work and not args.no_soak:
+            reps = max(1, -(-(100 if args.full else 48) // len(work)))
+            dts = [region_pass() for _ in range(reps)]
+            soak = {"steps": reps * len(work), "value": round(reps * audio / sum(dts), 2), "unit": "x real-time", "ms_per_step": round(1e3 * sum(dts) / (reps * len(work)), 3),
+                    "utterances": int(reps * nutt), "gpu_seconds": round(sum(dts), 3), "per_pass_value": [round(audio / d, 1) for d in dts],
+                    "stream_k_spin_timeouts": int(lib.ss_debug_sk_errors()),
+                    "note": f"the timed region's {len(work)} batches x {reps} passes on the same {S} streams right after the timed region"}
+    except Exception as e:  # noqa: BLE001  (an optional leg never costs the line)
+        soak = {"value": None, "skipped": f"soak: {type(e).__name__}: {e}"[:200]}
 
+    legs["bracket_ab_and_soak"] = round(time.perf_counter() - t_leg, 2)
+    t_leg = time.perf_counter()
     bf16x3_line = None
-    if world == 1 and Bsz > 1 and work and not args.no_bf16x3_line:
-        wav_f32 = [w.clone() for w in run_batch(model, voc, work[0][1], work[0][0])[0]]
-        for _, v in ctxs:
-            v.set_bf16x3(True)
-        try:
-            wav_x3 = run_batch(model, voc, work[0][1], work[0][0])[0]
-            num = sum(float(((a - b).double() ** 2).sum()) for a, b in zip(wav_x3, wav_f32))
-            den = sum(float((b.double() ** 2).sum()) for b in wav_f32)
-            n_s = sum(b.numel() for b in wav_f32)
-            region_pass()                                   # warm (first launches of the bf16 kernels on every context)
-            dt3 = min(region_pass(), region_pass())
-        finally:
+    try:
+        if world == 1 and Bsz > 1 and work and not args.no_bf16x3_line:
+            wav_f32 = [w.clone() for w in run_batch(model, voc, work[0][1], work[0][0])[0]]
             for _, v in ctxs:
-                v.set_bf16x3(False)
-        bf16x3_line = {"value": round(audio / dt3, 2), "unit": "x real-time (audio s / wall s)", "utterances_per_sec": round(nutt / dt3, 3),
-                       "ms_per_step": round(1e3 * dt3 / max(1, len(work)), 3), "dtype": "bf16x3 in the C >= 64 vocoder convs, f32 everywhere else",
-                       "wav_rms_vs_f32_path": round((num / max(n_s, 1)) ** 0.5, 9), "wav_rel_rms_vs_f32_path": round((num / max(den, 1e-30)) ** 0.5, 9),
-                       "note": "optional second line, NOT the headline: same timed batches and streams, best of two passes after one warm "
-                               "pass; durations and unit ids are identical by construction (only the vocoder's generator convs change)"}
+                v.set_bf16x3(True)
+            try:
+                wav_x3 = run_batch(model, voc, work[0][1], work[0][0])[0]
+                num = sum(float(((a - b).double() ** 2).sum()) for a, b in zip(wav_x3, wav_f32))
+                den = sum(float((b.double() ** 2).sum()) for b in wav_f32)
+                n_s = sum(b.numel() for b in wav_f32)
+                region_pass()                                   # warm (first launches of the bf16 kernels on every context)
+                dt3 = min(region_pass(), region_pass())
+            finally:
+                for _, v in ctxs:
+                    v.set_bf16x3(False)
+            bf16x3_line = {"value": round(audio / dt3, 2), "unit": "x real-time (audio s / wall s)", "utterances_per_sec": round(nutt / dt3, 3),
+                           "ms_per_step": round(1e3 * dt3 / max(1, len(work)), 3), "dtype": "bf16x3 in the C >= 64 vocoder convs, f32 everywhere else",
+                           "wav_rms_vs_f32_path": round((num / max(n_s, 1)) ** 0.5, 9), "wav_rel_rms_vs_f32_path": round((num / max(den, 1e-30)) ** 0.5, 9),
+                           "note": "optional second line, NOT the headline: same timed batches and streams, best of two passes after one warm "
+                                   "pass; durations and unit ids are identical by construction (only the vocoder's generator convs change)"}
+    except Exception as e:  # noqa: BLE001  (an optional leg never costs the line)
+        bf16x3_line = {"value": None, "skipped": f"bf16x3: {type(e).__name__}: {e}"[:200]}
 
     # BASELINE.json configs[4]: fr-en + es-en + de-en weight sets resident together (3 x (model + vocoder)), the SAME timed
     # batches dealt round-robin over the languages inside the same S-stream region (untimed for `value`); parity of exactly
@@ -1109,50 +1266,56 @@ def main():
     want_ml = world == 1 and Bsz > 1 and work and not args.no_multilingual
     if want_ml and not lanes:
         multilingual = {"value": None, "skipped": f"{ml_extra} more scratch contexts of {hbm['scratch_per_context_gb']} GB do not fit in the free HBM"}
-    if want_ml and lanes:
-        golden = os.path.join(ROOT, "tests", "golden")
-        order = ("fr", "es", "de")
-        per_lang = {"fr": {wi: ctxs[wi] for wi in range(S) if wi % lanes == 0}}
-        weights_mb = 4e-6 * (model.blob.numel() + voc.blob.numel())
-        for li, (seed, lang) in enumerate(((1, "es"), (2, "de")), start=1):
-            g = np.load(os.path.join(golden, f"gcmvn_{lang}-en.npz"))      # configs/{es,de}-en/gcmvn.npz of the reference
-            m = HipModel(synth.make_model_state_dict(seed, cfg), cfg, device=dev, cmvn_mean=g["mean"], cmvn_std=g["std"])
-            v = HipVocoder(synth.make_vocoder_state_dict(seed, vcfg), vcfg, device=dev)
-            weights_mb += 4e-6 * (m.blob.numel() + v.blob.numel())
-            mine_wi = [wi for wi in range(S) if wi % lanes == li % lanes]
-            per_lang[lang] = {wi: ((m, v) if k == 0 else (m.new_context(), v.new_context())) for k, wi in enumerate(mine_wi)}
-        big = max(work, key=lambda w: w[1].numel())
-        # the workload pins the MT length by max_new_tokens; a random es/de model may emit </s> earlier than the forced
-        # position, which run_batch reports -- min_len pins it (ss_batch_mt_greedy bans </s> before min_len)
-        for lang in order[1:]:
-            for wi, (m, v) in per_lang[lang].items():
-                with torch.cuda.stream(streams[wi]):
-                    run_batch(m, v, big[1], big[0])
-        torch.cuda.synchronize()
-        pick = lambda wi, i: per_lang[order[i % 3]][wi]   # noqa: E731   (lanes = 3: worker wi only draws items i with i % 3 == wi % 3)
-        region_pass(pick, lanes)                           # warm pass over every (language, stream) context
-        dt_ml = min(region_pass(pick, lanes), region_pass(pick, lanes))
-        dt_1 = min(region_pass(None, lanes), region_pass(None, lanes))   # the single-language set through the same queues, same moment
-        multilingual = {"value": round(audio / dt_ml, 2), "unit": "x real-time (audio s / wall s)", "utterances_per_sec": round(nutt / dt_ml, 3),
-                        "ms_per_step": round(1e3 * dt_ml / max(1, len(work)), 3), "languages": list(order),
-                        "weights_mb": round(weights_mb, 1), "contexts": sum(len(x) for x in per_lang.values()),
-                        "streams_per_language": {lang: len(per_lang[lang]) for lang in order},
-                        "single_language_same_method": {"value": round(audio / dt_1, 2), "ms_per_step": round(1e3 * dt_1 / max(1, len(work)), 3)},
-                        "multilingual_over_single": round(dt_1 / dt_ml, 4),
-                        "note": "BASELINE.json configs[4]: three weight sets (seeds 0/1/2 of the same architecture, es/de with the reference's "
-                                "gcmvn statistics) resident together; batch i is of language i % 3" +
-                                (" and runs on one of that language's streams (stream wi serves language wi % 3: a scratch context per "
-                                 "(language, stream) pair for all 3 x S pairs does not fit in HBM at this pack size)" if lanes == 3 else
-                                 " on whichever stream takes it (a scratch context per (language, stream) pair)") +
-                                "; best of two passes after one warm pass, next to the single-language set timed through the same queues"}
-        for lang in order[1:]:
-            del per_lang[lang]
-        torch.cuda.empty_cache()
+    try:
+        if want_ml and lanes:
+            golden = os.path.join(ROOT, "tests", "golden")
+            order = ("fr", "es", "de")
+            per_lang = {"fr": {wi: ctxs[wi] for wi in range(S) if wi % lanes == 0}}
+            weights_mb = 4e-6 * (model.blob.numel() + voc.blob.numel())
+            for li, (seed, lang) in enumerate(((1, "es"), (2, "de")), start=1):
+                g = np.load(os.path.join(golden, f"gcmvn_{lang}-en.npz"))      # configs/{es,de}-en/gcmvn.npz of the reference
+                m = HipModel(synth.make_model_state_dict(seed, cfg), cfg, device=dev, cmvn_mean=g["mean"], cmvn_std=g["std"])
+                v = HipVocoder(synth.make_vocoder_state_dict(seed, vcfg), vcfg, device=dev)
+                weights_mb += 4e-6 * (m.blob.numel() + v.blob.numel())
+                mine_wi = [wi for wi in range(S) if wi % lanes == li % lanes]
+                per_lang[lang] = {wi: ((m, v) if k == 0 else (m.new_context(), v.new_context())) for k, wi in enumerate(mine_wi)}
+            big = max(work, key=lambda w: w[1].numel())
+            # the workload pins the MT length by max_new_tokens; a random es/de model may emit </s> earlier than the forced
+            # position, which run_batch reports -- min_len pins it (ss_batch_mt_greedy bans </s> before min_len)
+            for lang in order[1:]:
+                for wi, (m, v) in per_lang[lang].items():
+                    with torch.cuda.stream(streams[wi]):
+                        run_batch(m, v, big[1], big[0])
+            torch.cuda.synchronize()
+            pick = lambda wi, i: per_lang[order[i % 3]][wi]   # noqa: E731   (lanes = 3: worker wi only draws items i with i % 3 == wi % 3)
+            region_pass(pick, lanes)                           # warm pass over every (language, stream) context
+            n_best = 2 if args.full else 1
+            dt_ml = min(region_pass(pick, lanes) for _ in range(n_best))
+            dt_1 = min(region_pass(None, lanes) for _ in range(n_best))     # the single-language set through the same queues, same moment
+            multilingual = {"value": round(audio / dt_ml, 2), "unit": "x real-time (audio s / wall s)", "utterances_per_sec": round(nutt / dt_ml, 3),
+                            "ms_per_step": round(1e3 * dt_ml / max(1, len(work)), 3), "languages": list(order),
+                            "weights_mb": round(weights_mb, 1), "contexts": sum(len(x) for x in per_lang.values()),
+                            "streams_per_language": {lang: len(per_lang[lang]) for lang in order},
+                            "single_language_same_method": {"value": round(audio / dt_1, 2), "ms_per_step": round(1e3 * dt_1 / max(1, len(work)), 3)},
+                            "multilingual_over_single": round(dt_1 / dt_ml, 4),
+                            "note": "BASELINE.json configs[4]: three weight sets (seeds 0/1/2 of the same architecture, es/de with the reference's "
+                                    "gcmvn statistics) resident together; batch i is of language i % 3" +
+                                    (" and runs on one of that language's streams (stream wi serves language wi % 3: a scratch context per "
+                                     "(language, stream) pair for all 3 x S pairs does not fit in HBM at this pack size)" if lanes == 3 else
+                                     " on whichever stream takes it (a scratch context per (language, stream) pair)") +
+                                    f"; best of {n_best} pass(es) after one warm pass, next to the single-language set timed through the same queues"}
+            for lang in order[1:]:
+                del per_lang[lang]
+            torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001  (an optional leg never costs the line)
+        multilingual = {"value": None, "skipped": f"multilingual: {type(e).__name__}: {e}"[:200]}
 
     # Strict configs[1] form: ONE utterance per call (the single-utterance entry points, no ragged packs),
     # 8 utterances in flight on 8 streams (untimed for `value`).
+    legs["bf16x3_and_multilingual"] = round(time.perf_counter() - t_leg, 2)
+    t_leg = time.perf_counter()
     b1_rtfx = b1_ups = None
-    if rank == 0 and not args.no_latency_pass:
+    if world == 1 and args.full and not args.no_latency_pass:
         S1, n1 = 8, min(Kpool, 64)
         sel = list(range(Wn, Wn + Kpool))[::max(1, Kpool // n1)][:n1]
         ctx1 = ctxs + [(model.new_context(), voc.new_context()) for _ in range(max(0, S1 - len(ctxs)))]
@@ -1189,17 +1352,14 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "real-time factor (RTFx = audio seconds / wall seconds) + utterances/sec, offline S2ST fr-en",
+            "metric": METRIC,
             "value": round(audio / wall, 2), "unit": "x real-time",
             "utterances_per_sec": round(nutt / wall, 3),
             "n_gpus": world, "steps": Ksteps, "warmup": Wsteps, "ms_per_step": round(1e3 * wall / max(1, steps_here), 3),
             "steps_per_gpu": steps_here,
             "utterances_per_step": Bsz, "ms_per_utterance": round(1e3 * wall / max(1, K), 4),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "offline S2ST fr-en, B=1 semantics per utterance (ragged no-padding batches), synthetic CVSS-C-shaped utterances "
-                                   "(LogNormal(ln 4.5 s, 0.45) clipped to [1,15] s, seed 1234), full "
-                                   "fbank+encoder+CTC+AR-MT+T2U+NAR-unit+vocoder HIP path, random-init weights "
-                                   "of the streamspeech.offline.fr-en architecture",
+            "config": {"workload": WORKLOAD,
                        "audio_seconds_per_gpu": round(sum(mine[i].seconds for i in timed_ids), 2), "utterances_per_gpu": K,
                        "lengths_pinned": "data-dependent lengths are pinned by the workload (SURVEY.md §8d): MT search forced to "
                                          "N = ceil(3.5 d) subwords + </s> (checked per batch inside the timed step), collapsed unit "
@@ -1231,23 +1391,36 @@ def main():
             "self_launched": bool(os.environ.get("SS_BENCH_SELF_LAUNCHED")),
             "timed_region_monotonic_ns": [t0_mono_ns, t1_mono_ns],   # tools/trace_gaps.py: window of a rocprofv3 kernel trace
         }
+        legs["pack_invariance_census_rccl_probe"] = round(time.perf_counter() - t_leg, 2)
+        t_leg = time.perf_counter()
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, workload.make_utterances(Wn + Kpool + 1)[Wn:], hip_model=model, dev=dev)
+            out["cpu_baseline"] = cpu_baseline(sd, vsd, cfg, vcfg, workload.make_utterances(Wn + Kpool + 1)[Wn:], hip_model=model, dev=dev,
+                                               reps=5 if args.full else 3, warm=2 if args.full else 1, budget_s=30.0 if args.full else 20.0)
             out["near_tie_rows"] = out["cpu_baseline"]["oracle_check"]["near_tie_rows"]
         else:
             out["cpu_baseline"] = None
             out["near_tie_rows"] = None
+        legs["cpu_baseline_and_oracle_check"] = round(time.perf_counter() - t_leg, 2)
+        t_leg = time.perf_counter()
+        out["streaming_320ms"] = None
         if world == 1 and not args.no_streaming_line:
-            # BASELINE.json configs[2] inside the driver's line: the agent's policy() loop on 320-ms segments (incremental state
-            # and the reference's full recompute), its CPU baseline on the same utterances, and the long-source sweep
-            st = streaming_measure(model, voc, lib, cfg, 320, args.utterances, cpu_sd=None if args.no_cpu_baseline else (sd, vsd, vcfg),
-                                   cpu_utts=3, long_seconds=(15, 30))
-            for k in ("metric", "mode", "n_gpus", "dtype", "data", "higher_is_better"):
-                st.pop(k, None)
-            out["streaming_320ms"] = st
-        else:
-            out["streaming_320ms"] = None
-        _emit(out)
+            # BASELINE.json configs[2] inside the driver's line: the agent's policy() loop on 320-ms segments with the incremental state
+            # (--full: also the reference's full recompute, the launch-per-op A/B, the CPU baseline on the same utterances and the
+            # long-source sweep -- `bench.py --mode streaming` prints those as its own line).  A failing optional leg never costs the line.
+            try:
+                st = streaming_measure(model, voc, lib, cfg, 320, args.utterances if args.full else min(args.utterances, 6),
+                                       cpu_sd=(sd, vsd, vcfg) if (args.full and not args.no_cpu_baseline) else None,
+                                       cpu_utts=3, long_seconds=(15, 30) if args.full else (),
+                                       configurations=None if args.full else ("incremental",))
+                for k in ("metric", "mode", "n_gpus", "dtype", "data", "higher_is_better"):
+                    st.pop(k, None)
+                out["streaming_320ms"] = st
+            except Exception as e:  # noqa: BLE001
+                out["streaming_320ms"] = {"value": None, "skipped": f"{type(e).__name__}: {e}"[:200]}
+        legs["streaming_320ms"] = round(time.perf_counter() - t_leg, 2)
+        legs["total_since_argument_parsing"] = round(time.perf_counter() - t_process, 2)
+        out["leg_seconds"] = legs
+        emit_result(out)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -120,7 +120,8 @@ def test_bench_gpus_2_as_typed_self_launches_its_ranks():
     assert out["n_gpus"] == 2 and out["self_launched"] and out["dry_plan"]
     assert [p["rank"] for p in out["per_rank"]] == [0, 1] and all(p["utterances"] == 4 * 64 for p in out["per_rank"])
     assert out["stand_in_wall_max_s"] == 1.001                    # MAX over ranks picked rank 1's
-    assert out["planned_utterances"] == 512 and out["comm"]["results_ok"] and out["comm"]["world"] == 2
+    assert out["planned_utterances"] == 512 and out["rccl"]["results_ok"] and out["rccl"]["world"] == 2   # the collectives' summary (gloo here)
+    assert len(lines[0]) < 6000
     # strong scaling: the one fixed set splits over the ranks
     r = _run_cli([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--batch", "64", "--dry-plan", "--scaling", "strong"], env, 240)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -159,8 +160,8 @@ def test_bench_gpus_8_dry_plan_balances_audio_and_prints_one_line():
     assert [p["rank"] for p in out["per_rank"]] == list(range(8)) and all(p["utterances"] == 20 * 128 for p in out["per_rank"])
     mean = sum(audio) / 8
     assert max(abs(a - mean) for a in audio) / mean < 0.01, audio
-    assert all("numa_node" in p and p["pinned_to_numa_node"] is False for p in out["per_rank"])     # dry plan never pins
-    assert out["comm"]["results_ok"] and out["comm"]["world"] == 8
+    assert out["rccl"]["results_ok"] and out["rccl"]["world"] == 8 and len(lines[0]) < 6000
+    # (per-rank host placement and the collectives' timings are sidecar material: tests/test_bench_line_cpu.py reads them there)
 
 
 def test_numa_pinning_picks_the_gpus_local_cpus(tmp_path):
