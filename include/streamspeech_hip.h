@@ -274,7 +274,7 @@ int ss_op_ffn_fused(void* stream, const float* dX, int ldx, float* dY, int ldy, 
                     const float* dW1, const float* db1, const float* dW2, const float* db2, float alpha,
                     const float* ln2_g, const float* ln2_b, int M, int D, int F);
 /* A/B + test hook of the same kernel: grid > 0 fixes its workgroup count (0: heuristic); row_tiles_per_wave 1..4 forces 16- .. 64-row
- * tiles (0: back to the default: 48 rows, or the pack-invariant form's own choice); enable 0 / 1 switches its use by ss_batch_encoder_forward off / on (-1: keep). */
+ * tiles (0: back to the process default: SS_FFN_WM if set, else 48 rows / the pack-invariant form's own choice; -1: keep); enable 0 / 1 switches its use by ss_batch_encoder_forward off / on (-1: keep). */
 int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable);
 /* A/B + test hook of the row-tile linear kernel (csrc/rtlin.hip: every K = 256 linear of more than 192 rows that goes through
  * ss_op_conv_gemm / the model entry points): grid > 0 fixes its workgroup count (0: heuristic); enable 0 / 1 routes those linears

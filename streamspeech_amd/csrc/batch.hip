@@ -89,8 +89,9 @@ extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const 
     // macaron FFN: x += 0.5 * W2 SiLU(W1 LN(x)); packed batches: ONE launch (ffn.hip), the [rows, 2048] hidden tile stays on chip
     // (pack-invariant contexts: ALWAYS the fused launch in its whole-tile form -- the two-launch form sums the 2048 hidden terms in
     //  another order, and which of the two runs must not depend on the row count)
-    const bool fuse_ffn = (canon || (disp().ffn_fusion && M2 >= disp().ffn_min_rows)) && ffn_fused_eligible(d, f, ACT_SILU, M2, d, d) &&
+    const bool fuse_ffn = (canon || (disp().ffn_fusion && M2 >= disp().ffn_min_rows)) && ffn_fused_eligible(d, f, ACT_SILU, M2, d, d, canon) &&
                           e.ffn1_w1.b && e.ffn1_w2.b && e.ffn2_w1.b && e.ffn2_w2.b;
+    if (canon && !fuse_ffn) return SS_ERR_ARG;      // never switch FFN forms silently in a pack-invariant context (the two-launch form sums in another order)
     if (fuse_ffn) {
       RET(launch_ffn_fused(x, d, x, d, e.ffn1_ln.g, e.ffn1_ln.b, e.ffn1_w1.w, e.ffn1_w1.b, e.ffn1_w2.w, e.ffn1_w2.b, 0.5f, nullptr,
                            nullptr, M2, d, f, s, canon));

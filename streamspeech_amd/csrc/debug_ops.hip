@@ -82,7 +82,7 @@ extern "C" int ss_debug_rtlin(int grid, int enable) {
   return SS_OK;
 }
 extern "C" int ss_debug_ffn(int grid, int row_tiles_per_wave, int enable) {
-  if (grid < 0 || row_tiles_per_wave < 0 || row_tiles_per_wave > 4) return SS_ERR_ARG;
+  if (grid < 0 || row_tiles_per_wave < -1 || row_tiles_per_wave > 4) return SS_ERR_ARG;     // row tiles: 1..4 force, 0 process default, -1 keep
   ffn_fused_debug_grid(grid);
   ffn_fused_debug_rows(row_tiles_per_wave);
   if (enable >= 0) dispatch_edit([enable](Dispatch& d) { d.ffn_fusion = enable ? 1 : 0; });

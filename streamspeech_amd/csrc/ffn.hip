@@ -185,7 +185,9 @@ __global__ __launch_bounds__(256, WMT <= 2 ? 2 : 1) void ffn_fused_kernel(const 
         const int n0_next = (u + 1 < my_n ? n0 + FF_UN : n0);      // after the last unit: a harmless re-read
         xoff = xoff0 + u * p.zero;
         const f32x4 bias1 = *reinterpret_cast<const f32x4*>(p.b1 + n0 + 4 * g);
-        f32x4 h[WMT];
+        // GEMM1 is summed as every K = 256 linear of the pack-invariant routes (CANON_KBLOCK = 64, gemm.hpp): one chain per 4 k-groups,
+        // block sums added in ascending order (round 6; one chain over 256 sat 1.4x farther from float64 than torch's CPU sgemm)
+        f32x4 h[WMT], ht[WMT];
 #pragma unroll
         for (int i = 0; i < WMT; ++i) h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 xa[WMT];
@@ -209,8 +211,18 @@ __global__ __launch_bounds__(256, WMT <= 2 ? 2 : 1) void ffn_fused_kernel(const 
 #pragma unroll
             for (int i = 0; i < WMT; ++i) xa[i] = xb[i];
           }
+          if ((s & 3) == 3) {
+#pragma unroll
+            for (int i = 0; i < WMT; ++i) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ht[i][e] = s == 3 ? h[i][e] : ht[i][e] + h[i][e];
+              h[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
           FF_STEP_FENCE;
         }
+#pragma unroll
+        for (int i = 0; i < WMT; ++i) h[i] = ht[i];
         // bias + SiLU in the accumulator layout (lane (r, g), register e = hidden column n0 + 4 g + e of row 16 i + r)
 #pragma unroll
         for (int i = 0; i < WMT; ++i)
@@ -392,8 +404,16 @@ __global__ __launch_bounds__(256, WMT <= 2 ? 2 : 1) void ffn_fused_kernel(const 
 void ffn_fused_debug_grid(int g) { dispatch_edit([g](Dispatch& d) { d.ffn_force_g = g; }); }   // tests / tuning: fixed grid
 
 // (16-row MFMA tiles per wave: Dispatch::ffn_wm, SS_FFN_WM; the pack-invariant form picks its own unless forced)
+// wm 1..4: force that tile height; 0: back to the process default (SS_FFN_WM if set, else the heuristic); < 0: keep (0 used
+// to clobber an SS_FFN_WM override with the built-in default)
 void ffn_fused_debug_rows(int wm) {
-  dispatch_edit([wm](Dispatch& d) { if (wm >= 1 && wm <= 4) { d.ffn_wm = wm; d.ffn_wm_forced = 1; } else if (wm == 0) { d.ffn_wm = 3; d.ffn_wm_forced = 0; } });
+  if (wm < 0) return;
+  static const int env_wm = getenv("SS_FFN_WM") ? atoi(getenv("SS_FFN_WM")) : 0;
+  dispatch_edit([wm](Dispatch& d) {
+    if (wm >= 1 && wm <= 4) { d.ffn_wm = wm; d.ffn_wm_forced = 1; }
+    else if (env_wm >= 1 && env_wm <= 4) { d.ffn_wm = env_wm; d.ffn_wm_forced = 1; }
+    else { d.ffn_wm = 3; d.ffn_wm_forced = 0; }
+  });
 }
 
 // relative cost of a row at tile height 16 h (h = 1..4), SS_FFN_COST="c1,c2,c3,c4" overrides (tuning)
@@ -405,9 +425,12 @@ static const FfnCost g_ffn_cost = [] {
   return k;
 }();
 
-bool ffn_fused_eligible(int D, int F, int act, int M, int ldx, int ldy) {
+// canon: the whole-tile form shares no tile between workgroups -- it needs no arrival counters, hence no bound on the row count.
+// Otherwise the per-tile counters bound it: FF_MAX_TILES tiles at the LOWEST tile height a launch may take (16 rows: ss_debug_ffn /
+// SS_FFN_WM allow it on this path; ADVICE r5: the bound used to assume 48-row tiles).
+bool ffn_fused_eligible(int D, int F, int act, int M, int ldx, int ldy, bool canon) {
   return D == FF_D && F >= 64 && F % 64 == 0 && F <= 8192 && act == ACT_SILU && M > 0 && (ldx & 3) == 0 && (ldy & 3) == 0 &&
-         (M + 47) / 48 <= FF_MAX_TILES;
+         (canon || (M + 15) / 16 <= FF_MAX_TILES);
 }
 
 template <int WMT>
@@ -420,6 +443,7 @@ static int launch_ffn_t(FfnKArgs a, int D, const float* ln2_g, hipStream_t strea
   if (rc != SS_OK) return rc;
   const int tiles = cdiv(a.M, BM);
   const long long U = (long long)tiles * (a.F / FF_UN);
+  if (!a.canon && tiles > FF_MAX_TILES) return SS_ERR_ARG;       // per-tile arrival counters (sync3) of this context
   if (a.canon) {
     // pack-invariant form: whole tiles per workgroup; two resident workgroups per CU at 16- / 32-row tiles (128 accumulator registers)
     long long G = disp().ffn_force_g > 0 ? disp().ffn_force_g : (long long)st->cus * (WMT <= 2 ? 2 : 1);
@@ -460,7 +484,7 @@ static int launch_ffn_t(FfnKArgs a, int D, const float* ln2_g, hipStream_t strea
 int launch_ffn_fused(const float* X, int ldx, float* Y, int ldy, const float* ln_g, const float* ln_b, const float* W1,
                      const float* b1, const float* W2, const float* b2, float alpha, const float* ln2_g, const float* ln2_b,
                      int M, int D, int F, hipStream_t stream, int canon) {
-  if (!ffn_fused_eligible(D, F, ACT_SILU, M, ldx, ldy) || !X || !Y || !ln_g || !ln_b || !W1 || !b1 || !W2 || !b2) return SS_ERR_ARG;
+  if (!ffn_fused_eligible(D, F, ACT_SILU, M, ldx, ldy, canon != 0) || !X || !Y || !ln_g || !ln_b || !W1 || !b1 || !W2 || !b2) return SS_ERR_ARG;
   FfnKArgs a;
   a.X = X; a.ldx = ldx; a.Y = Y; a.ldy = ldy; a.ln_g = ln_g; a.ln_b = ln_b; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
   a.ln2_g = ln2_g; a.ln2_b = ln2_g ? ln2_b : nullptr; a.alpha = alpha; a.M = M; a.F = F; a.canon = canon ? 1 : 0;

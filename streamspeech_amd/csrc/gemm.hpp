@@ -59,14 +59,20 @@ struct GemmArgs {
   int same_rows = 0;
   int x3 = 0;                 // 1: split-bf16 (3 x bf16 MFMA) contraction where the kernel has one (conv_sk2 only; opt-in, see ss_vocoder_set_bf16x3)
   // Pack-invariant arithmetic: the bits of output row m must be a function of row m's operands alone -- not of
-  // the row count M, the grid, or where stream-K cut the k-range.  CANON_SEQ: ONE accumulator chain per output element over k
-  // ascending (16-wide slabs, MFMA e contracts k = {e, 4+e, 8+e, 12+e}): conv_gemm_kernel without split-K, rt_linear, conv_sk2 cut
-  // on whole tiles -- these three give the same bits (tests/test_pack_invariance_gpu.py), so the choice among them may depend on M.
-  // CANON_SMALLM: the no-LDS small-M kernel with a split-K form fixed by (N, K) alone (the lock-step MT decode rows).
+  // the row count M, the grid, or where stream-K cut the k-range.  CANON_SEQ: the k walk (16-wide slabs ascending, MFMA e of a slab
+  // contracts k = {e, 4+e, 8+e, 12+e}) is cut into blocks of CANON_KBLOCK = 64; inside a block ONE accumulator chain, the block sums
+  // are added in ascending order into a running total (first block: the total IS the block sum).  conv_gemm_kernel<.., BLK = true>
+  // (no split-K), rt_linear (K = 256) and rt_linear_kb (K = 512 ...) implement exactly this -- the same bits
+  // (tests/test_pack_invariance_gpu.py) -- so the choice among them may depend on M.  Rounds 4-5 ran ONE chain over all of K: at
+  // K = 256 that is 1.35-1.5x, at K = 2048 2.8x farther from float64 than torch's CPU sgemm on the GPU box's host (VERDICT r5 #2;
+  // profiles/r06_op_accuracy_*.json); 64-blocks sit at ~0.7x of it.
+  // CANON_SMALLM: the no-LDS small-M kernel with a split-K form fixed by (N, K) alone (the lock-step MT decode rows; two
+  // interleaved chains per wave, flushed every 64 k like the above).
   // 0: the launcher takes the calling thread's CanonScope mode (none outside a scope = fastest kernel for the shape).
   int canon = 0;
 };
 constexpr int CANON_NONE = 0, CANON_SEQ = 1, CANON_SMALLM = 2;
+constexpr int CANON_KBLOCK = 64;      // CANON_SEQ since round 6: the chain is cut every 64 k of the walk, block sums added in ascending order
 // RAII: launches of the calling thread whose GemmArgs::canon is 0 take `mode` until the scope ends (the ss_batch_* entry points
 // open one: a packed utterance gets the arithmetic it would get alone or in any other pack)
 struct CanonScope {
@@ -79,7 +85,7 @@ void canon_debug_set(int mode);        // test hook: the calling thread's mode o
 
 // Optional per-launch timing with HIP events recorded on the launch stream (bench.py roofline
 // leg).  Tile-config classes: see kTileNames in gemm.hip.
-constexpr int kNumTileCfg = 31;
+constexpr int kNumTileCfg = 32;
 void prof_enable(int cls_mask);   // bit i set -> bracket launches of tile config i with events; 0 = off
 void prof_reset();
 int prof_read(int cls, double* ms_total, double* flops_total, long long* launches, double* bytes_total = nullptr);  // synchronises
@@ -204,18 +210,23 @@ bool rtlin_eligible(const GemmArgs& a);
 bool rtlin_shape_ok(const GemmArgs& a);   // what the kernel can compute at all (rtlin_eligible = this + "worth it at this row count")
 int launch_rtlin(const GemmArgs& a, hipStream_t stream);
 void rtlin_debug(int grid, int enable);   // tests / A-B: fixed workgroup count (0 = heuristic); enable 0 / 1 (-1: keep)
+// The same structure for K = 512 ... 8192 (multiples of 256), N % 256 == 0: the row tile goes through LDS one 256-wide k-block at a
+// time, block sums are added in ascending order (the CANON_KBLOCK summation: same bits as conv_gemm_kernel<.., BLK = true>).
+bool rtlin_kb_shape_ok(const GemmArgs& a);
+bool rtlin_kb_eligible(const GemmArgs& a);
+int launch_rtlin_kb(const GemmArgs& a, hipStream_t stream);
 
 // Fused Conformer feed-forward module (ffn.hip): Y = X + alpha * (W2 . SiLU(W1 . LayerNorm(X) + b1) + b2), optionally followed by
 // LayerNorm(ln2) over the result rows; one persistent launch, hidden activations stay in registers.  D = 256, F % 64 == 0.
 // Y may alias X (in place).
-bool ffn_fused_eligible(int D, int F, int act, int M, int ldx, int ldy);
+bool ffn_fused_eligible(int D, int F, int act, int M, int ldx, int ldy, bool canon = false);
 int launch_ffn_fused(const float* X, int ldx, float* Y, int ldy, const float* ln_g, const float* ln_b, const float* W1,
                      const float* b1, const float* W2, const float* b2, float alpha, const float* ln2_g, const float* ln2_b,
                      int M, int D, int F, hipStream_t stream, int canon = 0);
 // canon != 0: every row tile is computed whole by ONE workgroup (wave w contracts hidden units [32 w, 32 w + 32) whatever M is),
 // so a row's bits do not depend on the row count / grid; the tile height is picked for the fewest rounds over the CUs.
 void ffn_fused_debug_grid(int g);    // tests / tuning: fixed workgroup count (0 = heuristic)
-void ffn_fused_debug_rows(int wm);   // tests / tuning: 16-row MFMA tiles per wave (3: 48-row tiles, 4: 64-row tiles)
+void ffn_fused_debug_rows(int wm);   // tests / tuning: 16-row MFMA tiles per wave (1..4: force; 0: process default; < 0: keep)
 
 // True when launch_conv_gemm would route `a` to the decode GEMV (M <= 4 rows; the only form that honours ln_out).
 bool gemv_eligible(const GemmArgs& a);

@@ -607,7 +607,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
       MtStepArgs a;
       RET(mt_step_args(m, a, d_feats));
       a.tok = tok + first; a.feats = d_feats + (size_t)first * D; a.next = tok + first + 1;
-      a.pos0 = first; a.n_steps = n_steps; a.min_len = min_len; a.max_len = max_len;
+      a.pos0 = first; a.n_steps = n_steps; a.min_len = min_len; a.max_len = max_len; a.search = 1;
       RET(mt_inject(m, a, s));
       a.epoch = mt_next_epochs(m, n_steps);
       m->mt_last_stream = s;

@@ -159,7 +159,9 @@ __global__ __launch_bounds__(256) void mt_step_kernel(const MtStepArgs p) {
   // the prefix pass (launch-per-op, fed by ss_mt_greedy before this launch) may already have produced </s>: the search is over --
   // do not feed it and decode on until a later step happens to emit </s> again (~125 us per step on the streaming latency path,
   // and cache / feature rows past the end).  Uniform over workgroups: nobody waits for anybody.
-  if (p.pos0 > 0 && tk == p.eos) return;
+  // Only the search loop of ss_mt_greedy (p.search): a single step of ss_mt_append with the persistent step on computes what it is
+  // fed, </s> at position > 0 included, exactly like the launch-per-op form of the same call.
+  if (p.search && p.pos0 > 0 && tk == p.eos) return;
 #pragma unroll 1
   for (int it = 0; it < p.n_steps; ++it) {
   const unsigned epoch = p.epoch + (unsigned)it;

@@ -38,6 +38,8 @@ struct MtStepArgs {
   unsigned epoch;
   int Tp, pos0, V, pad, eos;
   int n_steps;             // decode steps of this launch (the loop ends early at </s>)
+  int search = 0;          // 1 (ss_mt_greedy after its prefix pass): a FED </s> at position > 0 means the search is already over -- decode nothing.
+                           // 0 (ss_mt_append's single step): compute what is fed, like the launch-per-op form of the same call
   int min_len, max_len;    // </s> is banned at positions < min_len and forced at positions >= max_len
   float emb_scale;
 };

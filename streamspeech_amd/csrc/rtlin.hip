@@ -60,7 +60,7 @@ struct RtArgs {
 }  // namespace
 
 template <bool GLU>
-__global__ __launch_bounds__(256, 3) void rt_linear_kernel(const RtArgs p) {
+__global__ __launch_bounds__(256, GLU ? 2 : 3) void rt_linear_kernel(const RtArgs p) {     // (GLU: two accumulator + two total sets -- 3 per CU would spill)
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256, 3) void rt_linear_kernel(const RtArgs p) {
         rr[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (!GLU && p.R) rr[i] = *reinterpret_cast<const f32x4*>(p.R + (size_t)min(m0 + i * 16 + r, p.M - 1) * p.ldr + oc);
       }
-      f32x4 acc[RT_WM], accg[GLU ? RT_WM : 1];
+      // CANON_KBLOCK = 64 (gemm.hpp): one chain per 4 slabs, block sums added in ascending order into tot / totg
+      f32x4 acc[RT_WM], accg[GLU ? RT_WM : 1], tot[RT_WM], totg[GLU ? RT_WM : 1];
 #pragma unroll
       for (int i = 0; i < RT_WM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
       if constexpr (GLU) {
@@ -200,7 +201,25 @@ __global__ __launch_bounds__(256, 3) void rt_linear_kernel(const RtArgs p) {
 #pragma unroll
           for (int i = 0; i < RT_WM; ++i) xa[i] = xb[i];
         }
+        if ((s & 3) == 3) {                            // end of a 64-wide k-block
+#pragma unroll
+          for (int i = 0; i < RT_WM; ++i) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tot[i][e] = s == 3 ? acc[i][e] : tot[i][e] + acc[i][e];
+            acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (GLU) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) totg[i][e] = s == 3 ? accg[i][e] : totg[i][e] + accg[i][e];
+              accg[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+        }
         RT_STEP_FENCE;
+      }
+#pragma unroll
+      for (int i = 0; i < RT_WM; ++i) {
+        acc[i] = tot[i];
+        if constexpr (GLU) accg[i] = totg[i];
       }
       // ---- epilogue of the unit: lane (r, g) holds output columns oc .. oc + 3 of rows m0 + 16 i + r ----
       if constexpr (GLU) {
@@ -236,6 +255,161 @@ __global__ __launch_bounds__(256, 3) void rt_linear_kernel(const RtArgs p) {
             for (int e = 0; e < 4; ++e) v[e] += rr[i][e];
           }
           if (m < p.M) *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + oc) = v;
+        }
+      }
+    }
+  }
+#endif
+}
+
+
+// ================================================================================================================================
+// K > 256 (round 6): the decoder-side linears of a packed batch -- T2U encoder / unit decoder QKV (512 -> 1536), attention outputs
+// and cross projections (512 -> 512 / 1024), FFN halves (512 -> 2048 with ReLU, 2048 -> 512 + residual) at 45-60 k rows
+// (researches/ctc_unity/modules/transformer_layer.py:388-551, fairseq/models/speech_to_speech/modules/ctc_decoder.py:11-18;
+// SURVEY.md §8a rows a11-a12).  Rounds 4-5 ran them on conv_sk2 cut on whole tiles: ONE accumulator chain over K <= 2048 (2.8x
+// farther from float64 than torch's blocked sgemm at K = 2048) at 3x the algorithmic HBM traffic (both operands
+// staged through LDS per 256 x 128 tile).  This kernel is the row-tile structure above with the row tile going through LDS one
+// 256-wide k-slice at a time, and the pack-invariant summation of round 6 (CANON_KBLOCK = 64: one chain inside a 64-wide block,
+// block sums added in ascending order -- bit-identical to conv_gemm_kernel<.., BLK = true> whatever the row count):
+//   * work unit = (48-row tile, column group of 4 waves x UW x 16 columns); the (tile, group) space is cut into equal contiguous
+//     ranges, one per workgroup; the groups of a tile are adjacent, so a tile's A rows are re-read from L2;
+//   * per k-slice the tile's [48 x 256] part goes once into LDS; each wave contracts its UW 16-column units against it
+//     (192 MFMAs per unit and slice, weight fragments L2 -> registers through the ring of 8), every 64 k the accumulator is
+//     added to the unit's running total (UW x 12 registers) and cleared;
+//   * epilogue per unit after the last block: bias / activation / alpha / residual as float4.
+// ================================================================================================================================
+namespace {
+struct RtKbArgs {
+  const float* X; int ldx;
+  const float* W; const float* bias;
+  const float* R; int ldr;
+  float* C; int ldc;
+  float alpha; int act;
+  int M, K, NCG, G;                            // rows, contraction length (multiple of 256), column groups per tile, workgroups
+  int zero;
+};
+}  // namespace
+
+template <int UW>
+__global__ __launch_bounds__(256, UW <= 4 ? 3 : 2) void rt_linear_kb_kernel(const RtKbArgs p) {
+#if __HIP_DEVICE_COMPILE__
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* xs = smem;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int w = blockIdx.x;
+  const int K = p.K, KB = K / RT_K;
+  const int tiles = (p.M + RT_BM - 1) / RT_BM;
+  const long long U = (long long)tiles * p.NCG;
+  const long long u0 = (long long)w * U / p.G, u1 = (long long)(w + 1) * U / p.G;
+  constexpr int CG = 4 * UW * 16;               // columns per group
+
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc((void*)p.W, 0, RT_NUM_RECORDS, 0x00020000);
+  const int vo = (r * K + 4 * g) * 4;
+  auto wload = [&](int n0, int kb, int f) -> f32x4 {      // fragment f (k-group) of block kb of the unit whose first weight row is n0
+    const int so = __builtin_amdgcn_readfirstlane((n0 * K + kb * RT_K + f * 16) * 4);
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsW, vo, so, 0);
+    return f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+  };
+  const int xoff0 = r * RT_XS + 4 * g;
+
+  for (long long unit = u0; unit < u1; ++unit) {
+    const int tile = (int)(unit / p.NCG), cg = (int)(unit - (long long)tile * p.NCG);
+    const int m0 = tile * RT_BM;
+    const int nw0 = cg * CG + wave * (UW * 16);              // this wave's first column of the group
+    f32x4 tot[UW][RT_WM];
+    f32x4 ring[RT_RING];
+#pragma unroll
+    for (int f = 0; f < RT_RING; ++f) ring[f] = wload(nw0, 0, f);
+
+    for (int kb = 0; kb < KB; ++kb) {
+      // ---- the tile's k-block into LDS (thread = row t / 4, 16-B chunks q, q + 4, ...) ----
+      __syncthreads();                                  // every wave is done reading the previous block
+      if (t < 4 * RT_BM) {
+        const int row = t >> 2, q = t & 3;
+        const int m = min(m0 + row, p.M - 1);           // clamped: rows >= M are computed on a copy, never stored
+        const float* src = p.X + (size_t)m * p.ldx + kb * RT_K;
+        f32x4 v[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + (i * 4 + q) * 4);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4*>(xs + row * RT_XS + ((i * 4 + q) << 2)) = v[i];
+      }
+      __syncthreads();
+      const int kb_next = (kb + 1 < KB ? kb + 1 : kb);  // after the last block: a harmless re-read
+      int xoff = xoff0;
+      auto xfrag = [&](int i, int kg) -> f32x4 { return *reinterpret_cast<const f32x4*>(xs + xoff + i * 16 * RT_XS + kg * 16); };
+#pragma unroll
+      for (int u = 0; u < UW; ++u) {
+        const int n0 = nw0 + u * 16;
+        const int n_nx = (u + 1 < UW ? n0 + 16 : nw0), kb_nx = (u + 1 < UW ? kb : kb_next);
+        xoff = xoff0 + (u + kb) * p.zero;               // (the fragments are the same for every unit: must LOOK unit-dependent, see above)
+        f32x4 acc[RT_WM];
+#pragma unroll
+        for (int i = 0; i < RT_WM; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 xa[RT_WM];
+#pragma unroll
+        for (int i = 0; i < RT_WM; ++i) xa[i] = xfrag(i, 0);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          f32x4 xb[RT_WM];
+          if (s + 1 < 16) {
+#pragma unroll
+            for (int i = 0; i < RT_WM; ++i) xb[i] = xfrag(i, s + 1);
+          }
+          const f32x4 wf = ring[s % RT_RING];
+          ring[s % RT_RING] = s + RT_RING < 16 ? wload(n0, kb, s + RT_RING) : wload(n_nx, kb_nx, s + RT_RING - 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < RT_WM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[e], xa[i][e], acc[i], 0, 0, 0);   // D = W . X^T
+          if (s + 1 < 16) {
+#pragma unroll
+            for (int i = 0; i < RT_WM; ++i) xa[i] = xb[i];
+          }
+          if ((s & 3) == 3) {                          // end of a 64-wide k-block: block sum -> running total (ascending; the first block IS the total)
+#pragma unroll
+            for (int i = 0; i < RT_WM; ++i) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) tot[u][i][e] = (kb == 0 && s == 3) ? acc[i][e] : tot[u][i][e] + acc[i][e];
+              acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+          }
+          RT_STEP_FENCE;
+        }
+      }
+    }
+
+    // ---- epilogue: lane (r, g) holds output columns oc .. oc + 3 of rows m0 + 16 i + r of every unit ----
+#pragma unroll
+    for (int u = 0; u < UW; ++u) {
+      const int oc = nw0 + u * 16 + 4 * g;
+      f32x4 bb = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (p.bias) bb = *reinterpret_cast<const f32x4*>(p.bias + oc);
+#pragma unroll
+      for (int i = 0; i < RT_WM; ++i) {
+        const int m = m0 + i * 16 + r;
+        f32x4 v = tot[u][i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += bb[e];
+        if (p.act == ACT_SILU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] / (1.0f + expf(-v[e]));
+        } else if (p.act == ACT_RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+        if (m < p.M) {
+          if (p.R) {
+            const f32x4 rr = *reinterpret_cast<const f32x4*>(p.R + (size_t)m * p.ldr + oc);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += rr[e];
+          }
+          *reinterpret_cast<f32x4*>(p.C + (size_t)m * p.ldc + oc) = v;
         }
       }
     }
@@ -286,7 +460,7 @@ int launch_rtlin(const GemmArgs& a, hipStream_t stream) {
   // tile prologue / unit epilogues run under the other's MFMAs); units are independent, so any grid gives the same bits
   // (measured: one per CU unless a workgroup would hold >= 64 units -- the vocabulary heads -- where three per CU gain 3-9 %)
   static const int per_cu_env = getenv("SS_RTLIN_WG_PER_CU") ? atoi(getenv("SS_RTLIN_WG_PER_CU")) : 0;
-  const int per_cu = per_cu_env > 0 ? per_cu_env : (U >= 64LL * cus ? 3 : 1);
+  const int per_cu = min(a.glu ? 2 : 3, per_cu_env > 0 ? per_cu_env : (U >= 64LL * cus ? 3 : 1));
   long long G = disp().rt_force_g > 0 ? disp().rt_force_g : (long long)cus * per_cu;      // at least 4 units (one per wave) each
   if (disp().rt_force_g <= 0 && G > U / 4) G = U / 4;
   if (G > U) G = U;
@@ -301,6 +475,54 @@ int launch_rtlin(const GemmArgs& a, hipStream_t stream) {
   } else {
     SS_MAX_LDS_ONCE((&rt_linear_kernel<false>), RT_LDS);
     hipLaunchKernelGGL(rt_linear_kernel<false>, dim3((unsigned)G), dim3(256), RT_LDS, stream, q);
+  }
+  SS_LAUNCH_CHECK();
+  return prof_end(stream, rec, prof);
+}
+
+
+// ---- K > 256 (rt_linear_kb_kernel) ----
+bool rtlin_kb_shape_ok(const GemmArgs& a) {
+  return a.taps == 1 && a.stride == 1 && a.pad == 0 && a.Cin > RT_K && a.Cin % RT_K == 0 && a.Cin <= 8192 && a.chunk == 0 &&
+         a.in_act == ACT_NONE && !a.R2 && !a.C2 && a.div == 0.f && !a.ln_out && !a.ln_g && !a.x3 && !a.glu && a.N % 256 == 0 && a.M >= 1 &&
+         a.nseg == 0 && (a.act == ACT_NONE || a.act == ACT_SILU || a.act == ACT_RELU) && (a.lda & 3) == 0 && (a.ldc & 3) == 0 &&
+         (!a.R || (a.ldr & 3) == 0) && a.A != a.C && a.in_len >= a.M && (size_t)a.N * a.Cin * 4 < 0x7ff00000ull;
+}
+
+bool rtlin_kb_eligible(const GemmArgs& a) {
+  if (disp().rt_off || !rtlin_kb_shape_ok(a)) return false;
+  // worth it from about one (tile, 256-column group) unit per resident workgroup (below: the 32 x 64 tiles fill the chip better)
+  return disp().rt_force_g > 0 || (long long)cdiv(a.M, RT_BM) * (a.N / 256) >= disp().rt_kb_min_units;
+}
+
+int launch_rtlin_kb(const GemmArgs& a, hipStream_t stream) {
+  if (!rtlin_kb_shape_ok(a)) return SS_ERR_ARG;
+  int cus = 0;
+  {
+    SkWorkspace* st = nullptr;
+    int rc = sk_workspace_acquire(stream, &st);
+    if (rc != SS_OK) return rc;
+    cus = st->cus;
+  }
+  RtKbArgs q;
+  q.X = a.A; q.ldx = a.lda; q.W = a.W; q.bias = a.bias; q.R = a.R; q.ldr = a.ldr; q.C = a.C; q.ldc = a.ldc;
+  q.alpha = a.alpha; q.act = a.act; q.M = a.M; q.K = a.Cin; q.zero = 0;
+  const int uw = (disp().rt_kb_uw == 8 && a.N % 512 == 0) ? 8 : 4;
+  q.NCG = a.N / (64 * uw);
+  const long long U = (long long)cdiv(a.M, RT_BM) * q.NCG;
+  long long G = disp().rt_force_g > 0 ? disp().rt_force_g : (long long)cus * (uw == 4 ? 3 : 2);
+  if (G > U) G = U;
+  if (G < 1) G = 1;
+  q.G = (int)G;
+  ProfRec rec{}; bool prof = false;
+  int rc = prof_begin(a, stream, 31, rec, prof);
+  if (rc != SS_OK) return rc;
+  if (uw == 8) {
+    SS_MAX_LDS_ONCE((&rt_linear_kb_kernel<8>), RT_LDS);
+    hipLaunchKernelGGL(rt_linear_kb_kernel<8>, dim3((unsigned)G), dim3(256), RT_LDS, stream, q);
+  } else {
+    SS_MAX_LDS_ONCE((&rt_linear_kb_kernel<4>), RT_LDS);
+    hipLaunchKernelGGL(rt_linear_kb_kernel<4>, dim3((unsigned)G), dim3(256), RT_LDS, stream, q);
   }
   SS_LAUNCH_CHECK();
   return prof_end(stream, rec, prof);

@@ -3,13 +3,24 @@
 // and the ragged-batch forward.
 #include "model_internal.hpp"
 
+#include <cstdint>
+#include <tuple>
+
 
 // Transformed weights are a function of the weight blob alone: contexts made over the same blob (HipVocoder.new_context: one per
-// concurrent stream) borrow one buffer instead of packing ~16 MB each.  Keyed by (device, blob pointer), ref-counted.
+// concurrent stream) borrow one buffer instead of packing ~16 MB each.  Keyed by (device, blob pointer, signature of
+// everything the layout of the transformed buffer depends on: channel plan, ResBlock kernel sizes, the blob's slot offsets), ref-counted:
+// a second configuration over a live blob gets its OWN entry (it used to erase the live one and orphan its buffer).
+// The blob must stay immutable while any context made over it lives (header): a rewrite in place is not detected.
 namespace {
 struct WinoShared { DevBuf buf; size_t floats = 0; int refs = 0; };
+struct WinoKey {
+  int dev; const float* blob; uint64_t sig;
+  bool operator<(const WinoKey& o) const { return std::tie(dev, blob, sig) < std::tie(o.dev, o.blob, o.sig); }
+};
 std::mutex g_wino_mu;
-std::map<std::pair<int, const float*>, WinoShared> g_wino;
+std::map<WinoKey, WinoShared> g_wino;
+inline uint64_t fnv(uint64_t h, uint64_t v) { for (int i = 0; i < 8; ++i) { h ^= (v >> (8 * i)) & 0xff; h *= 1099511628211ull; } return h; }
 }  // namespace
 
 extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_blob, size_t blob_floats,
@@ -63,12 +74,16 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess) { sk_workspace_free(v->skws); delete v; return SS_ERR_HIP; }
       std::lock_guard<std::mutex> lk(g_wino_mu);          // (held over the pack: a second context of the same blob waits for it)
-      WinoShared& sh = g_wino[std::make_pair(dev, d_blob)];
-      const bool fresh = sh.refs == 0 || sh.floats != need;
-      if (fresh && sh.refs > 0) { g_wino.erase(std::make_pair(dev, d_blob)); sk_workspace_free(v->skws); delete v; return SS_ERR_ARG; }   // same blob, another config
+      uint64_t sig = fnv(fnv(fnv(14695981039346656037ull, (uint64_t)C0), (uint64_t)cfg->n_up), (uint64_t)cfg->n_res);
+      for (int j = 0; j < cfg->n_res; ++j) sig = fnv(sig, (uint64_t)cfg->resblock_kernel_sizes[j]);
+      for (size_t i = 0; i < v->rb_c1.size(); ++i) sig = fnv(fnv(sig, (uint64_t)(v->rb_c1[i].w - d_blob)), (uint64_t)(v->rb_c2[i].w - d_blob));
+      const WinoKey key{dev, d_blob, sig};
+      WinoShared& sh = g_wino[key];
+      const bool fresh = sh.refs == 0;
+      if (!fresh && sh.floats != need) { sk_workspace_free(v->skws); delete v; return SS_ERR_ARG; }   // (same signature, another size: cannot happen; the live entry is left alone)
       if (fresh) {
         rc = sh.buf.ensure(need * sizeof(float));
-        if (rc != SS_OK) { g_wino.erase(std::make_pair(dev, d_blob)); sk_workspace_free(v->skws); delete v; return rc; }
+        if (rc != SS_OK) { g_wino.erase(key); sk_workspace_free(v->skws); delete v; return rc; }
         sh.floats = need;
       }
       float* dst = sh.buf.f();
@@ -92,7 +107,7 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
       // complete for every stream once this returns
       if (fresh && rc == SS_OK && hipDeviceSynchronize() != hipSuccess) rc = SS_ERR_HIP;
       if (rc != SS_OK) {
-        if (fresh) { sh.buf.release(); g_wino.erase(std::make_pair(dev, d_blob)); }
+        if (fresh) { sh.buf.release(); g_wino.erase(key); }
         sk_workspace_free(v->skws); delete v; return rc;
       }
       ++sh.refs;
@@ -115,7 +130,7 @@ extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
   if (v->wino_key) {
     std::lock_guard<std::mutex> lk(g_wino_mu);
     for (auto it = g_wino.begin(); it != g_wino.end(); ++it)
-      if (it->first.second == v->wino_key && it->second.buf.f() == v->wino) {
+      if (it->first.blob == v->wino_key && it->second.buf.f() == v->wino) {
         if (--it->second.refs == 0) { it->second.buf.release(); g_wino.erase(it); }
         break;
       }

@@ -143,3 +143,23 @@ def test_timed_out_persistent_step_falls_back_to_launch_per_op(hip_model):
     got = torch.cat(rows)
     assert got.shape == ref_f.shape and (got - ref_f).abs().max().item() < 5e-5
     assert lib.ss_debug_sk_errors() == err0            # the injection does not touch the real counter
+
+
+def test_single_persistent_step_computes_a_fed_eos_like_the_launch_per_op_form(hip_model):
+    """the early exit on a fed </s> belongs to ss_mt_greedy's search loop only; ss_mt_append with the persistent step on must
+    compute the step it is fed (cache row, state row, next token) exactly as its launch-per-op form does."""
+    from streamspeech_amd import synth
+    m = hip_model.new_context()
+    enc = m.encoder_forward(torch.from_numpy(synth.synth_fbank(92, 171)).cuda())
+    out = {}
+    for wg in (0, 64):
+        m.set_persistent_mt_step(wg)
+        m.mt_begin(enc)
+        m.mt_append([m.cfg.eos, 7, 4242], 0, False, False)
+        feats, nxt = m.mt_append([m.cfg.eos], 3, False, False)          # </s> fed at position 3
+        feats2, nxt2 = m.mt_append([11], 4, False, False)               # and the search goes on over that cache row
+        out[wg] = (feats.cpu(), nxt, feats2.cpu(), nxt2)
+    m.set_persistent_mt_step(0)
+    assert out[64][1] == out[0][1] and out[64][3] == out[0][3]
+    assert torch.isfinite(out[64][0]).all() and (out[64][0] - out[0][0]).abs().max().item() < 5e-5
+    assert (out[64][2] - out[0][2]).abs().max().item() < 5e-5

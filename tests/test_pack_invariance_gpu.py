@@ -4,9 +4,10 @@ The reference decodes one utterance per call (agent/speech_to_speech.streamspeec
 so an utterance's ids cannot depend on what it is batched with.  The ragged-batch twins (ss_batch_*) therefore compute a packed
 utterance with a summation order that is a function of that utterance alone.  Two levels:
 
-* op level: the kernels the pack-invariant routes may choose between (LDS-tiled kernel without split-K, row-tile kernel,
-  stream-K cut on whole tiles; the whole-tile fused FFN at every tile height; the fixed small-M form of the decode rows) give a
-  row the SAME BITS whatever the row count, i.e. whichever of them the row count selects;
+* op level: the kernels the pack-invariant routes may choose between (LDS-tiled kernel without split-K, row-tile kernels at
+  K = 256 and at K = 512 ... through 256-wide k-blocks; the whole-tile fused FFN at every tile height; the fixed small-M form of
+  the decode rows) give a row the SAME BITS whatever the row count, i.e. whichever of them the row count selects -- and (round 6)
+  sit no farther from float64 than torch's CPU sgemm: the chain is cut every 256 k, block sums added in ascending order;
 * model level: logits of every arg-max stage of an utterance are bit-identical alone (a pack of one), in a pack of 8 and in
   another pack at another position.
 """
@@ -64,6 +65,38 @@ def test_one_chain_kernels_give_a_row_the_same_bits_at_every_row_count(lib, cano
         for off in (0, Mmax - M):                                   # the same rows at another position of the launch
             part = run_conv_gemm(lib, A[off:off + M], W, b, M, N, K, act=act, alpha=0.5, R=R[off:off + M])
             assert torch.equal(part, full[off:off + M]), f"N={N} K={K}: rows differ between M={Mmax} and M={M} (offset {off})"
+
+
+@pytest.mark.parametrize("N,K,M", [(512, 2048, 20000), (512, 2048, 300), (2048, 512, 20000), (256, 256, 4000), (768, 256, 9000)])
+def test_blocked_chain_is_as_close_to_float64_as_torch_cpu_sgemm(lib, canon, N, K, M):
+    """one sequential chain over K = 2048 sat 2.8x farther from float64 than the oracle's BLAS.  The pack-invariant
+    routes now cut the chain every 256 k: RMS error against float64 at most 1.1x that of torch's CPU float32 matmul on the same
+    operands (and a row's bits still do not depend on M: the test above)."""
+    canon(1)
+    A, W = rnd(M, K, seed=71), rnd(N, K, seed=72, scale=K ** -0.5)
+    out = run_conv_gemm(lib, A, W, None, M, N, K)[:256].double()
+    ref = A[:256].double() @ W.double().t()
+    cpu = (A[:256] @ W.t()).double()
+    e_hip, e_cpu = float(((out - ref) ** 2).mean().sqrt()), float(((cpu - ref) ** 2).mean().sqrt())
+    print(f"N={N} K={K} M={M}: rms vs float64: HIP {e_hip:.3e}, torch CPU {e_cpu:.3e}, ratio {e_hip / e_cpu:.3f}")
+    assert e_hip <= 1.1 * e_cpu
+
+
+def test_subsampler_conv_blocked_chain_accuracy(lib, canon):
+    """The encoder's second subsampling conv (Conv1dSubsampler, fairseq/models/speech_to_text/s2t_transformer.py: 1024 -> 512, k = 5,
+    stride 2): K = 5120, the longest contraction upstream of the arg-maxes."""
+    canon(1)
+    Tin, Cin, N, taps = 1500, 1024, 512, 5
+    A, W = rnd(Tin, Cin, seed=73), rnd(N, taps * Cin, seed=74, scale=(taps * Cin) ** -0.5)
+    M = (Tin + 2 * 2 - taps) // 2 + 1
+    out = run_conv_gemm(lib, A, W, None, M, N, Cin, taps=taps, stride=2, pad=2, in_len=Tin).double()
+    x = A.double().t().unsqueeze(0)                                        # [1, Cin, T]
+    w = W.double().view(N, taps, Cin).permute(0, 2, 1).contiguous()       # tap-major [N][k][Cin] -> [N, Cin, k]
+    ref = F.conv1d(x, w, stride=2, padding=2)[0].t()
+    cpu = F.conv1d(x.float(), w.float(), stride=2, padding=2)[0].t().double()
+    e_hip, e_cpu = float(((out - ref) ** 2).mean().sqrt()), float(((cpu - ref) ** 2).mean().sqrt())
+    print(f"subsampler conv2: rms vs float64: HIP {e_hip:.3e}, torch CPU {e_cpu:.3e}, ratio {e_hip / e_cpu:.3f}")
+    assert e_hip <= 1.1 * e_cpu
 
 
 @pytest.mark.parametrize("N,glu", [(768, 0), (512, 1)])
