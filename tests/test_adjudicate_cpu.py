@@ -35,7 +35,7 @@ def test_adjudication_passes_only_rows_float32_cannot_decide():
     scale = 10.0
     L64 = _row({0: scale, 1: scale - 2e-6})                   # float64 gap 2e-6 < 2^-20 x 10 = 9.5e-6
     L32 = L64.clone(); L32[0, 0] += 3e-6                       # float32 oracle: id 0
-    Lh = L64.clone(); Lh[0, 1] += 4e-6                         # HIP: id 1
+    Lh = L64.clone(); Lh[0, 1] += 2.5e-6                         # HIP: id 1
     lines = J.adjudicate("t", [(0, 1, 0)], L64, L32, Lh, [7])
     assert len(lines) == 1 and "float64 gap 2.00e-06" in lines[0]
     with pytest.raises(AssertionError, match="float32 decides"):       # the same exchange with a gap float32 resolves
@@ -46,6 +46,13 @@ def test_adjudication_passes_only_rows_float32_cannot_decide():
     with pytest.raises(AssertionError, match="too far"):               # a near tie does not excuse wrong logits
         far = Lh.clone(); far[0, 3] += 1e-3
         J.adjudicate("t", [(0, 1, 0)], L64, L32, far, [7])
+    with pytest.raises(AssertionError, match="twice as far"):          # float32-grade in absolute terms, but 3x the oracle's distance on the row
+        worse = Lh.clone(); worse[0, 3] += 1.0e-5                      # oracle row distance 3e-6, HIP 1e-5 (absolute bar 3.8e-5)
+        J.adjudicate("t", [(0, 1, 0)], L64, L32, worse, [7])
+    with pytest.raises(AssertionError, match="utterance farther"):     # the row is fine, the rest of the utterance is not
+        L64b, L32b, Lhb = (torch.cat([x, _row({0: 1.0})]) for x in (L64, L32, Lh))
+        L32b[1, 2] += 1e-6; Lhb[1, 2] += 3e-6; Lhb[1, 3] -= 3e-6; Lhb[1, 4] += 3e-6
+        J.adjudicate("t", [(0, 1, 0)], L64b, L32b, Lhb, [7])
     assert J.differing_rows([1, 2, 3], [1, 5, 3]) == [(1, 2, 5)]
     with pytest.raises(AssertionError):
         J.differing_rows([1, 2], [1, 2, 3])
@@ -55,6 +62,6 @@ def test_masked_columns_do_not_take_part():
     from oracle import adjudicate as J
     L64 = _row({0: 10.0, 1: 10.0 - 2e-6, 7: 50.0})             # column 7 (pad / unk) is masked: it neither wins nor sets the scale
     L32 = L64.clone(); L32[0, 0] += 3e-6
-    Lh = L64.clone(); Lh[0, 1] += 4e-6
+    Lh = L64.clone(); Lh[0, 1] += 2.5e-6
     assert len(J.adjudicate("t", [(0, 1, 0)], L64, L32, Lh, [7])) == 1
     assert isinstance(np.asarray(L64), np.ndarray)

@@ -19,9 +19,9 @@ by recomputing the utterance with the oracle in float64 from the same inputs, an
   (1) HIP's id and the float32 oracle's id are exactly the float64 top-2 of the row,
   (2) their float64 gap is below 2^-20 x max|logit| -- i.e. below what the float32 ORACLE ITSELF is off from float64
       on that row (the test measures and prints it), so float32 cannot decide the row,
-  (3) the HIP logits of the row (dense, from the same pack-invariant arithmetic) are float32-grade: within 2^-18 x max|logit|
-      of float64 (the oracle's own distance and both RMS distances over the utterance are printed beside it),
-and at most one row per 40 k compared (MAX_ADJUDICATED_PER_ROWS; 5 of the ~200 k here) may need it; each is printed.  Seeded RANDOM weights make 6000-way
+  (3) the HIP logits (dense, from the same pack-invariant arithmetic) are float32-grade: on the row within 2^-18 x max|logit| of
+      float64 AND at most twice the oracle's own distance; over the utterance RMS(HIP - float64) <= 1.1 x RMS(oracle - float64),
+and at most 3 rows per ~250 k compared (max(3, rows // MAX_ADJUDICATED_PER_ROWS)) may need it; each is printed.  Seeded RANDOM weights make 6000-way
 rows with gaps of 1e-5 (no trained model has them; median margin 0.3): VERDICT r4 weak #1."""
 import threading
 
@@ -32,7 +32,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 WAV_RMS_TOL = 1e-3
-MAX_ADJUDICATED_PER_ROWS = 40000     # round 5 until the check was widened: 3 rows for the ~120 k of 192 utterances
+MAX_ADJUDICATED_PER_ROWS = 84000     # 3 rows per ~250 k compared (round 5 had loosened it to one per 40 k)
 
 
 def _hip_row_logits(m, pcm, u, stage, toks):
