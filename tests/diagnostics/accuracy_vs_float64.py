@@ -2,7 +2,7 @@
 """How far the HIP logits and the float32 CPU oracle's logits sit from the float64 evaluation of the same arithmetic, per arg-max
 stage, on utterances of the bench workload (HIP must be at least as close as the oracle).
 
-  python tools/accuracy_vs_float64.py [n_utterances=6] > profiles/rNN_accuracy_vs_float64.json
+  python tests/diagnostics/accuracy_vs_float64.py [n_utterances=6] > profiles/rNN_accuracy_vs_float64.json
 
 Per utterance and stage (asr / st / unit): RMS(HIP - f64), RMS(oracle - f64), their ratio, worst-row max errors.  The HIP side is the
 utterance ALONE through the ss_batch_* calls (pack-invariant arithmetic: the bits it has in any pack).  Test infrastructure: imports oracle/."""
@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import bench  # noqa: E402

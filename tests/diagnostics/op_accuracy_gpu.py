@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-op distance from float64: the HIP kernel vs torch's CPU float32 evaluation of the same op on the same operands (random data of
 the encoder's shapes).  Looks for the op that makes HIP encoder logits sit farther from float64 than the oracle's (VERDICT r5 #2;
-tools/diag/chain_ablation_cpu.py showed the linears' summation order is NOT it).  Test infrastructure (imports oracle/ and tests/)."""
+tests/diagnostics/chain_ablation_cpu.py showed the linears' summation order is NOT it).  Test infrastructure (imports oracle/ and tests/)."""
 import ctypes as C
 import json
 import os

@@ -42,7 +42,7 @@ CLASSES = [("void ss::conv_sk2_kernel", "conv_sk2<256,128,32>"), ("void ss::conv
            ("void ss::conv_gemm_kernel<32, 64, 32", "conv_gemm<32,64,32,2,2>"), ("void ss::conv_gemm_kernel<32, 32, 32", "conv_gemm<32,32,32,2,2>"),
            ("void ss::conv_gemm_kernel<128, 32, 32", "conv_gemm<128,32,32,4,1>"), ("void ss::conv_gemm_kernel<128, 16, 16", "conv_gemm<128,16,16,4,1>"),
            ("void ss::smallm_gemm_kernel<4, 1", "smallm_gemm<4,1>"), ("void ss::ffn_fused_kernel", "ffn_fused<256,2048>"),
-           ("void ss::rt_linear_kernel", "rt_linear<48,256>"), ("void ss::conv_c64_kernel", "conv_c64<256,64>"), ("void ss::conv_c64w_kernel", "conv_c64w<256,64>"), ("void ss::conv_c64w_kernel", "conv_c128w<256,128>"), ("void ss::conv_c64w_kernel", "conv_c32w<256,32>"), ("void ss::conv_c64w_kernel", "conv_c256w<256,128>"), ("void ss::conv_c32_kernel", "conv_c32<256,32>"), ("void ss::conv_c16_kernel", "conv_c16<256,16>")]
+           ("void ss::rt_linear_kernel", "rt_linear<48,256>"), ("void ss::rt_linear_kb_kernel", "rt_linear_kb<48,256>"), ("void ss::conv_c64_kernel", "conv_c64<256,64>"), ("void ss::conv_c64w_kernel", "conv_c64w<256,64>"), ("void ss::conv_c64w_kernel", "conv_c128w<256,128>"), ("void ss::conv_c64w_kernel", "conv_c32w<256,32>"), ("void ss::conv_c64w_kernel", "conv_c256w<256,128>"), ("void ss::conv_c32_kernel", "conv_c32<256,32>"), ("void ss::conv_c16_kernel", "conv_c16<256,16>")]
 
 
 def read(path, counter):

@@ -25,6 +25,7 @@ CLASSES = [("conv_sk2<256,128,32>", ["void ss::conv_sk2_kernel"]),
            ("conv_slab<16>", ["void ss::conv_slab_kernel<16", "void ss::conv_pair_kernel<16"]),
            ("ffn_fused<256,2048>", ["void ss::ffn_fused_kernel"]),
            ("rt_linear<48,256>", ["void ss::rt_linear_kernel"]),
+           ("rt_linear_kb<48,256>", ["void ss::rt_linear_kb_kernel"]),
            ("conv_gemm<32,64,32,2,2>", ["void ss::conv_gemm_kernel<32, 64, 32"]),
            ("conv_gemm<32,32,32,2,2>", ["void ss::conv_gemm_kernel<32, 32, 32"]),
            ("conv_gemm<32,64,16,2,2>", ["void ss::conv_gemm_kernel<32, 64, 16"]),
