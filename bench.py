@@ -12,10 +12,10 @@ A "step" is one pass of the whole HIP hot path over one ragged batch of --batch 
 utterances, each with B = 1 arithmetic (streamspeech_amd/workload.py): PCM already in HBM ->
 fbank+CMVN -> chunk-Conformer -> CTC x2 -> AR MT greedy decode -> T2U + NAR unit decoder -> CTC
 collapse -> unit HiFi-GAN -> waveform in HBM.  The default K = 16 steps is twice BASELINE.json's
-1024-utterance set -- two batches per stream: with one (K = 8) the region is as long as the longest pack alone, 5811x
-(rounds 1-3 packed 32 per batch, round 4 and most of round 5 64; ids do not depend on the pack since round 5 --
-tests/test_pack_invariance_gpu.py -- and 128 measures +3.3 % on the same build, profiles/r05_pack_sweep.txt: launches twice as long,
-half as many lock-step decode launches); with --batch 1 a step is one utterance through the single-utterance entry points.
+1024-utterance set, four batches on each of the 4 default streams (a scratch set each; 8 streams measure +0.9 % at twice the HBM,
+profiles/r06_stream_sweep.txt).  Packs: 32 in rounds 1-3, 64 in round 4, 128 since round 5 (ids do not depend on the pack --
+tests/test_pack_invariance_gpu.py); with --batch 1 a step is one utterance through the single-utterance entry points.
+stdout carries ONE line under 6 KB (compact_line); the full result goes to the sidecar bench_detail.json (SS_BENCH_DETAIL) and to stderr.
 value = total audio seconds / wall seconds over all ranks (RTFx; higher is better); the line also
 carries utterances/sec, the roofline of the dominant kernel (HIP events recorded on the launch
 stream inside the timed region) and the CPU oracle timed on this box's host cores (rank 0, N=1).
@@ -766,8 +766,8 @@ def main():
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak (default): --steps batches PER GPU; strong: --steps batches in TOTAL (configs[3] literally: "
                          "steps x batch utterances / N per GPU)")
-    ap.add_argument("--streams", type=int, default=8,
-                    help="concurrent HIP streams per GPU (own scratch context each)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="concurrent HIP streams per GPU, a scratch set each (4: within 1 %% of 8 at half the HBM -- profiles/r06_stream_sweep.txt)")
     ap.add_argument("--no-latency-pass", action="store_true", help="skip the single-stream latency measurement")
     ap.add_argument("--no-soak", action="store_true", help="skip the >= 100-step sustained passes after the timed region")
     ap.add_argument("--batch", type=int, default=128,
@@ -907,7 +907,13 @@ def main():
     t_leg = time.perf_counter()
     import threading
     hbm_free0, hbm_total = torch.cuda.mem_get_info(dev)     # before any scratch context has grown (weights + the packed PCM are resident)
-    ctxs = [(model, voc)] + [(model.new_context(), voc.new_context()) for _ in range(S - 1)]
+    # one scratch set per stream (activations, KV caches, stream-K state: everything a call mutates), shared by the model and the vocoder
+    # handle of the stream -- and by the other languages' handles in the configs[4] leg
+    from streamspeech_amd.engine import Scratch
+    scratches = [Scratch(dev) for _ in range(S)]
+    model.bind_scratch(scratches[0])
+    voc.bind_scratch(scratches[0])
+    ctxs = [(model, voc)] + [(model.new_context(scratch=scratches[wi]), voc.new_context(scratch=scratches[wi])) for wi in range(1, S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     # one work item per timed step: the utterances of the ragged batch + their packed PCM (built before the timed region)
     if Bsz == 1:
@@ -992,8 +998,9 @@ def main():
 
     hbm_free1, _ = torch.cuda.mem_get_info(dev)
     hbm = {"total_gb": round(hbm_total / 2 ** 30, 1), "in_use_after_the_timed_region_gb": round((hbm_total - hbm_free1) / 2 ** 30, 1),
-           "scratch_per_context_gb": round((hbm_free0 - hbm_free1) / S / 2 ** 30, 2), "contexts": S,
-           "note": "a scratch context (model + vocoder) keeps the activations of the largest pack it has run; it never shrinks"}
+           "scratch_sets": S, "scratch_set_gb": [round(sc.bytes() / 2 ** 30, 2) for sc in scratches],
+           "note": "a scratch set (ss_scratch: one per stream, model + vocoder side) keeps the activations of the largest pack it has run until "
+                   "ss_scratch_trim; ss_scratch_set_cap bounds it"}
     audio = sum(mine[i].seconds for i in timed_ids)
     per_rank = dp.gather_per_rank(dist, wall, audio, float(K), device=dev, placement=placement)
     wall, audio, nutt = dp.reduce_stats(dist, wall, audio, float(K), device=dev)
@@ -1090,7 +1097,7 @@ def main():
     roofline, roofline_conv = in_region, in_region_conv
     roofline_family, dispatch = None, None
     WINO = [c for c in range(lib.ss_prof_num_classes()) if lib.ss_prof_class_name(c).decode().startswith(("conv_c64w", "conv_c128w", "conv_c32w", "conv_c256w"))]
-    if dom is not None and S > 1 and work and not os.environ.get("SS_BENCH_NO_REPLAY"):   # (tools/jobs/*trace*: keep the trace to the timed region)
+    if rank == 0 and dom is not None and S > 1 and work and not os.environ.get("SS_BENCH_NO_REPLAY"):   # (ranks > 0 run no optional leg)   # (tools/jobs/*trace*: keep the trace to the timed region)
         lib.ss_prof_reset()
         mask = (1 << dom) | ((1 << dom_conv) if dom_conv is not None else 0)
         for c in WINO:
@@ -1159,11 +1166,10 @@ def main():
     # bf16(x) + bf16(x - bf16(x)) (ss_vocoder_set_bf16x3; f32 accumulation, everything else -- every argmax stage, the
     # duration predictor, the narrow vocoder stages -- stays f32).  Untimed for `value`; tests/test_bf16x3_gpu.py holds
     # its parity bars (durations identical, waveform RMS <= 1e-3 vs the FP32 oracle).
-    def region_pass(pick=None, lanes=1):
+    def region_pass(pick=None):
         """All timed batches once more over the same S streams (untimed for `value`); pick(wi, i) -> (model, vocoder)
-        context for work item i on worker wi (default: the worker's own fr-en context).  lanes > 1: work item i belongs to lane
-        i % lanes and worker wi serves lane wi % lanes only (one queue per lane)."""
-        nxt, errs = list(range(lanes)), []
+        handles for work item i on worker wi (default: the worker's own fr-en handles)."""
+        nxt, errs = [0], []
 
         def w2(wi):
             try:
@@ -1171,8 +1177,8 @@ def main():
                 with torch.cuda.stream(streams[wi]):
                     while True:
                         with lock:
-                            i = nxt[wi % lanes]
-                            nxt[wi % lanes] += lanes
+                            i = nxt[0]
+                            nxt[0] += 1
                         if i >= len(work):
                             break
                         m, v = ctxs[wi] if pick is None else pick(wi, i)
@@ -1252,66 +1258,41 @@ def main():
     # batches dealt round-robin over the languages inside the same S-stream region (untimed for `value`); parity of exactly
     # this arrangement against the oracle: tests/test_multilingual_gpu.py.
     multilingual = None
-    # configs[4] needs scratch contexts beyond the S timed ones: a (language, stream) pair each when 2 x S more fit (every stream serves every
-    # language: rounds 1-4, packs of 64); otherwise each stream serves ONE language (stream wi: language wi % 3, i.e. 3 / 3 / 2 streams at
-    # S = 8, batch i of language i % 3 queued on its language's streams): 2 x ceil(S / 3) more contexts; otherwise the leg is skipped.
-    per_ctx = (hbm_free0 - hbm_free1) / S
-    free_now = torch.cuda.mem_get_info(dev)[0]
-    if free_now > 1.15 * 2 * S * per_ctx:
-        lanes, ml_extra = 1, 2 * S
-    elif S >= 3 and free_now > 1.15 * 2 * -(-S // 3) * per_ctx:
-        lanes, ml_extra = 3, 2 * -(-S // 3)
-    else:
-        lanes, ml_extra = 0, 2 * -(-S // 3)
-    want_ml = world == 1 and Bsz > 1 and work and not args.no_multilingual
-    if want_ml and not lanes:
-        multilingual = {"value": None, "skipped": f"{ml_extra} more scratch contexts of {hbm['scratch_per_context_gb']} GB do not fit in the free HBM"}
+    # Scratch sets are objects of their own since round 6 (ss_scratch_*): the es / de weight handles of a stream are bound to THAT stream's
+    # scratch set, so any language runs on any stream with S scratch sets (round 5: a scratch set per (language, stream) pair, which no
+    # longer fitted at packs of 128 and forced one language per stream).
     try:
-        if want_ml and lanes:
+        if world == 1 and Bsz > 1 and work and not args.no_multilingual:
             golden = os.path.join(ROOT, "tests", "golden")
             order = ("fr", "es", "de")
-            per_lang = {"fr": {wi: ctxs[wi] for wi in range(S) if wi % lanes == 0}}
+            per_lang = {"fr": {wi: ctxs[wi] for wi in range(S)}}
             weights_mb = 4e-6 * (model.blob.numel() + voc.blob.numel())
-            for li, (seed, lang) in enumerate(((1, "es"), (2, "de")), start=1):
+            hbm_before = torch.cuda.mem_get_info(dev)[0]
+            for seed, lang in ((1, "es"), (2, "de")):
                 g = np.load(os.path.join(golden, f"gcmvn_{lang}-en.npz"))      # configs/{es,de}-en/gcmvn.npz of the reference
-                m = HipModel(synth.make_model_state_dict(seed, cfg), cfg, device=dev, cmvn_mean=g["mean"], cmvn_std=g["std"])
-                v = HipVocoder(synth.make_vocoder_state_dict(seed, vcfg), vcfg, device=dev)
+                m = HipModel(synth.make_model_state_dict(seed, cfg), cfg, device=dev, cmvn_mean=g["mean"], cmvn_std=g["std"], scratch=scratches[0])
+                v = HipVocoder(synth.make_vocoder_state_dict(seed, vcfg), vcfg, device=dev, scratch=scratches[0])
                 weights_mb += 4e-6 * (m.blob.numel() + v.blob.numel())
-                mine_wi = [wi for wi in range(S) if wi % lanes == li % lanes]
-                per_lang[lang] = {wi: ((m, v) if k == 0 else (m.new_context(), v.new_context())) for k, wi in enumerate(mine_wi)}
-            big = max(work, key=lambda w: w[1].numel())
-            # the workload pins the MT length by max_new_tokens; a random es/de model may emit </s> earlier than the forced
-            # position, which run_batch reports -- min_len pins it (ss_batch_mt_greedy bans </s> before min_len)
-            for lang in order[1:]:
-                for wi, (m, v) in per_lang[lang].items():
-                    with torch.cuda.stream(streams[wi]):
-                        run_batch(m, v, big[1], big[0])
-            torch.cuda.synchronize()
-            pick = lambda wi, i: per_lang[order[i % 3]][wi]   # noqa: E731   (lanes = 3: worker wi only draws items i with i % 3 == wi % 3)
-            region_pass(pick, lanes)                           # warm pass over every (language, stream) context
+                per_lang[lang] = {wi: ((m, v) if wi == 0 else (m.new_context(scratch=scratches[wi]), v.new_context(scratch=scratches[wi]))) for wi in range(S)}
+            pick = lambda wi, i: per_lang[order[i % 3]][wi]   # noqa: E731   batch i is of language i % 3, on whichever stream takes it
+            region_pass(pick)                                  # warm pass
             n_best = 2 if args.full else 1
-            dt_ml = min(region_pass(pick, lanes) for _ in range(n_best))
-            dt_1 = min(region_pass(None, lanes) for _ in range(n_best))     # the single-language set through the same queues, same moment
+            dt_ml = min(region_pass(pick) for _ in range(n_best))
+            dt_1 = min(region_pass() for _ in range(n_best))  # the single-language set through the same queues, same moment
             multilingual = {"value": round(audio / dt_ml, 2), "unit": "x real-time (audio s / wall s)", "utterances_per_sec": round(nutt / dt_ml, 3),
                             "ms_per_step": round(1e3 * dt_ml / max(1, len(work)), 3), "languages": list(order),
-                            "weights_mb": round(weights_mb, 1), "contexts": sum(len(x) for x in per_lang.values()),
-                            "streams_per_language": {lang: len(per_lang[lang]) for lang in order},
+                            "weights_mb": round(weights_mb, 1), "weight_handles": 3 * S, "scratch_sets": S,
+                            "hbm_added_by_two_more_languages_gb": round((hbm_before - torch.cuda.mem_get_info(dev)[0]) / 2 ** 30, 2),
                             "single_language_same_method": {"value": round(audio / dt_1, 2), "ms_per_step": round(1e3 * dt_1 / max(1, len(work)), 3)},
                             "multilingual_over_single": round(dt_1 / dt_ml, 4),
                             "note": "BASELINE.json configs[4]: three weight sets (seeds 0/1/2 of the same architecture, es/de with the reference's "
-                                    "gcmvn statistics) resident together; batch i is of language i % 3" +
-                                    (" and runs on one of that language's streams (stream wi serves language wi % 3: a scratch context per "
-                                     "(language, stream) pair for all 3 x S pairs does not fit in HBM at this pack size)" if lanes == 3 else
-                                     " on whichever stream takes it (a scratch context per (language, stream) pair)") +
-                                    f"; best of {n_best} pass(es) after one warm pass, next to the single-language set timed through the same queues"}
-            for lang in order[1:]:
-                del per_lang[lang]
+                                    "gcmvn statistics) resident together; batch i is of language i % 3 and runs on whichever stream takes it -- every "
+                                    f"stream's scratch set serves all three languages; best of {n_best} pass(es) after one warm pass"}
+            del per_lang["es"], per_lang["de"]
             torch.cuda.empty_cache()
     except Exception as e:  # noqa: BLE001  (an optional leg never costs the line)
         multilingual = {"value": None, "skipped": f"multilingual: {type(e).__name__}: {e}"[:200]}
 
-    # Strict configs[1] form: ONE utterance per call (the single-utterance entry points, no ragged packs),
-    # 8 utterances in flight on 8 streams (untimed for `value`).
     legs["bf16x3_and_multilingual"] = round(time.perf_counter() - t_leg, 2)
     t_leg = time.perf_counter()
     b1_rtfx = b1_ups = None

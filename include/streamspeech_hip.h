@@ -9,7 +9,7 @@
  *
  * Weight ownership: the caller owns one packed FP32 weight blob in HBM (built once from a fairseq
  * state dict by streamspeech_amd/weights.py) and lends it to ss_model_create(); the library keeps
- * borrowed pointers into it plus its own scratch / caches (hipMalloc).
+ * borrowed pointers into it; scratch / caches live in scratch sets (ss_scratch_*, hipMalloc).
  */
 #ifndef STREAMSPEECH_HIP_H
 #define STREAMSPEECH_HIP_H
@@ -21,10 +21,11 @@
 extern "C" {
 #endif
 
-#define SS_ABI_VERSION 1
+#define SS_ABI_VERSION 2              /* 2 (round 6): scratch sets are objects of their own (ss_scratch_*), SS_ERR_SCRATCH_CAP */
 
-typedef struct ss_model ss_model;      /* StreamSpeechModel replacement (encoder + CTC + MT + T2U + unit decoder) */
-typedef struct ss_vocoder ss_vocoder;  /* CodeHiFiGANVocoderWithDur replacement */
+typedef struct ss_model ss_model;      /* StreamSpeechModel replacement (encoder + CTC + MT + T2U + unit decoder): WEIGHTS of one language */
+typedef struct ss_vocoder ss_vocoder;  /* CodeHiFiGANVocoderWithDur replacement: WEIGHTS */
+typedef struct ss_scratch ss_scratch;  /* everything a call mutates: activations, KV caches, stream-K hand-off state, streaming state */
 
 /* Architecture hyper-parameters (reference researches/ctc_unity/models/streamspeech_model.py:418-430
  * and train_scripts/train.offline-s2st.sh). */
@@ -57,6 +58,28 @@ int ss_model_create(const ss_config* cfg, const float* d_blob, size_t blob_float
                     const char* const* names, const int64_t* offsets, const int64_t* numels,
                     int n_slots, ss_model** out);
 void ss_model_destroy(ss_model* m);
+
+/* ---- scratch sets -----------------------------------------------------------------------------
+ * The reference loads one model per language directory (configs/{fr,es,de}-en/, agent :357-401) and PyTorch's caching allocator
+ * holds the activations of whatever runs.  Here a weight handle (ss_model / ss_vocoder: borrowed pointers into the blob -- a few KB;
+ * the projected rel-pos table and the Winograd weight forms are shared per blob) is separate from a SCRATCH SET, which owns
+ * everything a call mutates.  A handle runs on the scratch set it is bound to: its own (made by ss_*_create, empty until used)
+ * or, after ss_model_bind_scratch / ss_vocoder_bind_scratch, a shared one -- so L languages on S concurrent streams need S scratch
+ * sets and L x S handles, not L x S scratch sets.  Rules: a scratch set (and every handle bound to it) is driven by ONE host
+ * thread at a time; a stateful sequence (ss_mt_begin ... ss_mt_append / ss_mt_truncate, ss_encoder_stream_*) stays on one (handle,
+ * scratch) pair from start to end; between sequences any handle bound to the set may use it.  Ref-counted: the memory goes when
+ * ss_scratch_destroy has been called AND every handle bound to the set is destroyed or re-bound.
+ * Buffers grow on demand and never shrink by themselves: ss_scratch_set_cap bounds their sum (a call that would pass it returns
+ * SS_ERR_SCRATCH_CAP and leaves the set as it was; 0 = no cap), ss_scratch_trim synchronises the device and lets the largest
+ * re-sizable buffers go until at most keep_bytes are held (fixed pieces -- MT cache, token chain, zero-initialised counters -- stay),
+ * ss_scratch_bytes reports what is held.  (The stream-K hand-off workspace, 32 MB + flags per set, is not counted.) */
+int ss_scratch_create(ss_scratch** out);
+void ss_scratch_destroy(ss_scratch* sc);
+int ss_scratch_set_cap(ss_scratch* sc, size_t max_bytes);
+int ss_scratch_trim(ss_scratch* sc, size_t keep_bytes);
+size_t ss_scratch_bytes(ss_scratch* sc);
+int ss_model_bind_scratch(ss_model* m, ss_scratch* sc);
+int ss_vocoder_bind_scratch(ss_vocoder* v, ss_scratch* sc);
 
 /* ---- a1: OnlineFeatureExtractor.__call__ (agent :66-98) on 16 kHz PCM already in HBM.
  * d_feat must hold ss_fbank_num_frames(n_samples)*80 floats. */

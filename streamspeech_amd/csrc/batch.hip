@@ -20,16 +20,16 @@ extern "C" int ss_batch_fbank_cmvn(ss_model* m, void* stream, int B, const float
     segs[3 * b] = (int)h_pcm_start[b]; segs[3 * b + 1] = T; segs[3 * b + 2] = row;
     row += T; mx = std::max(mx, T);
   }
-  RET(m->seg_buf.ensure(segs.size() * sizeof(int)));
-  RET(upload(s, (int*)m->seg_buf.p, segs));
+  RET(m->sc->seg_buf.ensure(segs.size() * sizeof(int)));
+  RET(upload(s, (int*)m->sc->seg_buf.p, segs));
   return launch_fbank_cmvn_batch(d_pcm, pcm_scale, m->fe_window, m->fe_melw, m->fe_mean, m->fe_std, d_feat,
-                                 (const int*)m->seg_buf.p, B, mx, s);
+                                 (const int*)m->sc->seg_buf.p, B, mx, s);
 }
 
 extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const float* d_fbank, const int32_t* h_T,
                                         int attn_chunk, int conv_chunk, float* d_enc_out, int32_t* h_Tp) {
   if (!m || B <= 0) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   CanonScope canon_scope(m->pack_invariant ? CANON_SEQ : CANON_NONE);
   const bool canon = m->pack_invariant && !debug_tile_forced();
   hipStream_t s = (hipStream_t)stream;
@@ -56,15 +56,15 @@ extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const 
     ta[4 * b] = o2.off[b]; ta[4 * b + 1] = T2[b]; ta[4 * b + 2] = o2.off[b]; ta[4 * b + 3] = T2[b];
     tr[2 * b] = o2.off[b]; tr[2 * b + 1] = T2[b];
   }
-  RET(m->seg_buf.ensure(tab.size() * sizeof(int)));
-  int* dt = (int*)m->seg_buf.p;
+  RET(m->sc->seg_buf.ensure(tab.size() * sizeof(int)));
+  int* dt = (int*)m->sc->seg_buf.p;
   RET(upload(s, dt, tab));
   const int *d0 = dt, *d1 = dt + 4 * B, *da = dt + 8 * B, *dr = dt + 12 * B;
 
   const size_t n_h1 = (size_t)M1 * (c.conv_channels / 2), n_x = (size_t)M2 * d, n_f = (size_t)M2 * f,
                n_qkv = (size_t)M2 * 3 * d;
-  RET(m->ws.ensure((n_h1 + 3 * n_x + n_f + n_qkv) * sizeof(float)));
-  float* h1 = m->ws.f();
+  RET(m->sc->ws.ensure((n_h1 + 3 * n_x + n_f + n_qkv) * sizeof(float)));
+  float* h1 = m->sc->ws.f();
   float* x = d_enc_out;
   float* h = h1 + n_h1;
   float* g = h + n_x;
@@ -103,7 +103,7 @@ extern "C" int ss_batch_encoder_forward(ss_model* m, void* stream, int B, const 
     AttnArgs at;
     at.Q = qkv; at.K = qkv + d; at.V = qkv + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
     at.O = h; at.ldo = d; at.H = c.enc_heads; at.scale = 0.125f; at.chunk = achunk;
-    at.P = m->pos_proj.f() + (size_t)l * d; at.ldp = Ld; at.p_tmax = c.max_rel_pos; at.bias_u = e.u; at.bias_v = e.v;
+    at.P = m->pos_proj + (size_t)l * d; at.ldp = Ld; at.p_tmax = c.max_rel_pos; at.bias_u = e.u; at.bias_v = e.v;
     at.segs = da; at.nseg = B; at.max_q = o2.mx;
     RET(launch_attention(at, s));
     RET(linear(s, h, d, M2, e.out, d, d, x, d, ACT_NONE, 1.f, x, d));
@@ -127,22 +127,22 @@ extern "C" int ss_batch_ctc_greedy(ss_model* m, void* stream, int head, int B, c
                                    const int32_t* h_Tp, int32_t* d_raw, int32_t* d_tokens, int32_t* d_index,
                                    int32_t* d_counts) {
   if (!m || B <= 0 || head < 0 || head > 1) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   CanonScope canon_scope(m->pack_invariant ? CANON_SEQ : CANON_NONE);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const Offsets o = prefix(h_Tp, B);
   const int V = head == 0 ? c.src_vocab : c.tgt_vocab;
-  RET(m->mt_ws.ensure((size_t)o.total * V * sizeof(float)));
-  float* logits = m->mt_ws.f();
+  RET(m->sc->mt_ws.ensure((size_t)o.total * V * sizeof(float)));
+  float* logits = m->sc->mt_ws.f();
   std::vector<int> tr(2 * B);
   for (int b = 0; b < B; ++b) { tr[2 * b] = o.off[b]; tr[2 * b + 1] = h_Tp[b]; }
-  RET(m->seg_buf.ensure(tr.size() * sizeof(int)));
-  RET(upload(s, (int*)m->seg_buf.p, tr));
+  RET(m->sc->seg_buf.ensure(tr.size() * sizeof(int)));
+  RET(upload(s, (int*)m->sc->seg_buf.p, tr));
   RET(linear(s, d_enc_out, c.enc_dim, o.total, head == 0 ? m->ctc_asr : m->ctc_st, V, c.enc_dim, logits, V));
-  m->dbg_logits = logits; m->dbg_rows = o.total; m->dbg_cols = V;
+  m->sc->dbg_logits = logits; m->sc->dbg_rows = o.total; m->sc->dbg_cols = V;
   RET(launch_masked_argmax(logits, V, o.total, V, c.pad, c.unk, -1, -1, d_raw, s));
-  return launch_ctc_collapse(d_raw, 0, 0, c.pad, d_tokens, d_index, d_counts, s, (const int*)m->seg_buf.p, B);
+  return launch_ctc_collapse(d_raw, 0, 0, c.pad, d_tokens, d_index, d_counts, s, (const int*)m->sc->seg_buf.p, B);
 }
 
 // Batched beam-1 search: all utterances start from [</s>] and advance in lockstep, one row per
@@ -151,7 +151,7 @@ extern "C" int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float*
                                   const int32_t* h_max_len, int min_len, int32_t* h_out_tokens, int out_stride,
                                   int32_t* h_n_out, float* d_feats, int feat_rows) {
   if (!m || B <= 0 || B > 128 || !d_feats) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   CanonScope canon_scope(m->pack_invariant ? CANON_SEQ : CANON_NONE);     // cross K|V over the packed encoder rows
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
@@ -165,22 +165,22 @@ extern "C" int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float*
   if (Lcap > feat_rows || Lcap + 2 > c.max_tgt_pos || out_stride < Lmax + 1) return SS_ERR_CAPACITY;
   const Offsets oe = prefix(h_Tp, B);
   // cross-attention K/V for every layer over the packed encoder rows
-  RET(m->mt_cross.ensure((size_t)c.mt_layers * oe.total * 2 * D * sizeof(float)));
+  RET(m->sc->mt_cross.ensure((size_t)c.mt_layers * oe.total * 2 * D * sizeof(float)));
   for (int l = 0; l < c.mt_layers; ++l)
     RET(linear(s, d_enc_out, c.enc_dim, oe.total, m->mt[l].cross_kv, 2 * D, c.enc_dim,
-               m->mt_cross.f() + (size_t)l * oe.total * 2 * D, 2 * D));
+               m->sc->mt_cross.f() + (size_t)l * oe.total * 2 * D, 2 * D));
   // caches / scratch
-  RET(m->bmt_self.ensure((size_t)c.mt_layers * B * Lcap * 3 * D * sizeof(float)));
-  RET(m->mt_ws.ensure(((size_t)B * (3 * D + F + V)) * sizeof(float)));
-  float* x = m->mt_ws.f();
+  RET(m->sc->bmt_self.ensure((size_t)c.mt_layers * B * Lcap * 3 * D * sizeof(float)));
+  RET(m->sc->mt_ws.ensure(((size_t)B * (3 * D + F + V)) * sizeof(float)));
+  float* x = m->sc->mt_ws.f();
   float* h = x + (size_t)B * D;
   float* q2 = h + (size_t)B * D;
   float* ff = q2 + (size_t)B * D;
   float* logits = ff + (size_t)B * F;
   // int tables: tokens [Lcap+1][B], max_len [B], cross segs [B][4], self segs per step [Lcap][B][4]
   const size_t n_tok = (size_t)(Lcap + 1) * B;
-  RET(m->seg_buf.ensure((n_tok + B + 4 * B + (size_t)Lcap * 4 * B) * sizeof(int)));
-  int* tok = (int*)m->seg_buf.p;
+  RET(m->sc->seg_buf.ensure((n_tok + B + 4 * B + (size_t)Lcap * 4 * B) * sizeof(int)));
+  int* tok = (int*)m->sc->seg_buf.p;
   int* d_maxlen = tok + n_tok;
   int* d_cross = d_maxlen + B;
   int* d_self = d_cross + 4 * B;
@@ -206,14 +206,14 @@ extern "C" int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float*
     // feed position `step` of every utterance
     RET(launch_embed_tokens(tok + (size_t)step * B, m->mt_emb, m->mt_pos, sqrtf((float)D), step + c.pad + 1, x, B, D, s, 0, -1, c.tgt_vocab));
     for (int l = 0; l < c.mt_layers; ++l) {
-      float* cache = m->bmt_self.f() + (size_t)l * B * Lcap * 3 * D;
+      float* cache = m->sc->bmt_self.f() + (size_t)l * B * Lcap * 3 * D;
       float* rows = cache + (size_t)step * 3 * D;                    // row b at + b*Lcap*3D
       AttnArgs at;
       at.Q = rows; at.ldq = Lcap * 3 * D; at.K = cache + D; at.V = cache + 2 * D; at.ldk = at.ldv = 3 * D;
       at.O = h; at.ldo = D; at.H = H; at.scale = 1.f; at.causal = 0;   // cache holds exactly the visible keys
       at.segs = d_self + (size_t)step * 4 * B; at.nseg = B; at.max_q = 1;
       AttnArgs ac;
-      ac.Q = q2; ac.ldq = D; ac.K = m->mt_cross.f() + (size_t)l * oe.total * 2 * D; ac.V = ac.K + D; ac.ldk = ac.ldv = 2 * D;
+      ac.Q = q2; ac.ldq = D; ac.K = m->sc->mt_cross.f() + (size_t)l * oe.total * 2 * D; ac.V = ac.K + D; ac.ldk = ac.ldv = 2 * D;
       ac.O = h; ac.ldo = D; ac.H = H; ac.scale = 1.f; ac.segs = d_cross; ac.nseg = B; ac.max_q = 1;
       RET(dec_layer_ex(s, c, m->mt[l], x, B, rows, Lcap * 3 * D, at, &ac, h, q2, ff));
     }
@@ -251,7 +251,7 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
                                   const int32_t* h_n, int t2u_causal, int mask_eos, int32_t* d_raw, int32_t* d_tokens,
                                   int32_t* d_counts) {
   if (!m || B <= 0) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   CanonScope canon_scope(m->pack_invariant ? CANON_SEQ : CANON_NONE);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
@@ -261,9 +261,9 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
   const Offsets on = prefix(h_n, B);
   const int Nn = on.total, U = Nn * up;
   const size_t nx = (size_t)U * D;
-  RET(m->ws.ensure((3 * nx + (size_t)U * 3 * D + (size_t)U * F + (size_t)Nn * 2 * D + (size_t)Nn * D +
+  RET(m->sc->ws.ensure((3 * nx + (size_t)U * 3 * D + (size_t)U * F + (size_t)Nn * 2 * D + (size_t)Nn * D +
                     (size_t)U * V + (size_t)U) * sizeof(float)));
-  float* x = m->ws.f();
+  float* x = m->sc->ws.f();
   float* h = x + nx;
   float* q2 = h + nx;
   float* selfbuf = q2 + nx;
@@ -282,8 +282,8 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
     int* x2 = &tab[8 * B + 4 * b]; x2[0] = o * up; x2[1] = n * up; x2[2] = o; x2[3] = n;
     tab[12 * B + 2 * b] = o * up; tab[12 * B + 2 * b + 1] = n * up;
   }
-  RET(m->seg_buf.ensure(tab.size() * sizeof(int)));
-  int* dt = (int*)m->seg_buf.p;
+  RET(m->sc->seg_buf.ensure(tab.size() * sizeof(int)));
+  int* dt = (int*)m->sc->seg_buf.p;
   RET(upload(s, dt, tab));
   // gather the decoder states of each utterance into packed rows: ONE launch (round 4 issued B device-to-device copies per pack --
   // 2975 __amd_rocclr_copyBuffer launches, 1 % of the one-stream kernel time and 64 more dependent launches per pack)
@@ -314,7 +314,7 @@ extern "C" int ss_batch_t2u_units(ss_model* m, void* stream, int B, const float*
   }
   RET(launch_layernorm(x, D, h, D, m->unit_ln.g, m->unit_ln.b, U, D, 1e-5f, s));
   RET(linear(s, h, D, U, m->unit_out, V, D, logits, V));
-  m->dbg_logits = logits; m->dbg_rows = U; m->dbg_cols = V;
+  m->sc->dbg_logits = logits; m->sc->dbg_rows = U; m->sc->dbg_cols = V;
   RET(launch_masked_argmax(logits, V, U, V, c.pad, c.unk, mask_eos ? c.eos : -1, -1, d_raw, s));
   return launch_ctc_collapse(d_raw, 0, V - 1, c.pad, d_tokens, idx_scratch, d_counts, s, dt + 12 * B, B);
 }

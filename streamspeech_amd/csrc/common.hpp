@@ -12,6 +12,7 @@
 #define SS_ERR_ARG 2
 #define SS_ERR_MISSING_WEIGHT 3
 #define SS_ERR_CAPACITY 4
+#define SS_ERR_SCRATCH_CAP 5       // a scratch buffer would have to grow past the cap set with ss_scratch_set_cap
 
 #define SS_HIP_CHECK(expr)                                                              \
   do {                                                                                  \

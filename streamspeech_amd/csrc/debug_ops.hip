@@ -31,10 +31,10 @@ extern "C" int ss_op_conv_gemm(void* stream, const float* dA, int lda, const flo
 
 extern "C" int ss_debug_last_logits(ss_model* m, void* stream, float* d_out, int64_t cap_floats, int* h_rows, int* h_cols) {
   if (!m || !h_rows || !h_cols) return SS_ERR_ARG;
-  *h_rows = m->dbg_rows; *h_cols = m->dbg_cols;
+  *h_rows = m->sc->dbg_rows; *h_cols = m->sc->dbg_cols;
   if (!d_out) return SS_OK;                                   // size query
-  if (!m->dbg_logits || cap_floats < (int64_t)m->dbg_rows * m->dbg_cols) return SS_ERR_CAPACITY;
-  SS_HIP_CHECK(hipMemcpyAsync(d_out, m->dbg_logits, (size_t)m->dbg_rows * m->dbg_cols * sizeof(float), hipMemcpyDeviceToDevice,
+  if (!m->sc->dbg_logits || cap_floats < (int64_t)m->sc->dbg_rows * m->sc->dbg_cols) return SS_ERR_CAPACITY;
+  SS_HIP_CHECK(hipMemcpyAsync(d_out, m->sc->dbg_logits, (size_t)m->sc->dbg_rows * m->sc->dbg_cols * sizeof(float), hipMemcpyDeviceToDevice,
                               (hipStream_t)stream));
   return SS_OK;
 }

@@ -39,8 +39,8 @@ struct Dispatch {
   // rtlin.hip
   int rt_off = 0, rt_min_rows = 193, rt_force_g = 0;   // SS_NO_RTLIN, SS_RTLIN_MIN_ROWS, ss_debug_rtlin
   long long rt_min_units = 4000;                       // SS_RTLIN_MIN_UNITS
-  long long rt_kb_min_units = 768;                     // SS_RTLIN_KB_MIN_UNITS: (48-row tile, 256-column group) units from which rt_linear_kb takes a K > 256 linear
-  int rt_kb_uw = 4;                                    // SS_RTLIN_KB_UW: 16-column units per wave and column group (4: 256-column groups, 3 workgroups per CU; 8: 512, 2)
+  long long rt_kb_min_units = 256;                     // SS_RTLIN_KB_MIN_UNITS: (48-row tile, 64-column group) units from which rt_linear_kb takes a K > 256 linear
+  int rt_kb_uw = 0;                                    // SS_RTLIN_KB_UW: 16-column units per wave and column group (0: by the launch's unit count; 1 / 2 / 4 force)
 };
 
 // The calling thread's settings: the scoped context's private copy, else this thread's own copy of the process settings.

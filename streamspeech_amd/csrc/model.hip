@@ -27,6 +27,19 @@ static int load_dec_layers(ss_model* m, std::vector<DecLayer>& v, const std::str
   return SS_OK;
 }
 
+// The projected rel-pos table is a function of the weight blob alone: handles made over the same blob (one per language AND stream
+// since scratch sets are separate objects) borrow one buffer instead of 67 MB each.  Keyed by (device, table slot, projection slot,
+// shape), ref-counted -- the same scheme as the vocoder's Winograd weights (vocoder.hip).
+namespace {
+struct PosShared { DevBuf buf; int refs = 0; };
+struct PosKey {
+  int dev; const float* table; const float* w; int rows, cols;
+  bool operator<(const PosKey& o) const { return std::tie(dev, table, w, rows, cols) < std::tie(o.dev, o.table, o.w, o.rows, o.cols); }
+};
+std::mutex g_pos_mu;
+std::map<PosKey, PosShared> g_pos;
+}  // namespace
+
 extern "C" int ss_abi_version(void) { return SS_ABI_VERSION; }
 
 extern "C" const char* ss_error_string(int code) {
@@ -36,6 +49,7 @@ extern "C" const char* ss_error_string(int code) {
     case SS_ERR_ARG: return "invalid argument";
     case SS_ERR_MISSING_WEIGHT: return "weight slot missing or wrong size";
     case SS_ERR_CAPACITY: return "output capacity too small";
+    case SS_ERR_SCRATCH_CAP: return "scratch set would grow past its cap (ss_scratch_set_cap)";
     default: return "unknown error";
   }
 }
@@ -47,10 +61,10 @@ extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t
   if (cfg->enc_dim / cfg->enc_heads != 64 || cfg->dec_dim / cfg->dec_heads != 64) return SS_ERR_ARG;
   ss_model* m = new ss_model();
   m->cfg = *cfg;
-  m->skws = sk_workspace_new();
-  SkScope sk_scope(m->skws);       // the pos_proj GEMM below may take a stream-K kernel
+  m->sc = new ss_scratch();            // the handle's own scratch set; ss_model_bind_scratch swaps it for a shared one
+  SkScope sk_scope(m->sc->skws);       // the pos_proj GEMM below may take a stream-K kernel
   int rc = m->wt.build(d_blob, blob_floats, names, offsets, numels, n_slots);
-  if (rc != SS_OK) { sk_workspace_free(m->skws); delete m; return rc; }
+  if (rc != SS_OK) { ss_model_destroy(m); return rc; }
   WeightTable& w = m->wt;
   const int d = cfg->enc_dim, f = cfg->enc_ffn, D = cfg->dec_dim, F = cfg->dec_ffn, k = cfg->conv_kernel;
   const int Tm = cfg->max_rel_pos;
@@ -100,22 +114,30 @@ extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t
   m->unit_ln = {w.get("unit.ln.g", D), w.get("unit.ln.b", D)};
   m->unit_out = {w.get("unit.out.w", (int64_t)cfg->unit_vocab * D), nullptr};
   m->unit_pos_row = w.get("unit.pos_row", D);
-  if (!w.missing.empty()) { sk_workspace_free(m->skws); delete m; return SS_ERR_MISSING_WEIGHT; }
+  if (!w.missing.empty()) { ss_model_destroy(m); return SS_ERR_MISSING_WEIGHT; }
 
   // projected rel-pos table for every layer at once: [2Tm-1, d] x [L*d, d]^T (linear_pos has no
   // bias, espnet_multihead_attention.py:125).  Depends only on the relative offset, so it is
   // computed once here and sliced per utterance.
   const int rows = 2 * Tm - 1, Ld = cfg->enc_layers * d;
-  rc = m->pos_proj.ensure((size_t)rows * Ld * sizeof(float));
-  if (rc == SS_OK) {
-    Lin lp{m->pos_w, nullptr};
-    rc = linear(nullptr, m->pos_table, d, rows, lp, Ld, d, m->pos_proj.f(), Ld);
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { ss_model_destroy(m); return SS_ERR_HIP; }
+    std::lock_guard<std::mutex> lk(g_pos_mu);        // (held over the GEMM: a second handle over the same blob waits for it)
+    const PosKey key{dev, m->pos_table, m->pos_w, rows, Ld};
+    PosShared& sh = g_pos[key];
+    if (sh.refs == 0) {
+      rc = sh.buf.ensure((size_t)rows * Ld * sizeof(float));
+      if (rc == SS_OK) {
+        Lin lp{m->pos_w, nullptr};
+        rc = linear(nullptr, m->pos_table, d, rows, lp, Ld, d, sh.buf.f(), Ld);
+      }
+      if (rc == SS_OK && hipDeviceSynchronize() != hipSuccess) rc = SS_ERR_HIP;
+      if (rc != SS_OK) { sh.buf.release(); g_pos.erase(key); }
+    }
+    if (rc == SS_OK) { ++sh.refs; m->pos_proj = sh.buf.f(); m->pos_key_dev = dev; }
   }
-  if (rc == SS_OK && hipDeviceSynchronize() != hipSuccess) rc = SS_ERR_HIP;
-  if (rc == SS_OK) rc = m->mt_self.ensure((size_t)cfg->mt_layers * cfg->max_tgt_pos * 3 * D * sizeof(float));
-  if (rc == SS_OK) rc = m->mt_tok.ensure((size_t)cfg->max_tgt_pos * sizeof(int32_t));
-  if (rc == SS_OK && hipHostMalloc((void**)&m->mt_tok_host, (size_t)cfg->max_tgt_pos * sizeof(int32_t)) != hipSuccess)
-    rc = SS_ERR_HIP;
+  if (rc == SS_OK) rc = scratch_fit_model(m->sc, *cfg);
   if (rc != SS_OK) { ss_model_destroy(m); return rc; }
   *out = m;
   return SS_OK;
@@ -123,12 +145,56 @@ extern "C" int ss_model_create(const ss_config* cfg, const float* d_blob, size_t
 
 extern "C" void ss_model_destroy(ss_model* m) {
   if (!m) return;
-  m->pos_proj.release(); m->ws.release(); m->mt_cross.release(); m->mt_self.release(); m->mt_ws.release();
-  m->mt_tok.release(); m->seg_buf.release(); m->bmt_self.release(); m->mt_gran.release(); m->attn_split.release();
-  m->es_qkv.release(); m->es_glu.release(); m->es_out.release();
-  if (m->mt_tok_host) (void)hipHostFree(m->mt_tok_host);
-  sk_workspace_free(m->skws);
+  if (m->pos_proj) {
+    std::lock_guard<std::mutex> lk(g_pos_mu);
+    for (auto it = g_pos.begin(); it != g_pos.end(); ++it)
+      if (it->first.dev == m->pos_key_dev && it->second.buf.f() == m->pos_proj) {
+        if (--it->second.refs == 0) { it->second.buf.release(); g_pos.erase(it); }
+        break;
+      }
+  }
+  scratch_unref(m->sc);
   delete m;
+}
+
+// ---- scratch sets (see ss_scratch in model_internal.hpp) -------------------------------------------------------------------------
+extern "C" int ss_scratch_create(ss_scratch** out) {
+  if (!out) return SS_ERR_ARG;
+  *out = new ss_scratch();
+  return SS_OK;
+}
+extern "C" void ss_scratch_destroy(ss_scratch* sc) { scratch_unref(sc); }
+extern "C" int ss_scratch_set_cap(ss_scratch* sc, size_t max_bytes) {
+  if (!sc) return SS_ERR_ARG;
+  sc->acct.cap = max_bytes;
+  return SS_OK;
+}
+extern "C" size_t ss_scratch_bytes(ss_scratch* sc) { return sc ? sc->acct.used : 0; }
+extern "C" int ss_scratch_trim(ss_scratch* sc, size_t keep_bytes) {
+  if (!sc) return SS_ERR_ARG;
+  SS_HIP_CHECK(hipDeviceSynchronize());              // nothing queued may still read what is let go
+  std::vector<DevBuf*> bufs = sc->trimmable();
+  std::sort(bufs.begin(), bufs.end(), [](const DevBuf* a, const DevBuf* b) { return a->bytes > b->bytes; });
+  for (DevBuf* b : bufs) {
+    if (sc->acct.used <= keep_bytes) break;
+    b->release();
+  }
+  // state that lived in the released buffers: a stateful sequence (ss_mt_begin ... ss_mt_append, ss_encoder_stream_*) starts over
+  sc->mt_Tp = 0; sc->mt_len = 0; sc->mt_enc = nullptr;
+  sc->es_cap = 0; sc->es_final = 0; sc->es_achunk = sc->es_cchunk = -1;
+  sc->dbg_logits = nullptr; sc->dbg_rows = sc->dbg_cols = 0;
+  return SS_OK;
+}
+extern "C" int ss_model_bind_scratch(ss_model* m, ss_scratch* sc) {
+  if (!m || !sc) return SS_ERR_ARG;
+  int rc = scratch_fit_model(sc, m->cfg);
+  if (rc != SS_OK) return rc;
+  if (sc != m->sc) {
+    sc->refs.fetch_add(1);
+    scratch_unref(m->sc);
+    m->sc = sc;
+  }
+  return SS_OK;
 }
 
 // ---- front-end ---------------------------------------------------------------------------------
@@ -169,7 +235,7 @@ extern "C" int ss_encoder_out_len(int T) {
 extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
                                   int conv_chunk, float* d_enc_out) {
   if (!m || T <= 0) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int d = c.enc_dim, f = c.enc_ffn, k = c.conv_kernel, Ld = c.enc_layers * d;
@@ -181,8 +247,8 @@ extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fban
   // scratch layout (floats)
   const size_t n_h1 = (size_t)T1 * (c.conv_channels / 2);
   const size_t n_x = (size_t)T2 * d, n_f = (size_t)T2 * f, n_qkv = (size_t)T2 * 3 * d;
-  RET(m->ws.ensure((n_h1 + 3 * n_x + n_f + n_qkv) * sizeof(float)));
-  float* h1 = m->ws.f();
+  RET(m->sc->ws.ensure((n_h1 + 3 * n_x + n_f + n_qkv) * sizeof(float)));
+  float* h1 = m->sc->ws.f();
   float* x = d_enc_out;                 // running activations live in the output buffer
   float* h = h1 + n_h1;                 // LN output / attention context
   float* g = h + n_x;                   // GLU output / misc
@@ -205,7 +271,7 @@ extern "C" int ss_encoder_forward(ss_model* m, void* stream, const float* d_fban
   }
   // x = Linear(sqrt(d) * x)  -- the sqrt(d)=16 scale is folded (exactly) into enc.linear.w
   RET(linear(s, g, d, T2, m->enc_linear, d, d, x, d));
-  const float* P = m->pos_proj.f() + (size_t)(c.max_rel_pos - T2) * Ld;
+  const float* P = m->pos_proj + (size_t)(c.max_rel_pos - T2) * Ld;
 
   for (int l = 0; l < c.enc_layers; ++l) {
     const EncLayer& e = m->enc[l];
@@ -277,20 +343,20 @@ static int stream_final_rows(int T, int T1, int T2, int k, int achunk, int cchun
 
 extern "C" int ss_encoder_stream_reset(ss_model* m) {
   if (!m) return SS_ERR_ARG;
-  m->es_final = 0; m->es_achunk = -1; m->es_cchunk = -1;
+  m->sc->es_final = 0; m->sc->es_achunk = -1; m->sc->es_cchunk = -1;
   return SS_OK;
 }
 
 extern "C" int ss_encoder_stream_set_tail(ss_model* m, int unsettled_fbank_frames) {
   if (!m || unsettled_fbank_frames < 0) return SS_ERR_ARG;
-  m->es_tail = unsettled_fbank_frames;
+  m->sc->es_tail = unsettled_fbank_frames;
   return SS_OK;
 }
 
 extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
                                          int conv_chunk, float* d_enc_out, int32_t* n_final, int32_t* n_computed) {
   if (!m || T <= 0) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int d = c.enc_dim, f = c.enc_ffn, k = c.conv_kernel, Ld = c.enc_layers * d, L = c.enc_layers;
@@ -299,38 +365,38 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
   const int cchunk = (conv_chunk > 0 && conv_chunk < 999) ? conv_chunk : 0;
   const int achunk_cfg = (attn_chunk > 0 && attn_chunk < 999999) ? attn_chunk : 0;   // as configured (not clipped by T2)
   const int achunk = (achunk_cfg > 0 && achunk_cfg < T2) ? achunk_cfg : 0;
-  if (m->es_achunk != achunk_cfg || m->es_cchunk != cchunk) { m->es_final = 0; m->es_achunk = achunk_cfg; m->es_cchunk = cchunk; }
-  if (m->es_final > T2) m->es_final = 0;           // audio got shorter: a new utterance without reset
-  if (m->es_cap < T2) {                             // grow (contents are only needed below es_final: keep them)
+  if (m->sc->es_achunk != achunk_cfg || m->sc->es_cchunk != cchunk) { m->sc->es_final = 0; m->sc->es_achunk = achunk_cfg; m->sc->es_cchunk = cchunk; }
+  if (m->sc->es_final > T2) m->sc->es_final = 0;           // audio got shorter: a new utterance without reset
+  if (m->sc->es_cap < T2) {                             // grow (contents are only needed below es_final: keep them)
     const int cap = std::min(c.max_rel_pos, std::max(2 * T2, 256));
     DevBuf nq, ng, no;
     RET(nq.ensure((size_t)L * cap * 3 * d * sizeof(float)));
     RET(ng.ensure((size_t)L * cap * d * sizeof(float)));
     RET(no.ensure((size_t)cap * d * sizeof(float)));
-    if (m->es_final > 0) {
+    if (m->sc->es_final > 0) {
       for (int l = 0; l < L; ++l) {
-        SS_HIP_CHECK(hipMemcpyAsync(nq.f() + (size_t)l * cap * 3 * d, m->es_qkv.f() + (size_t)l * m->es_cap * 3 * d,
-                                    (size_t)m->es_final * 3 * d * sizeof(float), hipMemcpyDeviceToDevice, s));
-        SS_HIP_CHECK(hipMemcpyAsync(ng.f() + (size_t)l * cap * d, m->es_glu.f() + (size_t)l * m->es_cap * d,
-                                    (size_t)m->es_final * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+        SS_HIP_CHECK(hipMemcpyAsync(nq.f() + (size_t)l * cap * 3 * d, m->sc->es_qkv.f() + (size_t)l * m->sc->es_cap * 3 * d,
+                                    (size_t)m->sc->es_final * 3 * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+        SS_HIP_CHECK(hipMemcpyAsync(ng.f() + (size_t)l * cap * d, m->sc->es_glu.f() + (size_t)l * m->sc->es_cap * d,
+                                    (size_t)m->sc->es_final * d * sizeof(float), hipMemcpyDeviceToDevice, s));
       }
-      SS_HIP_CHECK(hipMemcpyAsync(no.f(), m->es_out.f(), (size_t)m->es_final * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+      SS_HIP_CHECK(hipMemcpyAsync(no.f(), m->sc->es_out.f(), (size_t)m->sc->es_final * d * sizeof(float), hipMemcpyDeviceToDevice, s));
       SS_HIP_CHECK(hipStreamSynchronize(s));
     }
-    m->es_qkv.release(); m->es_glu.release(); m->es_out.release();
-    m->es_qkv = nq; m->es_glu = ng; m->es_out = no;
+    m->sc->es_qkv.release(); m->sc->es_glu.release(); m->sc->es_out.release();
+    m->sc->es_qkv = nq; m->sc->es_glu = ng; m->sc->es_out = no;
     nq.p = nullptr; ng.p = nullptr; no.p = nullptr;
-    m->es_cap = cap;
+    m->sc->es_cap = cap;
   }
-  const int cap = m->es_cap;
-  const int r0 = m->es_final;                       // first row to (re)compute
+  const int cap = m->sc->es_cap;
+  const int r0 = m->sc->es_final;                       // first row to (re)compute
   const int n = T2 - r0;
   if (n_computed) *n_computed = n;
 
   const size_t n_h1 = (size_t)T1 * (c.conv_channels / 2);
   const size_t n_x = (size_t)T2 * d, n_f = (size_t)n * f;
-  RET(m->ws.ensure((n_h1 + 3 * n_x + n_f) * sizeof(float)));
-  float* h1 = m->ws.f();
+  RET(m->sc->ws.ensure((n_h1 + 3 * n_x + n_f) * sizeof(float)));
+  float* h1 = m->sc->ws.f();
   float* g0 = h1 + n_h1;                // subsampler output [T2, d]
   float* h = g0 + n_x;                  // LN output / attention context (tail rows, indexed from 0)
   float* g2 = h + n_x;                  // depthwise output, absolute rows
@@ -350,14 +416,14 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
     RET(launch_conv_gemm(b, s));
   }
   if (r0 > 0)
-    SS_HIP_CHECK(hipMemcpyAsync(d_enc_out, m->es_out.f(), (size_t)r0 * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+    SS_HIP_CHECK(hipMemcpyAsync(d_enc_out, m->sc->es_out.f(), (size_t)r0 * d * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (n > 0) {
     RET(linear(s, g0 + (size_t)r0 * d, d, n, m->enc_linear, d, d, x, d));
-    const float* P = m->pos_proj.f() + (size_t)(c.max_rel_pos - T2) * Ld;
+    const float* P = m->pos_proj + (size_t)(c.max_rel_pos - T2) * Ld;
     for (int l = 0; l < L; ++l) {
       const EncLayer& e = m->enc[l];
-      float* qkv = m->es_qkv.f() + (size_t)l * cap * 3 * d;      // absolute rows
-      float* glu = m->es_glu.f() + (size_t)l * cap * d;
+      float* qkv = m->sc->es_qkv.f() + (size_t)l * cap * 3 * d;      // absolute rows
+      float* glu = m->sc->es_glu.f() + (size_t)l * cap * d;
       RET(ln_linear(s, x, n, e.ffn1_ln, e.ffn1_w1, f, d, ff, f, h, ACT_SILU));
       RET(linear(s, ff, f, n, e.ffn1_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
       RET(ln_linear(s, x, n, e.attn_ln, e.qkv, 3 * d, d, qkv + (size_t)r0 * 3 * d, 3 * d, h));
@@ -377,11 +443,11 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
       RET(layernorm(s, x, x, e.final_ln, n, d));
     }
   }
-  const int nf = std::max(r0, stream_final_rows(T, T1, T2, k, achunk_cfg, cchunk, c.dw_kernel, m->es_tail));
+  const int nf = std::max(r0, stream_final_rows(T, T1, T2, k, achunk_cfg, cchunk, c.dw_kernel, m->sc->es_tail));
   if (nf > r0)
-    SS_HIP_CHECK(hipMemcpyAsync(m->es_out.f() + (size_t)r0 * d, d_enc_out + (size_t)r0 * d, (size_t)(nf - r0) * d * sizeof(float),
+    SS_HIP_CHECK(hipMemcpyAsync(m->sc->es_out.f() + (size_t)r0 * d, d_enc_out + (size_t)r0 * d, (size_t)(nf - r0) * d * sizeof(float),
                                 hipMemcpyDeviceToDevice, s));
-  m->es_final = nf;
+  m->sc->es_final = nf;
   if (n_final) *n_final = nf;
   return SS_OK;
 }
@@ -391,14 +457,14 @@ extern "C" int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d
                              int32_t* d_raw, int32_t* d_tokens, int32_t* d_index, int32_t* d_count,
                              float* d_logits) {
   if (!m || Tp <= 0 || head < 0 || head > 1) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int V = head == 0 ? c.src_vocab : c.tgt_vocab;
   float* logits = d_logits;
   if (!logits) {
-    RET(m->mt_ws.ensure((size_t)Tp * V * sizeof(float)));
-    logits = m->mt_ws.f();
+    RET(m->sc->mt_ws.ensure((size_t)Tp * V * sizeof(float)));
+    logits = m->sc->mt_ws.f();
   }
   RET(linear(s, d_enc_out, c.enc_dim, Tp, head == 0 ? m->ctc_asr : m->ctc_st, V, c.enc_dim, logits, V));
   RET(launch_masked_argmax(logits, V, Tp, V, c.pad, c.unk, -1, -1, d_raw, s));
@@ -407,17 +473,17 @@ extern "C" int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d
 
 extern "C" int ss_mt_begin(ss_model* m, void* stream, const float* d_enc_out, int Tp) {
   if (!m || Tp <= 0) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int D = c.dec_dim;
-  RET(m->mt_cross.ensure((size_t)c.mt_layers * Tp * 2 * D * sizeof(float)));
+  RET(m->sc->mt_cross.ensure((size_t)c.mt_layers * Tp * 2 * D * sizeof(float)));
   for (int l = 0; l < c.mt_layers; ++l)
     RET(linear(s, d_enc_out, c.enc_dim, Tp, m->mt[l].cross_kv, 2 * D, c.enc_dim,
-               m->mt_cross.f() + (size_t)l * Tp * 2 * D, 2 * D));
-  m->mt_Tp = Tp;
-  m->mt_len = 0;
-  m->mt_enc = d_enc_out;
+               m->sc->mt_cross.f() + (size_t)l * Tp * 2 * D, 2 * D));
+  m->sc->mt_Tp = Tp;
+  m->sc->mt_len = 0;
+  m->sc->mt_enc = d_enc_out;
   return SS_OK;
 }
 
@@ -427,13 +493,13 @@ extern "C" int ss_mt_begin(ss_model* m, void* stream, const float* d_enc_out, in
 // the persistent form is switched (which both fall-back paths do).
 std::atomic<int> g_mt_timeouts{0};
 static unsigned* mt_err_word(ss_model* m) {
-  return reinterpret_cast<unsigned*>(static_cast<char*>(m->mt_gran.p) + mt_step_granule_bytes() + 16);
+  return reinterpret_cast<unsigned*>(static_cast<char*>(m->sc->mt_gran.p) + mt_step_granule_bytes() + 16);
 }
 static int mt_collect_errors(ss_model* m) {
-  if (!m->mt_gran.p) return SS_OK;
+  if (!m->sc->mt_gran.p) return SS_OK;
   // on the stream the persistent step was last launched on (torch streams are non-blocking: the legacy null stream orders
   // nothing against them -- ADVICE r4): the read sees every earlier launch's error word, the clear lands before any later one
-  hipStream_t s = m->mt_last_stream;
+  hipStream_t s = m->sc->mt_last_stream;
   unsigned e = 0;
   SS_HIP_CHECK(hipMemcpyAsync(&e, mt_err_word(m), sizeof(e), hipMemcpyDeviceToHost, s));
   SS_HIP_CHECK(hipStreamSynchronize(s));
@@ -447,22 +513,22 @@ static int mt_collect_errors(ss_model* m) {
 
 extern "C" int ss_mt_set_persistent(ss_model* m, int workgroups) {
   if (!m || !(workgroups == 0 || workgroups == 64 || workgroups == 128 || workgroups == 256)) return SS_ERR_ARG;
-  if (m->mt_persistent > 0) RET(mt_collect_errors(m));
-  m->mt_persistent = workgroups;
+  if (m->sc->mt_persistent > 0) RET(mt_collect_errors(m));
+  m->sc->mt_persistent = workgroups;
   return SS_OK;
 }
 
-extern "C" int ss_mt_get_persistent(ss_model* m) { return m ? m->mt_persistent : SS_ERR_ARG; }
+extern "C" int ss_mt_get_persistent(ss_model* m) { return m ? m->sc->mt_persistent : SS_ERR_ARG; }
 
 extern "C" int ss_debug_mt_inject_timeout(ss_model* m) {
   if (!m) return SS_ERR_ARG;
-  m->mt_inject_timeout = 1;
+  m->sc->mt_inject_timeout = 1;
   return SS_OK;
 }
 
 extern "C" int ss_mt_truncate(ss_model* m, int len) {
-  if (!m || len < 0 || len > m->mt_len) return SS_ERR_ARG;
-  m->mt_len = len;
+  if (!m || len < 0 || len > m->sc->mt_len) return SS_ERR_ARG;
+  m->sc->mt_len = len;
   return SS_OK;
 }
 
@@ -477,38 +543,38 @@ static int mt_step_args(ss_model* m, MtStepArgs& a, float* scratch_feats) {
     w.ln1_g = L.self_ln.g; w.ln1_b = L.self_ln.b; w.wqkv = L.self_qkv.w; w.bqkv = L.self_qkv.b; w.wo = L.self_out.w; w.bo = L.self_out.b;
     w.ln2_g = L.cross_ln.g; w.ln2_b = L.cross_ln.b; w.wcq = L.cross_q.w; w.bcq = L.cross_q.b; w.wco = L.cross_out.w; w.bco = L.cross_out.b;
     w.ln3_g = L.ffn_ln.g; w.ln3_b = L.ffn_ln.b; w.w1 = L.fc1.w; w.b1 = L.fc1.b; w.w2 = L.fc2.w; w.b2 = L.fc2.b;
-    w.selfbuf = m->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
-    w.cross = m->mt_cross.f() + (size_t)l * m->mt_Tp * 2 * D;
+    w.selfbuf = m->sc->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
+    w.cross = m->sc->mt_cross.f() + (size_t)l * m->sc->mt_Tp * 2 * D;
   }
   a.lnf_g = m->mt_ln.g; a.lnf_b = m->mt_ln.b; a.emb = m->mt_emb; a.pos_table = m->mt_pos;
   a.feats = scratch_feats;
-  a.gran = reinterpret_cast<mt_u64*>(m->mt_gran.p); a.err = mt_err_word(m);
-  a.Tp = m->mt_Tp; a.V = c.tgt_vocab; a.pad = c.pad; a.eos = c.eos;
+  a.gran = reinterpret_cast<mt_u64*>(m->sc->mt_gran.p); a.err = mt_err_word(m);
+  a.Tp = m->sc->mt_Tp; a.V = c.tgt_vocab; a.pad = c.pad; a.eos = c.eos;
   a.emb_scale = sqrtf((float)D);
   return SS_OK;
 }
 // n consecutive epochs for a launch of n steps (0 is what a fresh granule holds: skipped)
 static unsigned mt_next_epochs(ss_model* m, int n) {
-  if (m->mt_epoch + (unsigned)n + 1u < m->mt_epoch || m->mt_epoch == 0u) m->mt_epoch = 0u;      // wrap: start over above 0
-  const unsigned first = m->mt_epoch + 1u;
-  m->mt_epoch += (unsigned)n;
+  if (m->sc->mt_epoch + (unsigned)n + 1u < m->sc->mt_epoch || m->sc->mt_epoch == 0u) m->sc->mt_epoch = 0u;      // wrap: start over above 0
+  const unsigned first = m->sc->mt_epoch + 1u;
+  m->sc->mt_epoch += (unsigned)n;
   return first;
 }
 static int mt_inject(ss_model* m, MtStepArgs& a, hipStream_t s) {      // test hook: this one launch sees a time-out that already happened
-  if (!m->mt_inject_timeout) return SS_OK;
-  m->mt_inject_timeout = 0;
-  a.err = reinterpret_cast<unsigned*>(static_cast<char*>(m->mt_gran.p) + mt_step_granule_bytes());
+  if (!m->sc->mt_inject_timeout) return SS_OK;
+  m->sc->mt_inject_timeout = 0;
+  a.err = reinterpret_cast<unsigned*>(static_cast<char*>(m->sc->mt_gran.p) + mt_step_granule_bytes());
   SS_HIP_CHECK(hipMemsetAsync(a.err, 0x01, sizeof(unsigned), s));
   return SS_OK;
 }
 static bool mt_persistent_ok(const ss_model* m) {
   const ss_config& c = m->cfg;
-  return m->mt_persistent > 0 && c.mt_layers == MT_L && c.dec_dim == MT_D && c.dec_ffn == MT_F && c.dec_heads == MT_H;
+  return m->sc->mt_persistent > 0 && c.mt_layers == MT_L && c.dec_dim == MT_D && c.dec_ffn == MT_F && c.dec_heads == MT_H;
 }
 static int mt_gran_ensure(ss_model* m, hipStream_t s) {
-  if (!m->mt_gran.p) {
-    RET(m->mt_gran.ensure(mt_step_granule_bytes() + 64));   // + one spare error word (ss_debug_mt_inject_timeout) + the step's own
-    SS_HIP_CHECK(hipMemsetAsync(m->mt_gran.p, 0, mt_step_granule_bytes() + 64, s));
+  if (!m->sc->mt_gran.p) {
+    RET(m->sc->mt_gran.ensure(mt_step_granule_bytes() + 64));   // + one spare error word (ss_debug_mt_inject_timeout) + the step's own
+    SS_HIP_CHECK(hipMemsetAsync(m->sc->mt_gran.p, 0, mt_step_granule_bytes() + 64, s));
     SS_HIP_CHECK(hipStreamSynchronize(s));
   }
   return SS_OK;
@@ -516,14 +582,14 @@ static int mt_gran_ensure(ss_model* m, hipStream_t s) {
 
 extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, int n, int pos0, int ban_eos,
                             int force_eos, float* d_feats, int32_t* d_next, int n_tail_pad) {
-  if (!m || n <= 0 || pos0 < 0 || pos0 > m->mt_len || m->mt_Tp <= 0) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  if (!m || n <= 0 || pos0 < 0 || pos0 > m->sc->mt_len || m->sc->mt_Tp <= 0) return SS_ERR_ARG;
+  SkScope sk_scope(m->sc->skws);
   const ss_config& c = m->cfg;
   if (pos0 + n + 2 > c.max_tgt_pos) return SS_ERR_CAPACITY;
   hipStream_t s = (hipStream_t)stream;
   const int D = c.dec_dim, F = c.dec_ffn, V = c.tgt_vocab;
-  RET(m->mt_ws.ensure(((size_t)n * (4 * D + F) + V) * sizeof(float)));
-  float* x = m->mt_ws.f();
+  RET(m->sc->mt_ws.ensure(((size_t)n * (4 * D + F) + V) * sizeof(float)));
+  float* x = m->sc->mt_ws.f();
   float* h = x + (size_t)n * D;
   float* q2 = h + (size_t)n * D;
   float* feats = q2 + (size_t)n * D;
@@ -540,20 +606,20 @@ extern "C" int ss_mt_append(ss_model* m, void* stream, const int32_t* d_tokens, 
     a.max_len = force_eos ? pos0 : 0x7fffffff;
     RET(mt_inject(m, a, s));
     a.epoch = mt_next_epochs(m, 1);
-    m->mt_last_stream = s;
-    RET(launch_mt_step(a, m->mt_persistent, s));
-    m->mt_len = pos0 + n;
+    m->sc->mt_last_stream = s;
+    RET(launch_mt_step(a, m->sc->mt_persistent, s));
+    m->sc->mt_len = pos0 + n;
     return SS_OK;
   }
   // sqrt(D) * E[tok] + sinusoid(position), positions start at padding_idx + 1 (transformer_decoder.py:297-326)
   RET(launch_embed_tokens(d_tokens, m->mt_emb, m->mt_pos, sqrtf((float)D), pos0 + c.pad + 1, x, n, D, s, 1, c.pad, V));
   for (int l = 0; l < c.mt_layers; ++l) {
-    float* selfbuf = m->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
-    const float* cross = m->mt_cross.f() + (size_t)l * m->mt_Tp * 2 * D;
-    RET(dec_layer(s, c, m->mt[l], x, n, pos0, selfbuf, true, cross, m->mt_Tp, h, q2, ff, n_tail_pad, 0));
+    float* selfbuf = m->sc->mt_self.f() + (size_t)l * c.max_tgt_pos * 3 * D;
+    const float* cross = m->sc->mt_cross.f() + (size_t)l * m->sc->mt_Tp * 2 * D;
+    RET(dec_layer(s, c, m->mt[l], x, n, pos0, selfbuf, true, cross, m->sc->mt_Tp, h, q2, ff, n_tail_pad, 0));
   }
   float* fo = d_feats ? d_feats : feats;
-  m->mt_len = pos0 + n;
+  m->sc->mt_len = pos0 + n;
   Lin proj{m->mt_emb, nullptr};  // tied output projection, no bias
   GemmArgs g;                    // decode step (one new token): final LayerNorm in the prologue of the vocabulary GEMV,
   g.A = x; g.lda = D; g.W = proj.w; g.C = logits; g.ldc = V; g.M = 1; g.N = V; g.Cin = D; g.in_len = 1; g.same_rows = 1;
@@ -578,7 +644,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
                             float* d_feats, int* h_n_feats) {
   if (!m || !d_enc_out || Tp <= 0 || n_prefix < 0 || max_len < n_prefix || !h_out_tokens || !h_n_out || !d_feats)
     return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   const ss_config& c = m->cfg;
   if (max_len + 3 > c.max_tgt_pos) return SS_ERR_CAPACITY;
   for (int i = 0; i < n_prefix; ++i)
@@ -587,8 +653,8 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
   constexpr int kCheck = 4;
   const int D = c.dec_dim;
   RET(ss_mt_begin(m, stream, d_enc_out, Tp));
-  int32_t* tok = reinterpret_cast<int32_t*>(m->mt_tok.p);
-  int32_t* host = m->mt_tok_host;
+  int32_t* tok = reinterpret_cast<int32_t*>(m->sc->mt_tok.p);
+  int32_t* host = m->sc->mt_tok_host;
   host[0] = c.eos;
   for (int i = 0; i < n_prefix; ++i) host[1 + i] = h_prefix[i];
   const int start = n_prefix;
@@ -610,8 +676,8 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
       a.pos0 = first; a.n_steps = n_steps; a.min_len = min_len; a.max_len = max_len; a.search = 1;
       RET(mt_inject(m, a, s));
       a.epoch = mt_next_epochs(m, n_steps);
-      m->mt_last_stream = s;
-      RET(launch_mt_step(a, m->mt_persistent, s));
+      m->sc->mt_last_stream = s;
+      RET(launch_mt_step(a, m->sc->mt_persistent, s));
     }
     const int lo = start + 1, hi = max_len + 1;             // generated tokens live at chain indices lo .. hi
     SS_HIP_CHECK(hipMemcpyAsync(host + lo, tok + lo, (size_t)(hi - lo + 1) * sizeof(int32_t), hipMemcpyDeviceToHost, s));
@@ -620,9 +686,9 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
     for (int i = lo; i <= hi && eos_at < 0; ++i) {
       if (host[i] < 0) {                                    // a bounded wait of the persistent kernel timed out
         fprintf(stderr, "streamspeech_hip: persistent MT decode step timed out (its %d workgroups were not all resident); "
-                        "this context falls back to one launch per op\n", m->mt_persistent);
+                        "this context falls back to one launch per op\n", m->sc->mt_persistent);
         RET(mt_collect_errors(m));
-        m->mt_persistent = 0;
+        m->sc->mt_persistent = 0;
         return ss_mt_greedy(m, stream, d_enc_out, Tp, h_prefix, n_prefix, max_len, min_len, h_out_tokens, h_n_out, d_feats, h_n_feats);
       }
       if (host[i] == c.eos) eos_at = i;
@@ -632,7 +698,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
     for (int i = 0; i < n_out; ++i) h_out_tokens[i] = host[start + 1 + i];
     *h_n_out = n_out;
     if (h_n_feats) *h_n_feats = end;
-    m->mt_len = end;
+    m->sc->mt_len = end;
     return SS_OK;
   }
   // step `start`: feed [eos, prefix...] in one pass
@@ -646,11 +712,11 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
                                   hipMemcpyDeviceToHost, s));
       SS_HIP_CHECK(hipStreamSynchronize(s));
       for (int i = checked; i <= step && eos_at < 0; ++i) {
-        if (host[i] < 0 && m->mt_persistent > 0) {          // mt_step.hip: a bounded wait of the persistent step timed out
+        if (host[i] < 0 && m->sc->mt_persistent > 0) {          // mt_step.hip: a bounded wait of the persistent step timed out
           fprintf(stderr, "streamspeech_hip: persistent MT decode step timed out (its %d workgroups were not all resident); "
-                          "this context falls back to one launch per op\n", m->mt_persistent);
+                          "this context falls back to one launch per op\n", m->sc->mt_persistent);
           RET(mt_collect_errors(m));
-          m->mt_persistent = 0;
+          m->sc->mt_persistent = 0;
           return ss_mt_greedy(m, stream, d_enc_out, Tp, h_prefix, n_prefix, max_len, min_len, h_out_tokens, h_n_out, d_feats,
                               h_n_feats);
         }
@@ -668,7 +734,7 @@ extern "C" int ss_mt_greedy(ss_model* m, void* stream, const float* d_enc_out, i
   for (int i = 0; i < n_out; ++i) h_out_tokens[i] = host[start + 1 + i];
   *h_n_out = n_out;
   if (h_n_feats) *h_n_feats = end;                        // fed positions 0 .. end-1 hold valid features
-  m->mt_len = end;
+  m->sc->mt_len = end;
   return SS_OK;
 }
 
@@ -677,7 +743,7 @@ extern "C" int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, 
                             int mask_eos, int32_t* d_raw, int32_t* d_tokens, int32_t* d_count, float* d_logits,
                             int n_tail_pad) {
   if (!m || n <= 0) return SS_ERR_ARG;
-  SkScope sk_scope(m->skws);
+  SkScope sk_scope(m->sc->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_config& c = m->cfg;
   const int D = c.dec_dim, F = c.dec_ffn, U = n * c.ctc_upsample, V = c.unit_vocab;
@@ -685,8 +751,8 @@ extern "C" int ss_t2u_units(ss_model* m, void* stream, const float* d_mt_feats, 
   // t2u: x,h,self(3D) on n rows; unit: x,h,q2 on U rows, self 3D on U rows, ff U*F, cross kv n*2D, logits U*V
   const size_t total = 3 * nx + (size_t)U * 3 * D + (size_t)U * F + (size_t)n * 2 * D + (size_t)n * D +
                        (d_logits ? 0 : (size_t)U * V) + (size_t)U;
-  RET(m->ws.ensure(total * sizeof(float)));
-  float* x = m->ws.f();
+  RET(m->sc->ws.ensure(total * sizeof(float)));
+  float* x = m->sc->ws.f();
   float* h = x + nx;
   float* q2 = h + nx;
   float* selfbuf = q2 + nx;

@@ -11,6 +11,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <unordered_map>
 #include <vector>
 
@@ -53,18 +54,28 @@ struct WeightTable {
   }
 };
 
+// Bytes held by the buffers of one scratch set (ss_scratch): `cap` > 0 bounds them (ss_scratch_set_cap)
+struct ScratchAcct { size_t cap = 0, used = 0; };
+
 struct DevBuf {
   void* p = nullptr;
   size_t bytes = 0;
+  ScratchAcct* acct = nullptr;       // the scratch set this buffer is booked under (null: a weight-side buffer, not capped)
   int ensure(size_t need) {
     if (need <= bytes) return SS_OK;
-    if (p) { SS_HIP_CHECK(hipDeviceSynchronize()); SS_HIP_CHECK(hipFree(p)); p = nullptr; bytes = 0; }
     size_t cap = need + std::min(need / 4, (size_t)256 << 20) + 4096;   // growth slack: a quarter, at most 256 MB (a pack's activations run to 12 GB)
+    if (acct && acct->cap) {
+      const size_t others = acct->used - bytes;
+      if (others + cap > acct->cap) cap = need;                          // no slack under a cap ...
+      if (others + cap > acct->cap) return SS_ERR_SCRATCH_CAP;           // ... and a clean error past it (nothing was freed)
+    }
+    if (p) { SS_HIP_CHECK(hipDeviceSynchronize()); SS_HIP_CHECK(hipFree(p)); p = nullptr; if (acct) acct->used -= bytes; bytes = 0; }
     SS_HIP_CHECK(hipMalloc(&p, cap));
     bytes = cap;
+    if (acct) acct->used += cap;
     return SS_OK;
   }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; if (acct) acct->used -= bytes; bytes = 0; } }
   float* f() const { return reinterpret_cast<float*>(p); }
 };
 
@@ -151,25 +162,16 @@ struct DecLayer {
   bool has_cross = false;
 };
 
-struct ss_model {
-  ss_config cfg;
-  WeightTable wt;
-  SkWorkspace* skws = nullptr;       // stream-K hand-off state of this context (freed with the handle)
-  // encoder
-  Lin sub0, sub1, enc_linear, ctc_asr, ctc_st;
-  std::vector<EncLayer> enc;
-  const float* pos_table = nullptr;  // [2*Tmax-1, d]
-  const float* pos_w = nullptr;      // [L*d, d]
-  DevBuf pos_proj;                   // [2*Tmax-1, L*d]
-  // front-end
-  const float *fe_window = nullptr, *fe_melw = nullptr, *fe_mean = nullptr, *fe_std = nullptr;
-  // decoders
-  const float* mt_emb = nullptr; const float* mt_pos = nullptr; LN mt_ln;
-  std::vector<DecLayer> mt, t2u, unit;
-  LN t2u_ln, unit_ln;
-  Lin unit_out;
-  const float* unit_pos_row = nullptr;
-  // scratch
+// Everything a call MUTATES: activations, KV caches, the stream-K hand-off state, streaming-encoder state, the token chain.
+// One per concurrent stream (ss_scratch_create); any number of weight handles (ss_model / ss_vocoder: one per language, cheap) may be
+// bound to it one after the other (ss_model_bind_scratch / ss_vocoder_bind_scratch) -- round 5 welded a scratch set into every weight
+// handle, so L languages on S streams cost L x S scratch sets.  Ref-counted: freed when the creator and
+// every bound handle have let go.
+struct ss_scratch {
+  std::atomic<int> refs{1};
+  ScratchAcct acct;
+  SkWorkspace* skws = nullptr;       // stream-K hand-off state of this context
+  // ---- model side ----
   DevBuf ws;            // encoder / t2u / unit scratch
   DevBuf mt_cross;      // [mt_layers][Tp][2*D]
   DevBuf mt_self;       // [mt_layers][max_tgt_pos][3*D]
@@ -187,6 +189,7 @@ struct ss_model {
   DevBuf seg_buf;                // ragged-batch segment tables / batched token chain
   DevBuf bmt_self;               // batched MT self-attention cache [layer][B][Lcap][3D]
   int32_t* mt_tok_host = nullptr;  // pinned staging of the same
+  size_t mt_tok_host_n = 0;
   // incremental streaming encoder (ss_encoder_stream_*): per-layer fused q|k|v rows and GLU outputs
   // of every frame so far + the finished output rows; rows < es_final are final
   DevBuf es_qkv;        // [layers][es_cap][3d]
@@ -198,6 +201,56 @@ struct ss_model {
   // next call that uses the same scratch buffer)
   const float* dbg_logits = nullptr;
   int dbg_rows = 0, dbg_cols = 0;
+  // ---- vocoder side ----
+  DevBuf v_ws, v_small, v_segs;
+  ss_scratch() {
+    for (DevBuf* b : all()) b->acct = &acct;
+    skws = sk_workspace_new();
+  }
+  ~ss_scratch() {
+    for (DevBuf* b : all()) b->release();
+    if (mt_tok_host) (void)hipHostFree(mt_tok_host);
+    sk_workspace_free(skws);
+  }
+  std::vector<DevBuf*> all() {
+    return {&ws, &mt_cross, &mt_self, &mt_ws, &attn_split, &mt_gran, &mt_tok, &seg_buf, &bmt_self, &es_qkv, &es_glu, &es_out, &v_ws, &v_small, &v_segs};
+  }
+  // what ss_scratch_trim may let go: buffers every entry point re-sizes before use (the zero-initialised ones and the KV cache stay)
+  std::vector<DevBuf*> trimmable() { return {&ws, &mt_cross, &mt_ws, &seg_buf, &bmt_self, &es_qkv, &es_glu, &es_out, &v_ws, &v_small, &v_segs}; }
+};
+[[maybe_unused]] static void scratch_unref(ss_scratch* sc) { if (sc && sc->refs.fetch_sub(1) == 1) delete sc; }
+// the fixed-size pieces a model of configuration `c` needs in the scratch set it runs on: the MT self-attention cache, the token chain
+[[maybe_unused]] static int scratch_fit_model(ss_scratch* sc, const ss_config& c) {
+  int rc = sc->mt_self.ensure((size_t)c.mt_layers * c.max_tgt_pos * 3 * c.dec_dim * sizeof(float));
+  if (rc == SS_OK) rc = sc->mt_tok.ensure((size_t)c.max_tgt_pos * sizeof(int32_t));
+  if (rc == SS_OK && sc->mt_tok_host_n < (size_t)c.max_tgt_pos) {
+    if (sc->mt_tok_host) (void)hipHostFree(sc->mt_tok_host);
+    sc->mt_tok_host = nullptr; sc->mt_tok_host_n = 0;
+    if (hipHostMalloc((void**)&sc->mt_tok_host, (size_t)c.max_tgt_pos * sizeof(int32_t)) != hipSuccess) return SS_ERR_HIP;
+    sc->mt_tok_host_n = (size_t)c.max_tgt_pos;
+  }
+  return rc;
+}
+
+struct ss_model {
+  ss_config cfg;
+  WeightTable wt;
+  ss_scratch* sc = nullptr;          // the scratch set this handle is bound to (its own unless ss_model_bind_scratch said otherwise)
+  // encoder
+  Lin sub0, sub1, enc_linear, ctc_asr, ctc_st;
+  std::vector<EncLayer> enc;
+  const float* pos_table = nullptr;  // [2*Tmax-1, d]
+  const float* pos_w = nullptr;      // [L*d, d]
+  const float* pos_proj = nullptr;   // [2*Tmax-1, L*d]: a function of the blob -- ONE buffer per blob and device, shared by every handle over it (model.hip)
+  int pos_key_dev = 0;
+  // front-end
+  const float *fe_window = nullptr, *fe_melw = nullptr, *fe_mean = nullptr, *fe_std = nullptr;
+  // decoders
+  const float* mt_emb = nullptr; const float* mt_pos = nullptr; LN mt_ln;
+  std::vector<DecLayer> mt, t2u, unit;
+  LN t2u_ln, unit_ln;
+  Lin unit_out;
+  const float* unit_pos_row = nullptr;
   // ss_model_set_pack_invariant: 1 = every ss_batch_* stage upstream of an arg-max computes a packed utterance with arithmetic that
   // is a function of that utterance alone (same bits alone, in any pack, at any position); 0 = fastest kernel per shape (round-4 routes)
   int pack_invariant = g_pack_invariant_default;
@@ -206,12 +259,12 @@ struct ss_model {
 // Key-split scratch of this context for the single-utterance rel-pos attention: allocated and zeroed on first use (the
 // counters must read zero; the stream is synchronised once so that a later call on another stream sees them).
 [[maybe_unused]] static int bind_attn_split(ss_model* m, AttnArgs& at, hipStream_t s) {
-  if (!m->attn_split.p) {
-    RET(m->attn_split.ensure(attention_split_bytes()));
-    SS_HIP_CHECK(hipMemsetAsync(m->attn_split.p, 0, attention_split_bytes(), s));
+  if (!m->sc->attn_split.p) {
+    RET(m->sc->attn_split.ensure(attention_split_bytes()));
+    SS_HIP_CHECK(hipMemsetAsync(m->sc->attn_split.p, 0, attention_split_bytes(), s));
     SS_HIP_CHECK(hipStreamSynchronize(s));
   }
-  attention_bind_split(at, m->attn_split.p);
+  attention_bind_split(at, m->sc->attn_split.p);
   return SS_OK;
 }
 
@@ -262,7 +315,7 @@ struct ConvW { const float* w = nullptr; const float* b = nullptr; const float* 
 struct ss_vocoder {
   ss_vocoder_config cfg;
   WeightTable wt;
-  SkWorkspace* skws = nullptr;       // stream-K hand-off state of this context (freed with the handle)
+  ss_scratch* sc = nullptr;          // the scratch set this handle is bound to (ss_vocoder_bind_scratch; its own by default)
   const float* dict = nullptr;
   ConvW dur_c1, dur_c2, dur_proj, pre, post;
   LN dur_ln1, dur_ln2;
@@ -270,7 +323,6 @@ struct ss_vocoder {
   std::vector<ConvW> rb_c1, rb_c2;  // [(stage*n_res + j)*3 + d]
   float* wino = nullptr;             // Winograd F(2,3) forms of the 32- / 64- / 128-channel stages' ResBlock conv weights (conv_c64w.hip):
   const float* wino_key = nullptr;   // ONE buffer per weight blob, shared by every context over that blob (wino_share below)
-  DevBuf ws, small, segs;
   int x3 = 0;          // split-bf16 contraction of the C >= 64 generator convs (ss_vocoder_set_bf16x3); default off = exact f32
 };
 

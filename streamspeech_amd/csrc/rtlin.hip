@@ -292,7 +292,7 @@ struct RtKbArgs {
 }  // namespace
 
 template <int UW>
-__global__ __launch_bounds__(256, UW <= 4 ? 3 : 2) void rt_linear_kb_kernel(const RtKbArgs p) {
+__global__ __launch_bounds__(256, 3) void rt_linear_kb_kernel(const RtKbArgs p) {
 #if __HIP_DEVICE_COMPILE__
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* xs = smem;
@@ -491,8 +491,9 @@ bool rtlin_kb_shape_ok(const GemmArgs& a) {
 
 bool rtlin_kb_eligible(const GemmArgs& a) {
   if (disp().rt_off || !rtlin_kb_shape_ok(a)) return false;
-  // worth it from about one (tile, 256-column group) unit per resident workgroup (below: the 32 x 64 tiles fill the chip better)
-  return disp().rt_force_g > 0 || (long long)cdiv(a.M, RT_BM) * (a.N / 256) >= disp().rt_kb_min_units;
+  // worth it from about one (tile, 64-column group) unit per CU (profiles/r06_rtlin_kb_bench.txt: 2500 rows x 512 columns, K = 2048:
+  // 60 vs 72 us on the 32 x 64 tiles)
+  return disp().rt_force_g > 0 || (long long)cdiv(a.M, RT_BM) * (a.N / 64) >= disp().rt_kb_min_units;
 }
 
 int launch_rtlin_kb(const GemmArgs& a, hipStream_t stream) {
@@ -507,19 +508,27 @@ int launch_rtlin_kb(const GemmArgs& a, hipStream_t stream) {
   RtKbArgs q;
   q.X = a.A; q.ldx = a.lda; q.W = a.W; q.bias = a.bias; q.R = a.R; q.ldr = a.ldr; q.C = a.C; q.ldc = a.ldc;
   q.alpha = a.alpha; q.act = a.act; q.M = a.M; q.K = a.Cin; q.zero = 0;
-  const int uw = (disp().rt_kb_uw == 8 && a.N % 512 == 0) ? 8 : 4;
+  // 16-column units per wave: 4 (256-column groups: the tile's A slice is re-read N / 256 times, from L2) unless the launch then has
+  // fewer units than three workgroups per CU -- short packs halve the group width until it has (profiles/r06_rtlin_kb_bench.txt:
+  // 9000 rows x 512 columns, K = 2048: 376 units on 768 workgroup slots at UW = 4)
+  int uw = disp().rt_kb_uw == 1 || disp().rt_kb_uw == 2 ? disp().rt_kb_uw : 4;
+  if (disp().rt_kb_uw <= 0)
+    while (uw > 1 && (long long)cdiv(a.M, RT_BM) * (a.N / (64 * uw)) < 3LL * cus) uw >>= 1;
   q.NCG = a.N / (64 * uw);
   const long long U = (long long)cdiv(a.M, RT_BM) * q.NCG;
-  long long G = disp().rt_force_g > 0 ? disp().rt_force_g : (long long)cus * (uw == 4 ? 3 : 2);
+  long long G = disp().rt_force_g > 0 ? disp().rt_force_g : 3LL * cus;
   if (G > U) G = U;
   if (G < 1) G = 1;
   q.G = (int)G;
   ProfRec rec{}; bool prof = false;
   int rc = prof_begin(a, stream, 31, rec, prof);
   if (rc != SS_OK) return rc;
-  if (uw == 8) {
-    SS_MAX_LDS_ONCE((&rt_linear_kb_kernel<8>), RT_LDS);
-    hipLaunchKernelGGL(rt_linear_kb_kernel<8>, dim3((unsigned)G), dim3(256), RT_LDS, stream, q);
+  if (uw == 1) {
+    SS_MAX_LDS_ONCE((&rt_linear_kb_kernel<1>), RT_LDS);
+    hipLaunchKernelGGL(rt_linear_kb_kernel<1>, dim3((unsigned)G), dim3(256), RT_LDS, stream, q);
+  } else if (uw == 2) {
+    SS_MAX_LDS_ONCE((&rt_linear_kb_kernel<2>), RT_LDS);
+    hipLaunchKernelGGL(rt_linear_kb_kernel<2>, dim3((unsigned)G), dim3(256), RT_LDS, stream, q);
   } else {
     SS_MAX_LDS_ONCE((&rt_linear_kb_kernel<4>), RT_LDS);
     hipLaunchKernelGGL(rt_linear_kb_kernel<4>, dim3((unsigned)G), dim3(256), RT_LDS, stream, q);

@@ -29,9 +29,9 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
   if (!cfg || !d_blob || !out || cfg->n_up > 8 || cfg->n_res > 4) return SS_ERR_ARG;
   ss_vocoder* v = new ss_vocoder();
   v->cfg = *cfg;
-  v->skws = sk_workspace_new();
+  v->sc = new ss_scratch();          // the handle's own scratch set; ss_vocoder_bind_scratch swaps it for a shared one
   int rc = v->wt.build(d_blob, blob_floats, names, offsets, numels, n_slots);
-  if (rc != SS_OK) { sk_workspace_free(v->skws); delete v; return rc; }
+  if (rc != SS_OK) { scratch_unref(v->sc); delete v; return rc; }
   WeightTable& w = v->wt;
   const int E = cfg->embedding_dim, Hd = cfg->dur_hidden, kd = cfg->dur_kernel;
   v->dict = w.get("voc.dict", (int64_t)cfg->num_embeddings * E);
@@ -60,7 +60,7 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
     C = Co;
   }
   v->post = {w.get("voc.post.w", (int64_t)7 * C), w.get("voc.post.b", 1)};
-  if (!w.missing.empty()) { sk_workspace_free(v->skws); delete v; return SS_ERR_MISSING_WEIGHT; }
+  if (!w.missing.empty()) { scratch_unref(v->sc); delete v; return SS_ERR_MISSING_WEIGHT; }
   {
     // Winograd forms of the 32-, 64- and 128-channel stages' ResBlock convs (conv_c64w.hip), made once per context from the packed weights
     auto wino_stage = [](int ch) { return ch == 32 || ch == 64 || ch == 128 || ch == 256; };
@@ -72,7 +72,7 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
     }
     if (need) {
       int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess) { sk_workspace_free(v->skws); delete v; return SS_ERR_HIP; }
+      if (hipGetDevice(&dev) != hipSuccess) { scratch_unref(v->sc); delete v; return SS_ERR_HIP; }
       std::lock_guard<std::mutex> lk(g_wino_mu);          // (held over the pack: a second context of the same blob waits for it)
       uint64_t sig = fnv(fnv(fnv(14695981039346656037ull, (uint64_t)C0), (uint64_t)cfg->n_up), (uint64_t)cfg->n_res);
       for (int j = 0; j < cfg->n_res; ++j) sig = fnv(sig, (uint64_t)cfg->resblock_kernel_sizes[j]);
@@ -80,10 +80,10 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
       const WinoKey key{dev, d_blob, sig};
       WinoShared& sh = g_wino[key];
       const bool fresh = sh.refs == 0;
-      if (!fresh && sh.floats != need) { sk_workspace_free(v->skws); delete v; return SS_ERR_ARG; }   // (same signature, another size: cannot happen; the live entry is left alone)
+      if (!fresh && sh.floats != need) { scratch_unref(v->sc); delete v; return SS_ERR_ARG; }   // (same signature, another size: cannot happen; the live entry is left alone)
       if (fresh) {
         rc = sh.buf.ensure(need * sizeof(float));
-        if (rc != SS_OK) { g_wino.erase(key); sk_workspace_free(v->skws); delete v; return rc; }
+        if (rc != SS_OK) { g_wino.erase(key); scratch_unref(v->sc); delete v; return rc; }
         sh.floats = need;
       }
       float* dst = sh.buf.f();
@@ -108,7 +108,7 @@ extern "C" int ss_vocoder_create(const ss_vocoder_config* cfg, const float* d_bl
       if (fresh && rc == SS_OK && hipDeviceSynchronize() != hipSuccess) rc = SS_ERR_HIP;
       if (rc != SS_OK) {
         if (fresh) { sh.buf.release(); g_wino.erase(key); }
-        sk_workspace_free(v->skws); delete v; return rc;
+        scratch_unref(v->sc); delete v; return rc;
       }
       ++sh.refs;
       v->wino = sh.buf.f(); v->wino_key = d_blob;
@@ -126,7 +126,6 @@ extern "C" int ss_vocoder_set_bf16x3(ss_vocoder* v, int on) {
 
 extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
   if (!v) return;
-  v->ws.release(); v->small.release(); v->segs.release();
   if (v->wino_key) {
     std::lock_guard<std::mutex> lk(g_wino_mu);
     for (auto it = g_wino.begin(); it != g_wino.end(); ++it)
@@ -135,8 +134,18 @@ extern "C" void ss_vocoder_destroy(ss_vocoder* v) {
         break;
       }
   }
-  sk_workspace_free(v->skws);
+  scratch_unref(v->sc);
   delete v;
+}
+
+extern "C" int ss_vocoder_bind_scratch(ss_vocoder* v, ss_scratch* sc) {
+  if (!v || !sc) return SS_ERR_ARG;
+  if (sc != v->sc) {
+    sc->refs.fetch_add(1);
+    scratch_unref(v->sc);
+    v->sc = sc;
+  }
+  return SS_OK;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -313,13 +322,13 @@ extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_
                                   const int32_t* d_forced_dur, float* d_wav, int64_t wav_capacity,
                                   int32_t* d_dur, int64_t* h_n_samples) {
   if (!v || K <= 0 || !d_codes || !d_wav || !d_dur) return SS_ERR_ARG;
-  SkScope sk_scope(v->skws);
+  SkScope sk_scope(v->sc->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_vocoder_config& c = v->cfg;
   const int E = c.embedding_dim, Hd = c.dur_hidden;
   // --- embedding + duration predictor (codehifigan.py:56-66, fastspeech2.py:117-151) ---
-  RET(v->small.ensure(((size_t)K * (E + 2 * Hd + 1) + 2 * (K + 2)) * sizeof(float)));
-  float* emb = v->small.f();
+  RET(v->sc->v_small.ensure(((size_t)K * (E + 2 * Hd + 1) + 2 * (K + 2)) * sizeof(float)));
+  float* emb = v->sc->v_small.f();
   float* t1 = emb + (size_t)K * E;
   float* t2 = t1 + (size_t)K * Hd;
   float* logdur = t2 + (size_t)K * Hd;
@@ -355,8 +364,8 @@ extern "C" int ss_vocoder_forward(ss_vocoder* v, void* stream, const int32_t* d_
     int T = Fr, C = c.upsample_initial_channel;
     for (int i = 0; i < c.n_up; ++i) { T *= c.upsample_rates[i]; C /= 2; stage_max = std::max(stage_max, (size_t)T * C); }
   }
-  RET(v->ws.ensure((8 * stage_max + (size_t)Fr * E) * sizeof(float)));
-  float* frames = v->ws.f();
+  RET(v->sc->v_ws.ensure((8 * stage_max + (size_t)Fr * E) * sizeof(float)));
+  float* frames = v->sc->v_ws.f();
   GenBufs gb;
   gb.bx = frames + (size_t)Fr * E;       // stage input / MRF accumulator
   gb.bt = gb.bx + stage_max;             // conv1 output
@@ -384,7 +393,7 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
                                         int64_t wav_capacity, int32_t* d_dur, int64_t* h_wav_start,
                                         int64_t* h_n_samples) {
   if (!v || B <= 0 || !d_codes || !d_wav || !d_dur) return SS_ERR_ARG;
-  SkScope sk_scope(v->skws);
+  SkScope sk_scope(v->sc->skws);
   hipStream_t s = (hipStream_t)stream;
   const ss_vocoder_config& c = v->cfg;
   const int E = c.embedding_dim, Hd = c.dur_hidden;
@@ -392,8 +401,8 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
     if (h_K[b] <= 0) return SS_ERR_ARG;                    // the single-utterance form refuses K = 0 too; callers drop unit-less utterances
   const Offsets ok = prefix(h_K, B);
   const int Kt = ok.total;
-  RET(v->small.ensure(((size_t)Kt * (E + 2 * Hd + 1) + 2 * (Kt + B + 2)) * sizeof(float)));
-  float* emb = v->small.f();
+  RET(v->sc->v_small.ensure(((size_t)Kt * (E + 2 * Hd + 1) + 2 * (Kt + B + 2)) * sizeof(float)));
+  float* emb = v->sc->v_small.f();
   float* t1 = emb + (size_t)Kt * E;
   float* t2 = t1 + (size_t)Kt * Hd;
   float* logdur = t2 + (size_t)Kt * Hd;
@@ -405,8 +414,8 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
     int* a = &tk[4 * b]; a[0] = ok.off[b]; a[1] = h_K[b]; a[2] = ok.off[b]; a[3] = h_K[b];
     tk[4 * B + 2 * b] = ok.off[b]; tk[4 * B + 2 * b + 1] = h_K[b];
   }
-  RET(v->segs.ensure((6 * B + 16 * B) * sizeof(int)));
-  int* dk = (int*)v->segs.p;
+  RET(v->sc->v_segs.ensure((6 * B + 16 * B) * sizeof(int)));
+  int* dk = (int*)v->sc->v_segs.p;
   RET(upload(s, dk, tk));
   RET(launch_gather_rows(d_codes, v->dict, E, emb, Kt, s, v->cfg.num_embeddings));
   const int* forced = d_forced_dur;
@@ -447,8 +456,8 @@ extern "C" int ss_batch_vocoder_forward(ss_vocoder* v, void* stream, int B, cons
     int T = Ft, C = c.upsample_initial_channel;
     for (int i = 0; i < c.n_up; ++i) { T *= c.upsample_rates[i]; C /= 2; stage_max = std::max(stage_max, (size_t)T * C); }
   }
-  RET(v->ws.ensure((8 * stage_max + (size_t)Ft * E) * sizeof(float)));
-  float* frames = v->ws.f();
+  RET(v->sc->v_ws.ensure((8 * stage_max + (size_t)Ft * E) * sizeof(float)));
+  float* frames = v->sc->v_ws.f();
   GenBufs gb;
   gb.bx = frames + (size_t)Ft * E;
   gb.bt = gb.bx + stage_max;

@@ -123,11 +123,46 @@ class BatchMixin:
         return (out, raws) if return_raw else out
 
 
+class Scratch:
+    """One scratch set (ss_scratch: activations, KV caches, stream-K hand-off state, streaming-encoder state) -- everything a call
+    mutates.  One per concurrent stream; weight handles of any language (HipModel / HipVocoder) are bound to it with
+    `handle.bind_scratch(scratch)` or at construction (`scratch=`).  Driven by one host thread at a time."""
+
+    def __init__(self, device="cuda:0", cap_bytes: int = 0):
+        self.lib = L.load()
+        self.device = _require_gpu(device)
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ss_scratch_create(C.byref(h)), "ss_scratch_create")
+        self.h = h
+        if cap_bytes:
+            self.set_cap(cap_bytes)
+
+    def set_cap(self, max_bytes: int):
+        L.check(self.lib.ss_scratch_set_cap(self.h, int(max_bytes)), "ss_scratch_set_cap")
+
+    def trim(self, keep_bytes: int = 0):
+        """Synchronises the device and releases the re-sizable buffers, largest first, until at most keep_bytes are held."""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ss_scratch_trim(self.h, int(keep_bytes)), "ss_scratch_trim")
+
+    def bytes(self) -> int:
+        return int(self.lib.ss_scratch_bytes(self.h))
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.ss_scratch_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class HipModel(BatchMixin):
     """ss_model handle + packed weights (StreamSpeechModel replacement)."""
 
     def __init__(self, state_dict, cfg: ModelConfig = None, device="cuda:0", cmvn_mean=None, cmvn_std=None,
-                 max_rel_pos: int = 2048, max_tgt_pos: int = 1026, _share=None):
+                 max_rel_pos: int = 2048, max_tgt_pos: int = 1026, _share=None, scratch: "Scratch" = None):
         self.lib = L.load()
         self.cfg = cfg or ModelConfig()
         self.device = _require_gpu(device)
@@ -149,6 +184,9 @@ class HipModel(BatchMixin):
             L.check(self.lib.ss_model_create(C.byref(self.c_cfg), _ptr(self.blob), self.blob.numel(), cn, co, cm, n,
                                              C.byref(h)), "ss_model_create")
         self.h = h
+        self.scratch = None                 # None: the handle's own scratch set (made by ss_model_create)
+        if scratch is not None:
+            self.bind_scratch(scratch)
         self.max_tgt_pos = max_tgt_pos
         # MT decode step of single-utterance searches (ss_mt_greedy / ss_mt_append with one token): the C ABI's default is the
         # launch-per-op form (SS_MT_PERSISTENT overrides it); a PRIMARY context -- the one an agent / the offline driver / a
@@ -159,12 +197,20 @@ class HipModel(BatchMixin):
         if _share is None and "SS_MT_PERSISTENT" not in os.environ:
             self.set_persistent_mt_step(64)
 
-    def new_context(self) -> "HipModel":
-        """A second ss_model handle (own scratch / KV caches) borrowing the same weights: one per
-        concurrent utterance stream.  (Concurrent contexts start with the launch-per-op MT decode step: the persistent step's
-        workgroups must all be resident, which only a context that decodes alone on the device can count on.)"""
+    def new_context(self, scratch: "Scratch" = None) -> "HipModel":
+        """Another ss_model handle borrowing the same weights -- on its own scratch set, or on `scratch` (a set shared with the
+        handles of other languages on the same stream): one per concurrent utterance stream.  (Concurrent contexts start with the
+        launch-per-op MT decode step: the persistent step's workgroups must all be resident, which only a context that decodes
+        alone on the device can count on.)"""
         return HipModel(None, self.cfg, device=str(self.device), max_rel_pos=self._dims[0],
-                        max_tgt_pos=self._dims[1], _share=self._packed)
+                        max_tgt_pos=self._dims[1], _share=self._packed, scratch=scratch)
+
+    def bind_scratch(self, scratch: "Scratch"):
+        """Run this handle on `scratch` from now on (between stateful sequences only: mt_begin ... mt_append and the streaming
+        encoder keep their state in the scratch set)."""
+        with torch.cuda.device(self.device):
+            L.check(self.lib.ss_model_bind_scratch(self.h, scratch.h), "ss_model_bind_scratch")
+        self.scratch = scratch
 
     def __del__(self):
         try:
@@ -354,7 +400,7 @@ class HipModel(BatchMixin):
 class HipVocoder:
     """ss_vocoder handle (CodeHiFiGANVocoderWithDur replacement)."""
 
-    def __init__(self, generator_state_dict, cfg: VocoderConfig = None, device="cuda:0", _share=None):
+    def __init__(self, generator_state_dict, cfg: VocoderConfig = None, device="cuda:0", _share=None, scratch: "Scratch" = None):
         self.lib = L.load()
         self.cfg = cfg or VocoderConfig()
         self.device = _require_gpu(device)
@@ -385,11 +431,18 @@ class HipVocoder:
             L.check(self.lib.ss_vocoder_create(C.byref(cc), _ptr(self.blob), self.blob.numel(), cn, co, cm, n,
                                                C.byref(h)), "ss_vocoder_create")
         self.h = h
+        self.scratch = None
+        if scratch is not None:
+            self.bind_scratch(scratch)
         self.hop = int(np.prod(c.upsample_rates))
         self.max_dur = 64
 
-    def new_context(self) -> "HipVocoder":
-        v = HipVocoder(None, self.cfg, device=str(self.device), _share=self._packed)
+    def bind_scratch(self, scratch: "Scratch"):
+        L.check(self.lib.ss_vocoder_bind_scratch(self.h, scratch.h), "ss_vocoder_bind_scratch")
+        self.scratch = scratch
+
+    def new_context(self, scratch: "Scratch" = None) -> "HipVocoder":
+        v = HipVocoder(None, self.cfg, device=str(self.device), _share=self._packed, scratch=scratch)
         if getattr(self, "bf16x3", False):
             v.set_bf16x3(True)
         return v

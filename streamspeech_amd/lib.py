@@ -36,6 +36,13 @@ SIGNATURES = {
     "ss_model_create": (_i, [C.POINTER(SSConfig), _vp, C.c_size_t, C.POINTER(C.c_char_p), C.POINTER(_i64),
                              C.POINTER(_i64), _i, C.POINTER(_vp)]),
     "ss_model_destroy": (None, [_vp]),
+    "ss_scratch_create": (_i, [C.POINTER(_vp)]),
+    "ss_scratch_destroy": (None, [_vp]),
+    "ss_scratch_set_cap": (_i, [_vp, C.c_size_t]),
+    "ss_scratch_trim": (_i, [_vp, C.c_size_t]),
+    "ss_scratch_bytes": (C.c_size_t, [_vp]),
+    "ss_model_bind_scratch": (_i, [_vp, _vp]),
+    "ss_vocoder_bind_scratch": (_i, [_vp, _vp]),
     "ss_fbank_num_frames": (_i, [_i]),
     "ss_fbank_cmvn": (_i, [_vp, _vp, _vp, _i, _f, _vp, C.POINTER(_i)]),
     "ss_encoder_out_len": (_i, [_i]),
@@ -128,7 +135,7 @@ def load():
             raise StreamSpeechHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.ss_abi_version() != 1:
+    if lib.ss_abi_version() != 2:
         raise StreamSpeechHipError("ABI version mismatch")
     _lib = lib
     return lib

@@ -113,7 +113,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = L.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.ss_abi_version() == 1
+    assert lib.ss_abi_version() == 2
     assert lib.ss_fbank_num_frames(16000) == 98
     assert lib.ss_encoder_out_len(83) == 21
 
