@@ -192,7 +192,7 @@ bool conv_c16_eligible(const GemmArgs& a) {
          a.lda == C1_C && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && (!a.R2 || (a.ldr2 & 3) == 0) && (!a.C2 || (a.ldc2 & 3) == 0) &&
          (a.taps == 3 || a.taps == 7 || a.taps == 11) && a.dil >= 1 && (a.taps - 1) * a.dil <= C1_MAXHALO && a.pad >= 0 &&
          a.pad <= (a.taps - 1) * a.dil && a.nseg <= C1_MAXSEG && a.M >= disp().c16_min_rows &&
-         ((size_t)(a.M + a.pad + 512) * a.lda) * 4 < 0x7ff00000ull &&
+         slab_rows_ok(a.M) &&
          (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) &&
          (a.act == ACT_NONE || a.act == ACT_LRELU);
 }

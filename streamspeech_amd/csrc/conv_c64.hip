@@ -260,7 +260,7 @@ bool conv_c64_eligible(const GemmArgs& a) {
   return !disp().c64_off && a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && !a.x3 && a.Cin == C6_C && a.N == C6_C &&
          a.lda == C6_C && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && (!a.R2 || (a.ldr2 & 3) == 0) && (!a.C2 || (a.ldc2 & 3) == 0) &&
          a.taps >= 1 && a.dil >= 1 && (a.taps - 1) * a.dil <= C6_MAXHALO && a.pad >= 0 && a.pad <= (a.taps - 1) * a.dil &&
-         a.nseg <= C6_MAXSEG && a.M >= disp().c64_min_rows && ((size_t)(a.M + a.pad + 512) * a.lda) * 4 < 0x7ff00000ull &&
+         a.nseg <= C6_MAXSEG && a.M >= disp().c64_min_rows && slab_rows_ok(a.M) &&
          (size_t)a.taps * C6_C * C6_C * 4 < 0x7ff00000ull && (a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) &&
          (a.act == ACT_NONE || a.act == ACT_LRELU);
 }

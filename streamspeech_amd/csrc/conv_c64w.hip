@@ -417,7 +417,7 @@ bool conv_c128w_eligible(const GemmArgs& a) {
   if (!disp().c128w_on || !a.Wwino || !a.same_rows || a.stride != 1 || a.chunk || a.glu || a.ln_g || a.x3 || a.Cin != 128 || a.N != 128) return false;
   if (a.lda != 128 || (a.ldc & 3) || (a.R && (a.ldr & 3)) || (a.R2 && (a.ldr2 & 3)) || (a.C2 && (a.ldc2 & 3))) return false;
   if (a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.pad != a.dil * (a.taps - 1) / 2) return false;
-  if (a.nseg > CW_MAXSEG || a.M < disp().c128w_min_rows || ((size_t)(a.M + a.pad + 512) * a.lda) * 4 >= 0x7ff00000ull) return false;
+  if (a.nseg > CW_MAXSEG || a.M < disp().c128w_min_rows || !slab_rows_ok(a.M)) return false;
   if (!(a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) || !(a.act == ACT_NONE || a.act == ACT_LRELU)) return false;
   const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;
   return slab_rows <= CW_MAXROWS && cw_lds(a, 128) <= 160 * 1024;
@@ -429,7 +429,7 @@ bool conv_c256w_eligible(const GemmArgs& a) {
   if (!disp().c256w_on || !a.Wwino || !a.same_rows || a.stride != 1 || a.chunk || a.glu || a.ln_g || a.x3 || a.Cin != 256 || a.N != 256) return false;
   if (a.lda != 256 || (a.ldc & 3) || (a.R && (a.ldr & 3)) || (a.R2 && (a.ldr2 & 3)) || (a.C2 && (a.ldc2 & 3))) return false;
   if (a.taps < 3 || (a.dil != 1 && a.dil != 3 && a.dil != 5) || a.pad != a.dil * (a.taps - 1) / 2) return false;
-  if (a.nseg > CW_MAXSEG || a.M < disp().c256w_min_rows || ((size_t)(a.M + a.pad + 512) * a.lda) * 4 >= 0x7ff00000ull) return false;
+  if (a.nseg > CW_MAXSEG || a.M < disp().c256w_min_rows || !slab_rows_ok(a.M)) return false;
   if ((size_t)256 * cw_groups(a) * 4 * 256 * 4 >= 0x7ff00000ull) return false;
   if (!(a.in_act == ACT_NONE || (a.in_act == ACT_LRELU && a.in_slope > 0.f && a.in_slope < 1.f)) || !(a.act == ACT_NONE || a.act == ACT_LRELU)) return false;
   const int slab_rows = cw_bme(a.dil) + 3 * cw_groups(a) * a.dil;

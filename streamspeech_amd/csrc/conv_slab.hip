@@ -197,7 +197,7 @@ bool conv_slab_eligible(const GemmArgs& a) {
          (!a.R2 || (a.ldr2 & 3) == 0) && (!a.C2 || (a.ldc2 & 3) == 0) && a.taps >= 1 && a.taps * a.Cin <= 512 &&
          (a.taps - 1) * a.dil <= 128 &&   // slab <= 256 rows (register prefetch budget)
          a.nseg <= SL_MAXSEG && a.M > 0 &&
-         ((size_t)(a.M + a.pad + 256) * a.lda) * 4 < 0x7ff00000ull &&
+         slab_rows_ok(a.M) &&
          (a.in_act == ACT_NONE || a.in_act == ACT_LRELU);
 }
 
@@ -461,7 +461,7 @@ size_t conv_pair_lds(int C, int taps, int dil) {
 bool conv_pair_eligible(int C, int taps, int dil, int lda, int ldc, int nseg, long long M) {
   return (C == 16 || C == 32) && lda == C && (ldc & 3) == 0 && (taps & 1) == 1 && taps * C <= 512 && (taps - 1) * dil <= 50 &&
          nseg <= SL_MAXSEG && M >= 2048 && conv_pair_lds(C, taps, dil) <= 72 * 1024 &&
-         ((size_t)(M + 256) * lda) * 4 < 0x7ff00000ull;
+         slab_rows_ok(M);
 }
 
 template <int C>

@@ -145,6 +145,11 @@ bool conv_sk2_eligible(const GemmArgs& a);
 int launch_conv_sk2(const GemmArgs& a, hipStream_t stream, int g_force = 0);
 int conv_sk2_error_count();
 
+// Row bound of the slab kernels (conv_slab / conv_pair / resblock_fused / conv_c16 / c32 / c64 / c64w): they address activations as
+// base + (size_t)row * ld -- 64-bit -- so a tensor may pass 2^31 BYTES (a 256-utterance pack's 16-channel stage: rounds 1-5 sent such
+// tensors to the generic tiles on a byte bound inherited from the buffer-addressed stream-K kernels); rows and segment tables are int.
+inline bool slab_rows_ok(long long rows) { return rows > 0 && rows < (1ll << 30); }
+
 // Slab conv for the narrow vocoder stages (conv_slab.hip): C, N in {16, 32}, weights + input slab in LDS.
 bool conv_slab_eligible(const GemmArgs& a);
 int launch_conv_slab(const GemmArgs& a, hipStream_t stream);

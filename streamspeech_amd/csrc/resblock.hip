@@ -373,7 +373,7 @@ bool resblock_fused_eligible(int C, int taps, const int* dil, int ldx, int ldy, 
   const int H = (taps - 1) / 2 * (dil[0] + dil[1] + dil[2] + 3);
   // the valid range may lose at most the first and the last tile slot of a wave: H <= 64 rows per side
   return dil[0] >= 1 && dil[1] >= 1 && dil[2] >= 1 && H <= 64 && ldx == C && (ldy & 3) == 0 && nseg <= RB_MAXSEG && M > 0 &&
-         ((size_t)(M + 1024) * C) * 4 < 0x7ff00000ull;
+         slab_rows_ok(M);
 }
 
 static int rb_cus(int& cus) {             // CU count of the CURRENT device, read once per device (thread-safe)
