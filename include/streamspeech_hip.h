@@ -229,7 +229,7 @@ int ss_batch_ctc_greedy(ss_model* m, void* stream, int head, int B, const float*
 /* Lockstep beam-1 search from [</s>] (offline: no prefix).  h_max_len[b] = forced-</s> step of
  * utterance b.  h_out_tokens [B][out_stride] receives the generated tokens (incl. the final </s>),
  * h_n_out[b] their number (= rows of valid decoder states); d_feats is [B][feat_rows][dec_dim].
- * B <= 128.  Synchronises. */
+ * B <= 256.  Synchronises. */
 int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float* d_enc_out, const int32_t* h_Tp,
                        const int32_t* h_max_len, int min_len, int32_t* h_out_tokens, int out_stride,
                        int32_t* h_n_out, float* d_feats, int feat_rows);

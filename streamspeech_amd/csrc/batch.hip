@@ -150,7 +150,7 @@ extern "C" int ss_batch_ctc_greedy(ss_model* m, void* stream, int head, int B, c
 extern "C" int ss_batch_mt_greedy(ss_model* m, void* stream, int B, const float* d_enc_out, const int32_t* h_Tp,
                                   const int32_t* h_max_len, int min_len, int32_t* h_out_tokens, int out_stride,
                                   int32_t* h_n_out, float* d_feats, int feat_rows) {
-  if (!m || B <= 0 || B > 128 || !d_feats) return SS_ERR_ARG;
+  if (!m || B <= 0 || B > 256 || !d_feats) return SS_ERR_ARG;     // (256: the segment tables of the slab kernels)
   SkScope sk_scope(m->sc->skws);
   CanonScope canon_scope(m->pack_invariant ? CANON_SEQ : CANON_NONE);     // cross K|V over the packed encoder rows
   hipStream_t s = (hipStream_t)stream;

@@ -147,11 +147,7 @@ __global__ __launch_bounds__(256, 1) void conv_sk2_kernel(const GemmArgs p, cons
   const int tiles_n = p.N / BN;
   const int tiles_m = (p.M + BM - 1) / BM;
   const long long U = (long long)tiles_m * tiles_n * nk;
-  long long u0 = (long long)w * U / q.G, u1 = (long long)(w + 1) * U / q.G;
-  if (p.canon) {       // pack-invariant form: ranges end on tile boundaries, every tile is ONE k-chain (no partial is ever parked)
-    const long long T = (long long)tiles_m * tiles_n;
-    u0 = ((long long)w * T / q.G) * nk; u1 = ((long long)(w + 1) * T / q.G) * nk;
-  }
+  const long long u0 = (long long)w * U / q.G, u1 = (long long)(w + 1) * U / q.G;
   if (u1 <= u0) return;
   const int t_first = (int)(u0 / nk), t_last = (int)((u1 - 1) / nk);
 
@@ -619,8 +615,11 @@ extern "C" int ss_debug_sk2_timing(unsigned long long* h_out, int cap_wgs) {
 #endif
 static const int g_k2_spare_cus = getenv("SS_SK2_SPARE_CUS") ? atoi(getenv("SS_SK2_SPARE_CUS")) : 0;   // tuning knob (measured flat)
 
+// (Rounds 4-5 had a pack-invariant mode here -- ranges cut on whole tiles, one accumulator chain over all of K.  Round 6's blocked
+//  chain needs a second accumulator set, which 128 accumulator registers per wave leave no room for: CANON_SEQ launches no longer
+//  come here -- launch_canon in gemm.hip -- and a.canon is refused below.)
 bool conv_sk2_eligible(const GemmArgs& a) {
-  return a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && a.Cin % K2_BK == 0 && (a.lda & 3) == 0 &&
+  return a.canon != CANON_SEQ && a.same_rows && a.stride == 1 && a.chunk == 0 && !a.glu && !a.ln_g && a.Cin % K2_BK == 0 && (a.lda & 3) == 0 &&
          a.N % 64 == 0 && a.M > 0 && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0) && (!a.R2 || (a.ldr2 & 3) == 0) &&
          (!a.C2 || (a.ldc2 & 3) == 0) && ((size_t)(a.M + a.pad + 256) * a.lda + a.Cin) * 4 < 0x7ff00000ull &&
          (size_t)a.N * a.taps * a.Cin * 4 < 0x7ff00000ull &&
@@ -645,7 +644,6 @@ static int launch_sk2(const GemmArgs& a, hipStream_t stream, int g_force) {
   long long G = g_force > 0 ? g_force : cus;        // one workgroup per CU (147 | 123 KB of LDS each), all resident
   if (G > cus) G = cus;
   if (G > U / 4) G = U / 4;                         // at least 4 k-steps per workgroup
-  if (a.canon && G > U / nk) G = U / nk;            // whole tiles per workgroup
   if (G < 1) G = 1;
   Sk2Args q;
   q.ws = st->ws; q.sync = st->sync2; q.G = (int)G; q.dbg = nullptr;

@@ -987,7 +987,7 @@ static bool smallm_shape_ok(const GemmArgs& a) {
   const bool glu_ok = !a.glu || (a.N % 32 == 0 && a.act == ACT_NONE && a.alpha == 1.f && !a.R);
   return a.taps == 1 && a.stride == 1 && a.pad == 0 && glu_ok && a.nseg == 0 && a.chunk == 0 && a.in_act == ACT_NONE && !a.R2 &&
          !a.C2 && a.div == 0.f && !a.ln_out && (a.act == ACT_NONE || a.act == ACT_SILU || a.act == ACT_RELU) && a.M > 0 &&
-         a.M <= 192 && a.Cin % 64 == 0 && (a.lda & 3) == 0 && (!a.ln_g || a.Cin <= 512);
+         a.M <= 1024 && a.Cin % 64 == 0 && (a.lda & 3) == 0 && (!a.ln_g || a.Cin <= 512);     // (rows = utterances of a lock-step pack: 16-row tiles are independent, any count gives a row the same bits)
 }
 
 // Pack-invariant routes (GemmArgs::canon): see gemm.hpp.  Nothing here may make the BITS depend on M; the choice among kernels
