@@ -294,7 +294,8 @@ def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=No
            "n_gpus": 1, "dtype": "f32", "data": "synthetic", "segment_ms": segment_ms,
            "config": {"workload": f"{n_utts} synthetic CVSS-C-shaped utterances (LogNormal(ln 4.5 s, 0.45) clipped to [1,15] s, <= {cap_s:.0f} s kept), "
                                   f"{segment_ms}-ms source segments at 16 kHz, StreamSpeechS2STAgent.policy() per segment, "
-                                  "random-init weights of the streamspeech.simultaneous.fr-en architecture"},
+                                  "random-init weights of the streamspeech.simultaneous.fr-en architecture; the source-finished call's "
+                                  "first-pass search pinned to 8 more subwords (random weights never emit </s>: `incremental_search_to_cap` is that case)"},
            "scorer": "streamspeech_amd/streaming_eval.py: restatement of SimulEval's SpeechOutputInstance timing + RTF/StartOffset/EndOffset "
                      "scorers (SimulEval itself cannot import here: yt_dlp / soundfile / textgrid absent; the reference files do not exist on the "
                      "GPU box); pinned against the reference's RTFScorer / StartOffsetScorer / EndOffsetScorer classes loaded from "
@@ -308,14 +309,29 @@ def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=No
             tot += n.value
         return tot
 
+    def pin_final_search(agent, remainder=8):
+        """The source-finished policy() call lets the first-pass search run to </s> (agent :520-533, max_len_b = 100).  A trained model
+        emits </s> a few subwords after the committed prefix; seeded random weights never do, so that call would decode to the 100-token
+        cap -- 100 x 145 us that say nothing about the path.  The workload pins the remainder of the final
+        search to `remainder` subwords, like the offline workload pins N; the to-the-cap case stays as its own row."""
+        gen = agent.generator_mt
+        plain = gen.generate_decoder
+
+        def generate_decoder(*a, max_new_tokens=-1, **kw):
+            return plain(*a, max_new_tokens=remainder if max_new_tokens == -1 else max_new_tokens, **kw)
+        gen.generate_decoder = generate_decoder
+
     kept_ids = None
     # the agent's default: incremental encoder + tail vocoder + the MT decode step as one persistent launch (mt_step.hip);
-    # then the reference's full recompute per call, and the default with the launch-per-op decode step (A/B of mt_step.hip)
+    # then the reference's full recompute per call, the default with the launch-per-op decode step (A/B of mt_step.hip), and the
+    # default with the final search left to run to the reference's 100-token cap (what random weights do without the pin)
     for name, over in (("incremental", {}), ("full_recompute", {"full_recompute_encoder": True, "vocoder_context_units": 0}),
-                       ("incremental_launch_per_op_mt", {"mt_step_workgroups": 0})):
+                       ("incremental_launch_per_op_mt", {"mt_step_workgroups": 0}), ("incremental_search_to_cap", {})):
         if configurations is not None and name not in configurations:
             continue
         agent = StreamSpeechS2STAgent(_agent_args(segment_ms, **over), model=StreamSpeechModel.from_engine(model), vocoder=VocSurface(voc))
+        if name != "incremental_search_to_cap":
+            pin_final_search(agent)
         SE.run_utterance(agent, pcms[0], segment_ms)                      # warm-up utterance
         n0 = census_launches()
         runs, skipped, ids = [], 0, []
@@ -349,6 +365,9 @@ def streaming_measure(model, voc, lib, cfg, segment_ms=320, n_utts=12, cpu_sd=No
         sd, vsd, vcfg = cpu_sd
         a = _agent_args(segment_ms, full_recompute_encoder=True, vocoder_context_units=0)
         agent = StreamSpeechS2STAgent(a, model=StreamSpeechModel.from_engine(OracleEngine(sd, cfg)), vocoder=OracleVocoder(vsd, vcfg))
+        pin_final_search(agent)
+        if torch.get_num_threads() > 16:
+            torch.set_num_threads(16)         # torch's default (all cores of a 128-core host) is ~20x slower on these small ops (see _pick_threads)
         runs = []
         t_begin = time.perf_counter()
         with torch.inference_mode():
@@ -446,7 +465,7 @@ def emit_streaming(out):
     line = {k: out.get(k) for k in ("metric", "mode", "value", "unit", "higher_is_better", "n_gpus", "dtype", "data", "segment_ms",
                                     "incremental_speedup_over_full_recompute")}
     line["config"] = {"workload": out["config"]["workload"]}
-    for name in ("incremental", "full_recompute", "incremental_launch_per_op_mt"):
+    for name in ("incremental", "full_recompute", "incremental_launch_per_op_mt", "incremental_search_to_cap"):
         v = out.get(name)
         if v:
             line[name] = {**{k: v[k] for k in ("rtfx_compute", "utterances", "policy_calls", "ms_per_policy_call_mean", "ms_per_policy_call_p95",

@@ -424,6 +424,9 @@ __global__ __launch_bounds__(256) void smallm_gemm_kernel(const GemmArgs p) {
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};   // 2 chains: MFMA dependent latency 40 > issue 32
   f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+  // a wave whose k-range is at most 128 (K <= 512 on four waves) already runs two chains of <= 64 terms: nothing to cut.  A function of
+  // (K, SK) alone -- never of M -- so a row's bits stay the same in any pack.
+  const bool blocked = (c_end - c_begin) > 8;
   auto load4 = [&](f32x4 (&a)[4], f32x4 (&w)[4], int c) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -444,7 +447,7 @@ __global__ __launch_bounds__(256) void smallm_gemm_kernel(const GemmArgs p) {
     acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[1], w[1], acc2, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[2], w[2], acc, 0, 0, 0);
     acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[3], w[3], acc2, 0, 0, 0);
-    if ((c & 3) == 3) {            // end of a 64-wide k-block (round 6, gemm.hpp CANON_KBLOCK): block sums added in ascending order
+    if (blocked && (c & 3) == 3) {  // end of a 64-wide k-block (round 6, gemm.hpp CANON_KBLOCK): block sums added in ascending order
 #pragma unroll
       for (int e = 0; e < 4; ++e) { tot[e] += acc[e] + acc2[e]; acc[e] = 0.f; acc2[e] = 0.f; }
     }
