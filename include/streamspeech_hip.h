@@ -150,7 +150,9 @@ int ss_ctc_greedy(ss_model* m, void* stream, int head, const float* d_enc_out, i
  * workgroups = 64 | 128 | 256: the whole step as ONE persistent launch (csrc/mt_step.hip: phases exchange their output vectors
  * through agent-scope {epoch, value} granules; every wait is bounded and counted by ss_debug_sk_errors).  All workgroups of a
  * launch must become resident: meant for a context that decodes one utterance at a time on an otherwise lightly loaded
- * device (the SimulEval agent), at most 8 such contexts concurrently at 64 workgroups. */
+ * device (the SimulEval agent), at most 8 such contexts concurrently at 64 workgroups.
+ * The setting belongs to the SCRATCH SET the handle is bound to when this is called (the granule region lives there): a handle bound
+ * to another set afterwards runs with that set's setting. */
 int ss_mt_set_persistent(ss_model* m, int workgroups);
 /* The current setting.  It drops to 0 by itself when a launch of the persistent step times out: the kernel then publishes -1
  * as the next token, ss_mt_greedy (which reads the token chain back anyway) repeats the whole search with one launch per op and

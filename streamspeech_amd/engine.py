@@ -194,7 +194,7 @@ class HipModel(BatchMixin):
         # 125 vs 189 us per token).  Contexts made by new_context() exist for concurrency and keep the launch-per-op form; a
         # time-out of the persistent step (its workgroups were not all resident) falls back to it for good and says so.
         self.persistent_mt = int(self.lib.ss_mt_get_persistent(self.h))
-        if _share is None and "SS_MT_PERSISTENT" not in os.environ:
+        if _share is None and scratch is None and "SS_MT_PERSISTENT" not in os.environ:     # (a handle made ON a shared scratch set is a concurrent one)
             self.set_persistent_mt_step(64)
 
     def new_context(self, scratch: "Scratch" = None) -> "HipModel":
@@ -211,6 +211,8 @@ class HipModel(BatchMixin):
         with torch.cuda.device(self.device):
             L.check(self.lib.ss_model_bind_scratch(self.h, scratch.h), "ss_model_bind_scratch")
         self.scratch = scratch
+        if hasattr(self, "persistent_mt"):      # the MT decode-step form is a setting of the scratch set (its granule region lives there)
+            self.persistent_mt = int(self.lib.ss_mt_get_persistent(self.h))
 
     def __del__(self):
         try:
