@@ -315,6 +315,10 @@ int ss_debug_conv_c64(int enable);
  * 4 / 5 = the Winograd form of those per-conv launches (csrc/conv_c64w.hip at 32 channels) off / on. */
 int ss_debug_conv_c32(int enable);
 int ss_debug_conv_c16(int enable);       /* ... and for the 16-channel stage (csrc/conv_c16.hip) */
+/* Persistent layer launches of the incremental streaming encoder (csrc/enc_step.hip: two launches + the attention kernel per layer
+ * instead of eleven, on a scratch set whose persistent forms are on -- ss_mt_set_persistent -- and for calls with <= 48 rows to compute;
+ * SS_NO_ENC_STEP=1 keeps one launch per op): how many such launches this process has made (tests). */
+int64_t ss_debug_enc_step_launches(void);
 /* Unit-test entry of the LayerNorm-prologue linears (what ln_linear() in model.hip issues for QKV / pointwise conv 1 / the FFNs
  * of one utterance): dC = epi(LayerNorm(dX; ln_g, ln_b, eps 1e-5) . dW^T + dbias), epi as ss_op_conv_gemm (act, alpha, + dR, glu).
  * Served by the small-M kernel (<= 192 rows) or the row-tile kernel (K = 256, more rows); SS_ERR_ARG otherwise. */

@@ -7,7 +7,7 @@ HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result ${SS_EXTRA_FLAGS:-}"
 OUT=${SS_OUT_LIB:-../libstreamspeech_hip.so}
 B=${SS_BUILD_DIR:-build}
-SRCS="gemm conv_sk conv_sk2 conv_slab resblock ffn rtlin conv_c64 conv_c64w conv_c32 conv_c16 attention elementwise fbank mt_step model batch vocoder debug_ops"
+SRCS="gemm conv_sk conv_sk2 conv_slab resblock ffn rtlin conv_c64 conv_c64w conv_c32 conv_c16 attention elementwise fbank mt_step enc_step model batch vocoder debug_ops"
 mkdir -p $B
 rm -f $B/.failed          # stale flag of an earlier run: cleared BEFORE the jobs start (a fast failure must survive)
 for f in $SRCS; do

@@ -76,6 +76,7 @@ extern "C" int ss_debug_conv_c32(int enable) {      // 0 / 1: the per-conv slab 
   return SS_OK;
 }
 extern "C" int ss_debug_conv_c16(int enable) { conv_c16_debug(enable); return SS_OK; }
+extern "C" int64_t ss_debug_enc_step_launches(void) { return (int64_t)enc_step_launch_count(); }
 extern "C" int ss_debug_rtlin(int grid, int enable) {
   if (grid < 0) return SS_ERR_ARG;
   rtlin_debug(grid, enable);

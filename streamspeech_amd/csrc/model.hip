@@ -417,6 +417,19 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
   }
   if (r0 > 0)
     SS_HIP_CHECK(hipMemcpyAsync(d_enc_out, m->sc->es_out.f(), (size_t)r0 * d * sizeof(float), hipMemcpyDeviceToDevice, s));
+  // The layers as two persistent launches around the attention kernel (enc_step.hip) when this scratch set runs the persistent forms
+  // (ss_mt_set_persistent: a context that decodes one utterance at a time -- the agents) and the call has at most 48 rows to compute;
+  // a bounded wait that times out is counted, the set falls back to one launch per op for good and THIS call is repeated that way.
+  bool es_persistent = n > 0 && n <= ES_MAXR && m->sc->mt_persistent > 0 && !m->sc->es_step_off && !g_no_enc_step && d == ES_D && f == ES_F &&
+                       c.enc_heads * 64 == d && c.dw_kernel <= 31 && (size_t)T2 * 3 * d * 4 < 0x7ff00000ull;
+  if (es_persistent && !m->sc->es_step.p) {
+    RET(m->sc->es_step.ensure(enc_step_scratch_bytes()));
+    SS_HIP_CHECK(hipMemsetAsync(m->sc->es_step.p, 0, enc_step_scratch_bytes(), s));
+    m->sc->es_bar = 0;
+  }
+  float* es_part = es_persistent ? m->sc->es_step.f() : nullptr;
+  float* es_g2 = es_persistent ? es_part + (size_t)ES_G * ES_MAXR * ES_D : nullptr;
+  unsigned* es_sync = es_persistent ? reinterpret_cast<unsigned*>(es_g2 + (size_t)ES_MAXR * ES_D) : nullptr;      // [64] flags, then the error word
   if (n > 0) {
     RET(linear(s, g0 + (size_t)r0 * d, d, n, m->enc_linear, d, d, x, d));
     const float* P = m->pos_proj + (size_t)(c.max_rel_pos - T2) * Ld;
@@ -424,6 +437,28 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
       const EncLayer& e = m->enc[l];
       float* qkv = m->sc->es_qkv.f() + (size_t)l * cap * 3 * d;      // absolute rows
       float* glu = m->sc->es_glu.f() + (size_t)l * cap * d;
+      if (es_persistent) {
+        EsArgs a;
+        a.w = EsLayerW{e.ffn1_ln.g, e.ffn1_ln.b, e.ffn1_w1.w, e.ffn1_w1.b, e.ffn1_w2.w, e.ffn1_w2.b,
+                       e.attn_ln.g, e.attn_ln.b, e.qkv.w, e.qkv.b, e.out.w, e.out.b,
+                       e.conv_ln.g, e.conv_ln.b, e.pw1.w, e.dw_wt, e.bn_mean, e.bn_var, e.bn_g, e.bn_b, e.pw2.w,
+                       e.ffn2_ln.g, e.ffn2_ln.b, e.ffn2_w1.w, e.ffn2_w1.b, e.ffn2_w2.w, e.ffn2_w2.b, e.final_ln.g, e.final_ln.b};
+        a.x = x; a.qkv = qkv; a.glu = glu; a.hctx = h; a.part = es_part; a.g2 = es_g2; a.bar = es_sync;
+        a.err = es_sync + 64; a.n = n; a.r0 = r0; a.T2 = T2; a.cchunk = cchunk; a.dwk = c.dw_kernel;
+        a.ph0 = 0; a.ph1 = 2; a.bar_base = m->sc->es_bar;
+        RET(launch_enc_step(a, s));
+        m->sc->es_bar += (unsigned)ES_G * 2u;
+        AttnArgs at;
+        at.Q = qkv + (size_t)r0 * 3 * d; at.K = qkv + d; at.V = qkv + 2 * d; at.ldq = at.ldk = at.ldv = 3 * d;
+        at.O = h; at.ldo = d; at.Tq = n; at.Tk = T2; at.q0 = r0; at.H = c.enc_heads; at.scale = 0.125f;
+        at.chunk = achunk; at.P = P + (size_t)l * d; at.ldp = Ld; at.bias_u = e.u; at.bias_v = e.v;
+        RET(bind_attn_split(m, at, s));
+        RET(launch_attention(at, s));
+        a.ph0 = 4; a.ph1 = 9; a.bar_base = m->sc->es_bar;
+        RET(launch_enc_step(a, s));
+        m->sc->es_bar += (unsigned)ES_G * 5u;
+        continue;
+      }
       RET(ln_linear(s, x, n, e.ffn1_ln, e.ffn1_w1, f, d, ff, f, h, ACT_SILU));
       RET(linear(s, ff, f, n, e.ffn1_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
       RET(ln_linear(s, x, n, e.attn_ln, e.qkv, 3 * d, d, qkv + (size_t)r0 * 3 * d, 3 * d, h));
@@ -441,6 +476,20 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
       RET(ln_linear(s, x, n, e.ffn2_ln, e.ffn2_w1, f, d, ff, f, h, ACT_SILU));
       RET(linear(s, ff, f, n, e.ffn2_w2, d, f, x, d, ACT_NONE, 0.5f, x, d));
       RET(layernorm(s, x, x, e.final_ln, n, d));
+    }
+  }
+  if (es_persistent) {
+    unsigned e = 0;
+    SS_HIP_CHECK(hipMemcpyAsync(&e, es_sync + 64, sizeof(e), hipMemcpyDeviceToHost, s));
+    SS_HIP_CHECK(hipStreamSynchronize(s));
+    if (e) {     // a workgroup of some launch was not resident: count it, leave the persistent form, compute this call again the other way
+      fprintf(stderr, "streamspeech_hip: persistent encoder-layer launch timed out (its %d workgroups were not all resident); "
+                      "this context falls back to one launch per op\n", ES_G);
+      g_mt_timeouts.fetch_add((int)e, std::memory_order_relaxed);
+      SS_HIP_CHECK(hipMemsetAsync(es_sync, 0, 512, s));
+      m->sc->es_bar = 0;
+      m->sc->es_step_off = 1;
+      return ss_encoder_stream_forward(m, stream, d_fbank, T, attn_chunk, conv_chunk, d_enc_out, n_final, n_computed);
     }
   }
   const int nf = std::max(r0, stream_final_rows(T, T1, T2, k, achunk_cfg, cchunk, c.dw_kernel, m->sc->es_tail));

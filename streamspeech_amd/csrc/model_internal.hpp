@@ -22,6 +22,7 @@
 #include "fbank.hpp"
 #include "gemm.hpp"
 #include "mt_step.hpp"
+#include "enc_step.hpp"
 
 using namespace ss;
 
@@ -90,6 +91,7 @@ static int mt_persistent_env() {
 }
 static const int g_mt_persistent_default = mt_persistent_env();   // default of ss_mt_set_persistent for new contexts (0: launch-per-op decode step)
 static const int g_no_mt_device_loop = getenv("SS_NO_MT_DEVICE_LOOP") ? atoi(getenv("SS_NO_MT_DEVICE_LOOP")) : 0;   // A/B knob: one persistent launch per TOKEN (round 3) instead of one per search
+static const int g_no_enc_step = getenv("SS_NO_ENC_STEP") ? atoi(getenv("SS_NO_ENC_STEP")) : 0;   // A/B knob: the streaming encoder's layers as one launch per op even on a persistent context
 static const int g_no_mt_ln_fusion = getenv("SS_NO_MT_LN_FUSION") ? atoi(getenv("SS_NO_MT_LN_FUSION")) : 0;   // A/B knob: separate final LayerNorm launch in the MT decode step
 
 [[maybe_unused]] int linear(hipStream_t s, const float* A, int lda, int M, const Lin& l, int N, int K, float* C, int ldc,
@@ -195,6 +197,9 @@ struct ss_scratch {
   DevBuf es_qkv;        // [layers][es_cap][3d]
   DevBuf es_glu;        // [layers][es_cap][d]
   DevBuf es_out;        // [es_cap][d]
+  DevBuf es_step;       // persistent layer launches (enc_step.hip): partial FFN outputs, depthwise output, arrival counter + error word (zeroed once)
+  unsigned es_bar = 0;  // value of the arrival counter when the next launch starts
+  int es_step_off = 0;  // 1 after a time-out: this scratch set stays on one launch per op
   int es_cap = 0, es_final = 0, es_achunk = -1, es_cchunk = -1;
   int es_tail = 0;                                  // trailing fbank frames that may still change (resampler edge)
   // ss_debug_last_logits: where the last batched argmax stage of this context left its dense logits (scratch, valid until the
@@ -213,7 +218,7 @@ struct ss_scratch {
     sk_workspace_free(skws);
   }
   std::vector<DevBuf*> all() {
-    return {&ws, &mt_cross, &mt_self, &mt_ws, &attn_split, &mt_gran, &mt_tok, &seg_buf, &bmt_self, &es_qkv, &es_glu, &es_out, &v_ws, &v_small, &v_segs};
+    return {&ws, &mt_cross, &mt_self, &mt_ws, &attn_split, &mt_gran, &mt_tok, &seg_buf, &bmt_self, &es_qkv, &es_glu, &es_out, &es_step, &v_ws, &v_small, &v_segs};
   }
   // what ss_scratch_trim may let go: buffers every entry point re-sizes before use (the zero-initialised ones and the KV cache stay)
   std::vector<DevBuf*> trimmable() { return {&ws, &mt_cross, &mt_ws, &seg_buf, &bmt_self, &es_qkv, &es_glu, &es_out, &v_ws, &v_small, &v_segs}; }

@@ -95,6 +95,7 @@ SIGNATURES = {
     "ss_debug_conv_c64": (_i, [_i]),
     "ss_debug_conv_c32": (_i, [_i]),
     "ss_debug_conv_c16": (_i, [_i]),
+    "ss_debug_enc_step_launches": (_i64, []),
     "ss_op_ln_linear": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i]),
     "ss_debug_last_logits": (_i, [_vp, _vp, _vp, _i64, C.POINTER(_i), C.POINTER(_i)]),
     "ss_debug_sk_errors": (_i, []),

@@ -1,0 +1,72 @@
+"""Persistent layer launches of the incremental streaming encoder (csrc/enc_step.hip): on a scratch set whose
+persistent forms are on, a streaming call with <= 48 rows to compute runs every Conformer layer as two persistent launches around
+the attention kernel instead of eleven launches.  Must stay equal to the full recompute the reference does per chunk
+(agent/speech_to_speech.streamspeech.agent.py:425-435) and to the launch-per-op form of the same call; rows reported final never
+change; a call with more rows (the first call of a long prefix) takes the launch-per-op form."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from streamspeech_amd import synth
+    from streamspeech_amd.config import ModelConfig
+    from streamspeech_amd.engine import HipModel
+    cfg = ModelConfig()
+    return HipModel(synth.make_model_state_dict(0, cfg), cfg)
+
+
+def _drive(m, fb_all, ac, cc, Ts):
+    m.encoder_stream_reset()
+    outs, finals = [], []
+    for T in Ts:
+        outs.append(m.encoder_stream_forward(fb_all[:T].contiguous(), ac, cc).clone())
+        finals.append(m.stream_stats[0])
+    m.encoder_stream_reset()
+    return outs, finals
+
+
+@pytest.mark.parametrize("ac,cc,step", [(8, 8, 32), (16, 16, 32), (8, 8, 45), (24, 16, 64)])
+def test_persistent_layer_launches_equal_launch_per_op_and_full_recompute(model, ac, cc, step):
+    from streamspeech_amd import synth
+    lib = model.lib
+    fb_all = torch.from_numpy(synth.synth_fbank(43, 620)).to(model.device)
+    Ts = list(range(40, 620, step)) + [620]
+    model.set_persistent_mt_step(0)
+    n0 = lib.ss_debug_enc_step_launches()
+    ref, ref_final = _drive(model, fb_all, ac, cc, Ts)
+    assert lib.ss_debug_enc_step_launches() == n0                          # launch per op
+    model.set_persistent_mt_step(64)
+    got, got_final = _drive(model, fb_all, ac, cc, Ts)
+    used = lib.ss_debug_enc_step_launches() - n0
+    assert used >= 2 * model.cfg.enc_layers * 3 and used % (2 * model.cfg.enc_layers) == 0, used   # two per layer and call with <= 48 rows to compute
+    assert got_final == ref_final
+    worst = 0.0
+    for T, a, b in zip(Ts, got, ref):
+        assert a.shape == b.shape
+        worst = max(worst, (a - b).abs().max().item())
+        full = model.encoder_forward(fb_all[:T].contiguous(), ac, cc)
+        assert (a - full).abs().max().item() < 5e-5, T
+    assert worst < 2e-5, worst
+    for i in range(1, len(got)):                                           # final rows are served unchanged
+        nf = got_final[i - 1]
+        assert torch.equal(got[i][:nf], got[i - 1][:nf])
+    assert model.ctc_greedy(0, got[-1])[0] == model.ctc_greedy(0, ref[-1])[0]
+    assert lib.ss_debug_sk_errors() == 0
+
+
+def test_calls_with_more_than_48_rows_take_the_launch_per_op_form(model):
+    from streamspeech_amd import synth
+    lib = model.lib
+    model.set_persistent_mt_step(64)
+    fb = torch.from_numpy(synth.synth_fbank(44, 400)).to(model.device)       # 100 encoder rows at once: nothing is final yet
+    model.encoder_stream_reset()
+    n0 = lib.ss_debug_enc_step_launches()
+    out = model.encoder_stream_forward(fb, 8, 8)
+    assert lib.ss_debug_enc_step_launches() == n0
+    assert (out - model.encoder_forward(fb, 8, 8)).abs().max().item() < 5e-5
+    model.encoder_stream_reset()
