@@ -454,14 +454,8 @@ def streaming_mode(args, model, voc, lib, cfg, sd, vsd, vcfg):
     emit_streaming(out)
 
 
-def emit_streaming(out):
-    """--mode streaming: the full report to the sidecar / stderr, a compact line (< LINE_BYTE_CAP) to stdout."""
-    path = detail_path()
-    try:
-        json.dump(out, open(path, "w"), indent=1)
-    except OSError:
-        path = None
-    print("bench.py full result: " + json.dumps(out), file=sys.stderr, flush=True)
+def compact_streaming_line(out, detail=None):
+    """--mode streaming: the compact stdout line (< LINE_BYTE_CAP) of a streaming_measure() result."""
     line = {k: out.get(k) for k in ("metric", "mode", "value", "unit", "higher_is_better", "n_gpus", "dtype", "data", "segment_ms",
                                     "incremental_speedup_over_full_recompute")}
     line["config"] = {"workload": out["config"]["workload"]}
@@ -477,8 +471,19 @@ def emit_streaming(out):
     line["cpu_baseline"] = None if not cb else {k: cb[k] for k in ("value", "unit", "cores", "kind", "ms_per_policy_call_mean", "RTF_CA")}
     if out.get("long_prefix_sweep"):
         line["long_prefix_speedup_total"] = {str(r["source_s"]): r["speedup_total"] for r in out["long_prefix_sweep"]}
-    line["detail"] = path and os.path.relpath(path, ROOT)
-    _emit(line)
+    line["detail"] = detail
+    return line
+
+
+def emit_streaming(out):
+    """--mode streaming: the full report to the sidecar / stderr, the compact line to stdout."""
+    path = detail_path()
+    try:
+        json.dump(out, open(path, "w"), indent=1)
+    except OSError:
+        path = None
+    print("bench.py full result: " + json.dumps(out), file=sys.stderr, flush=True)
+    _emit(compact_streaming_line(out, path and os.path.relpath(path, ROOT)))
 
 
 def _pmc_file():

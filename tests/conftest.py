@@ -29,6 +29,10 @@ def pytest_configure(config):
     # 900; the slowest GPU test takes ~2 min, the slowest CPU test ~15 s) fails instead
     if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
         config.option.timeout = float(os.environ.get("SS_TEST_TIMEOUT", "900"))
+        # "thread": a watchdog thread dumps every thread's stack and ends the process -- the default (SIGALRM) cannot interrupt a test
+        # that is stuck inside a C call (seen twice in round 6: the CPU suite spinning in native code past the 900 s, no traceback)
+        if not getattr(config.option, "timeout_method", None) or config.option.timeout_method == "signal":
+            config.option.timeout_method = "thread"
 
 
 @pytest.fixture(scope="session")

@@ -92,3 +92,14 @@ def test_gpus_8_dry_plan_prints_a_parseable_line_under_the_cap_and_a_sidecar(tmp
     assert line["detail"] and "dropped" not in line
     full = json.load(open(side))
     assert "numa_node" in full["per_rank"][0] and full["comm"]["barrier_us"] > 0
+
+
+def test_the_streaming_mode_line_is_under_the_cap():
+    """`bench.py --mode streaming` prints its own compact line (four agent configurations, CPU leg, long-prefix sweep)."""
+    full = _full()["streaming_320ms"]
+    full.update(metric="simultaneous S2ST fr-en", mode="streaming", higher_is_better=True, n_gpus=1, dtype="f32", data="synthetic")
+    full["incremental_search_to_cap"] = full["incremental"]
+    text = json.dumps(bench.compact_streaming_line(full, "bench_detail.json"))
+    line = json.loads(text)
+    assert len(text) < bench.LINE_BYTE_CAP and line["value"] == full["value"] and line["incremental"]["ms_per_read_call_mean"] > 0
+    assert set(line["long_prefix_speedup_total"]) == {"15", "30"} and line["cpu_baseline"]["kind"] == "port"
