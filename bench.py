@@ -482,7 +482,7 @@ def emit_streaming(out):
         json.dump(out, open(path, "w"), indent=1)
     except OSError:
         path = None
-    print("bench.py full result: " + json.dumps(out), file=sys.stderr, flush=True)
+    print("bench.py full result (indented on purpose: no stderr line can be taken for the bench line):\n" + json.dumps(out, indent=1), file=sys.stderr, flush=True)
     _emit(compact_streaming_line(out, path and os.path.relpath(path, ROOT)))
 
 
@@ -609,7 +609,7 @@ def emit_result(full):
     except OSError as e:
         full["detail_file"] = None
         print(f"bench.py: could not write {path}: {e}", file=sys.stderr)
-    print("bench.py full result: " + json.dumps(full), file=sys.stderr, flush=True)
+    print("bench.py full result (indented on purpose: no stderr line can be taken for the bench line):\n" + json.dumps(full, indent=1), file=sys.stderr, flush=True)
     _emit(compact_line(full))
 
 

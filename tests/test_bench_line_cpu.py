@@ -92,6 +92,13 @@ def test_gpus_8_dry_plan_prints_a_parseable_line_under_the_cap_and_a_sidecar(tmp
     assert line["detail"] and "dropped" not in line
     full = json.load(open(side))
     assert "numa_node" in full["per_rank"][0] and full["comm"]["barrier_us"] > 0
+    # a harness that merges the two streams still finds ONE candidate: no stderr line parses as an object with a "metric"
+    for ln in r.stderr.splitlines():
+        if ln.lstrip().startswith("{") or '{"metric"' in ln:
+            try:
+                assert "metric" not in json.loads(ln[ln.index("{"):]), ln[:200]
+            except ValueError:
+                pass
 
 
 def test_the_streaming_mode_line_is_under_the_cap():
