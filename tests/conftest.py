@@ -26,9 +26,14 @@ def pytest_configure(config):
     if not config.option.durations:
         config.option.durations = 10          # always print the ten slowest tests
     # no test may hang the suite: with pytest-timeout present (it is in this image) a test that passes SS_TEST_TIMEOUT seconds (default
-    # 900; the slowest GPU test takes ~2 min, the slowest CPU test ~15 s) fails instead
+    # 900 on a GPU box, 300 without one; the slowest GPU test takes ~2 min, the slowest CPU test ~15 s) fails instead
     if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
-        config.option.timeout = float(os.environ.get("SS_TEST_TIMEOUT", "900"))
+        try:
+            import torch
+            has_gpu = torch.cuda.is_available()
+        except Exception:  # noqa: BLE001
+            has_gpu = False
+        config.option.timeout = float(os.environ.get("SS_TEST_TIMEOUT", "900" if has_gpu else "300"))
         # "thread": a watchdog thread dumps every thread's stack and ends the process -- the default (SIGALRM) cannot interrupt a test
         # that is stuck inside a C call (seen twice in round 6: the CPU suite spinning in native code past the 900 s, no traceback)
         if not getattr(config.option, "timeout_method", None) or config.option.timeout_method == "signal":

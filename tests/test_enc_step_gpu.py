@@ -30,7 +30,7 @@ def _drive(m, fb_all, ac, cc, Ts):
     return outs, finals
 
 
-@pytest.mark.parametrize("ac,cc,step", [(8, 8, 32), (16, 16, 32), (8, 8, 45), (24, 16, 64)])
+@pytest.mark.parametrize("ac,cc,step", [(8, 8, 32), (16, 16, 32), (8, 8, 45), (24, 16, 64), (16, 16, 128)])   # 8 ... 40 rows per call: the 1-, 2- and 3-row-tile kernels
 def test_persistent_layer_launches_equal_launch_per_op_and_full_recompute(model, ac, cc, step):
     from streamspeech_amd import synth
     lib = model.lib
