@@ -40,6 +40,7 @@ struct Dispatch {
   int rt_off = 0, rt_min_rows = 193, rt_force_g = 0;   // SS_NO_RTLIN, SS_RTLIN_MIN_ROWS, ss_debug_rtlin
   long long rt_min_units = 4000;                       // SS_RTLIN_MIN_UNITS
   long long rt_kb_min_units = 256;                     // SS_RTLIN_KB_MIN_UNITS: (48-row tile, 64-column group) units from which rt_linear_kb takes a K > 256 linear
+  int rt_kb_xmap = 1;                                  // SS_RTLIN_KB_XMAP: 0 = every workgroup walks a contiguous (tile, column group) range; 1 = the column groups of a row tile run side by side on one XCD
   int rt_kb_uw = 0;                                    // SS_RTLIN_KB_UW: 16-column units per wave and column group (0: by the launch's unit count; 1 / 2 / 4 force)
 };
 

@@ -903,7 +903,7 @@ Dispatch env_defaults() {
   if (getenv("SS_SK_MIN_GFLOP")) d.sk_min_flops = 1e9 * atof(getenv("SS_SK_MIN_GFLOP"));
   d.no_resblock_fusion = I("SS_NO_RESBLOCK_FUSION", 0); d.no_pair_fusion = I("SS_NO_PAIR_FUSION", 0);
   d.rt_off = I("SS_NO_RTLIN", 0) ? 1 : 0; d.rt_min_rows = I("SS_RTLIN_MIN_ROWS", d.rt_min_rows); d.rt_min_units = L("SS_RTLIN_MIN_UNITS", d.rt_min_units);
-  d.rt_kb_min_units = L("SS_RTLIN_KB_MIN_UNITS", d.rt_kb_min_units); d.rt_kb_uw = I("SS_RTLIN_KB_UW", d.rt_kb_uw);
+  d.rt_kb_min_units = L("SS_RTLIN_KB_MIN_UNITS", d.rt_kb_min_units); d.rt_kb_uw = I("SS_RTLIN_KB_UW", d.rt_kb_uw); d.rt_kb_xmap = I("SS_RTLIN_KB_XMAP", d.rt_kb_xmap);
   return d;
 }
 Dispatch& process_settings() { static Dispatch d = env_defaults(); return d; }      // (callers hold g_disp_mu)

@@ -288,6 +288,7 @@ struct RtKbArgs {
   float alpha; int act;
   int M, K, NCG, G;                            // rows, contraction length (multiple of 256), column groups per tile, workgroups
   int zero;
+  int xmap;                                    // != 0: XCD-aware unit order (see the kernel's unit loop); needs G % 8 == 0 and (G / 8) % NCG == 0
 };
 }  // namespace
 
@@ -315,8 +316,20 @@ __global__ __launch_bounds__(256, 3) void rt_linear_kb_kernel(const RtKbArgs p) 
   };
   const int xoff0 = r * RT_XS + 4 * g;
 
-  for (long long unit = u0; unit < u1; ++unit) {
-    const int tile = (int)(unit / p.NCG), cg = (int)(unit - (long long)tile * p.NCG);
+  // Unit order.  Plain: a contiguous range of (tile, column group) units per workgroup -- a workgroup then walks the column groups of ONE
+  // row tile one after the other, and by the time it comes back for the tile's A rows the XCD's L2 (4 MB = one weight matrix of this
+  // size) has turned over: the A slice came from HBM N / 256 times (PMC: 2.7x the algorithmic bytes).  XCD-aware (p.xmap): workgroup w
+  // sits on XCD w % 8 (observed placement; only speed depends on it) with local index q = w / 8; in step s the XCD's G / 8 workgroups
+  // take G / 8 / NCG row tiles and ALL their column groups side by side (tile = (s tps + q / NCG) 8 + x, group = q % NCG), so a tile's
+  // k-blocks are fetched once and hit in L2 for the other groups.  Every unit is still computed whole by one workgroup: same bits.
+  const int xx = w & 7, xq = w >> 3;
+  const int tps = p.xmap ? (p.G >> 3) / p.NCG : 1;
+  long long nit = u1 - u0;
+  if (p.xmap) { const int first = (xq / p.NCG) * 8 + xx; nit = first < tiles ? (tiles - first + tps * 8 - 1) / (tps * 8) : 0; }
+  for (long long it = 0; it < nit; ++it) {
+    int tile, cg;
+    if (p.xmap) { tile = ((int)it * tps + xq / p.NCG) * 8 + xx; cg = xq % p.NCG; }
+    else { const long long unit = u0 + it; tile = (int)(unit / p.NCG); cg = (int)(unit - (long long)tile * p.NCG); }
     const int m0 = tile * RT_BM;
     const int nw0 = cg * CG + wave * (UW * 16);              // this wave's first column of the group
     f32x4 tot[UW][RT_WM];
@@ -520,6 +533,7 @@ int launch_rtlin_kb(const GemmArgs& a, hipStream_t stream) {
   if (G > U) G = U;
   if (G < 1) G = 1;
   q.G = (int)G;
+  q.xmap = (disp().rt_kb_xmap && disp().rt_force_g <= 0 && G == 3LL * cus && (cus & 7) == 0 && ((G >> 3) % q.NCG) == 0 && U >= 2 * G) ? 1 : 0;
   ProfRec rec{}; bool prof = false;
   int rc = prof_begin(a, stream, 31, rec, prof);
   if (rc != SS_OK) return rc;
