@@ -337,6 +337,9 @@ int ss_debug_sk_errors(void);
 /* Test hook for the key-split form of the single-utterance rel-pos attention (csrc/attention.hip): -1 never split, 0 the
  * launch heuristic (default), n > 0 force n key tiles (of 64 keys) per split. */
 int ss_debug_attention_split(int v);
+/* Test hook for the few-queries form of the rel-pos attention (attention_relpos_q16_kernel: <= 48 query rows over all keys, the
+ * incremental streaming encoder's calls): 0 = off (the 64-query tile kernel takes those launches), 1 = on (default). */
+int ss_debug_attention_q16(int v);
 /* Test hook: the next launch of the persistent MT decode step behaves as if a bounded wait had timed out (it publishes -1),
  * without touching the counter above.  tests/test_mt_persistent_gpu.py drives the fall-back with it. */
 int ss_debug_mt_inject_timeout(ss_model* m);

@@ -15,6 +15,7 @@
 namespace ss {
 
 void attention_debug_no_mfma(int v) { dispatch_edit([v](Dispatch& d) { d.attn_no_mfma = v; }); }   // test hook: route plain attention to the VALU kernel
+void attention_debug_q16(int v) { dispatch_edit([v](Dispatch& d) { d.attn_q16 = v; }); }          // test hook: 0 = the few-queries form off
 void attention_debug_split(int v) { dispatch_edit([v](Dispatch& d) { d.attn_split = v; }); }   // test hook; SS_ATTN_NO_SPLIT=1: never split
 
 constexpr int QB = 16;     // query rows per workgroup
@@ -623,6 +624,180 @@ __global__ __launch_bounds__(256) void attention_relpos_mfma_kernel(AttnArgs p) 
   }
 }
 
+// -------------------------------------------------------------------------------------------------
+// Rel-pos attention of a FEW query rows over all keys: the tail rows of the incremental streaming encoder (<= 48 per policy() call,
+// 8-16 for the 320-ms agent; ss_encoder_stream_forward).  attention_relpos_mfma_kernel gives such a call one workgroup per (head, key
+// split) whose four waves are four 16-query sub-tiles -- three of them empty -- and walks a 64-key tile through LDS (K, V^T and 127
+// table rows staged, 192 MFMAs per wave and tile): 14 us per layer, all latency.  Here a workgroup is (16-query tile, 64-key tile,
+// head) and its four waves are the four 16-KEY sub-tiles: every operand fragment (q + u, q + v, K rows, the 31 table rows the sub-tile
+// can touch, V columns) is loaded straight into registers in ONE round trip, a wave issues 48 + 16 MFMAs, and the waves meet twice in
+// LDS (softmax statistics, then the 16 x 64 output sum).  Same arithmetic per score as the tile kernel (the BD term through the per-wave
+// skew patch); the softmax is normalised per key tile and merged in key-tile order by the last arriving workgroup of a (query tile,
+// head) -- the hand-off protocol of the SPLIT form above.
+// -------------------------------------------------------------------------------------------------
+constexpr int Q16_LDO = 68;           // padded row of the cross-wave output sum
+
+__global__ __launch_bounds__(256) void attention_relpos_q16_kernel(AttnArgs p) {
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+  __shared__ __attribute__((aligned(16))) float Gs_all[4 * 16 * LDG];
+  __shared__ float ms[4][16], ls[4][16];
+  __shared__ __attribute__((aligned(16))) float osum[4][16][Q16_LDO];
+  __shared__ int s_last;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int r = lane & 15, g = lane >> 4;
+  const int h = blockIdx.y, hoff = h * DH;
+  const int nqt = gridDim.x / p.ksplit;
+  const int sp = blockIdx.x / nqt, qt = blockIdx.x - sp * nqt;
+  const int i0 = qt * 16, q0 = p.q0;
+  const int ilast = min(i0 + 16, p.Tq) - 1;
+  int kmax = p.Tk;
+  if (p.chunk > 0) kmax = min(kmax, ((ilast + q0) / p.chunk + 1) * p.chunk);
+  const int s_eff = (kmax + KT - 1) / KT;              // key tiles that hold a visible key of this query tile
+  if (sp >= s_eff) return;
+  const int jb = sp * KT + 16 * wave;                   // this wave's 16 keys
+  const int iq = i0 + r;
+  const bool q_ok = iq < p.Tq;
+  int lim = p.Tk;
+  if (p.chunk > 0) lim = min(lim, ((iq + q0) / p.chunk + 1) * p.chunk);
+  if (!q_ok) lim = 0;
+
+  // ---- every operand of the wave in one round trip ----
+  f32x4 quf[4], qvf[4], kf[4], pa[4], pb[4];
+  float vv[4][4];
+  const int pbase = jb - (q0 + i0 + 15) + p.Tk - 1;     // table row of window row 0: key jb against the tile's last query
+  const int pra = pbase + r, prb = pbase + 16 + r;
+  const bool pa_ok = pra >= 0 && pra < 2 * p.Tk - 1, pb_ok = r < 15 && prb >= 0 && prb < 2 * p.Tk - 1;
+  const bool k_ok = jb + r < p.Tk;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    const int c = hoff + 16 * kk + 4 * g;
+    f32x4 q = {0.f, 0.f, 0.f, 0.f};
+    if (q_ok) q = *reinterpret_cast<const f32x4*>(p.Q + (size_t)iq * p.ldq + c);
+    const f32x4 bu = *reinterpret_cast<const f32x4*>(p.bias_u + c);
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias_v + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { quf[kk][e] = q[e] + bu[e]; qvf[kk][e] = q[e] + bv[e]; }
+    kf[kk] = pa[kk] = pb[kk] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (k_ok) kf[kk] = *reinterpret_cast<const f32x4*>(p.K + (size_t)(jb + r) * p.ldk + c);
+    if (pa_ok) pa[kk] = *reinterpret_cast<const f32x4*>(p.P + (size_t)pra * p.ldp + c);
+    if (pb_ok) pb[kk] = *reinterpret_cast<const f32x4*>(p.P + (size_t)prb * p.ldp + c);
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int key = jb + 4 * g + e;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vv[dt][e] = key < p.Tk ? p.V[(size_t)key * p.ldv + hoff + dt * 16 + r] : 0.f;
+  }
+
+  // ---- scores: AC = K (q + u)^T, BD through the skew patch (see attention_relpos_mfma_kernel) ----
+  f32x4 s = {0.f, 0.f, 0.f, 0.f}, ga = s, gb = s;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      s = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[kk][e], quf[kk][e], s, 0, 0, 0);
+      ga = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[kk][e], qvf[kk][e], ga, 0, 0, 0);
+      gb = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[kk][e], qvf[kk][e], gb, 0, 0, 0);
+    }
+  float* Gs = Gs_all + wave * 16 * LDG;
+  *reinterpret_cast<f32x4*>(Gs + r * LDG + 4 * g) = ga;
+  *reinterpret_cast<f32x4*>(Gs + r * LDG + 16 + 4 * g) = gb;
+  const float* gr = Gs + r * LDG + 15 - r + 4 * g;
+  float mw = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int j = jb + 4 * g + e;
+    s[e] = (j < lim) ? (s[e] + gr[e]) * p.scale : -INFINITY;
+    mw = fmaxf(mw, s[e]);
+  }
+  mw = fmaxf(mw, __shfl_xor(mw, 16, 64));
+  mw = fmaxf(mw, __shfl_xor(mw, 32, 64));
+  float pe[4], lw = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { pe[e] = (s[e] > -INFINITY) ? expf(s[e] - mw) : 0.f; lw += pe[e]; }
+  lw += __shfl_xor(lw, 16, 64);
+  lw += __shfl_xor(lw, 32, 64);
+  if (g == 0) { ms[wave][r] = mw; ls[wave][r] = lw; }
+  __syncthreads();
+  {
+    const float mt = fmaxf(fmaxf(ms[0][r], ms[1][r]), fmaxf(ms[2][r], ms[3][r]));
+    const float fw = (mw > -INFINITY) ? expf(mw - mt) : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pe[e] *= fw;
+  }
+  // ---- P V: D[query][d] += P[query][key] V[key][d] -- lane (r, g) ends up with queries 4 g + e', head column 16 dt + r ----
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) {
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o = __builtin_amdgcn_mfma_f32_16x16x4f32(pe[e], vv[dt][e], o, 0, 0, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) osum[wave][4 * g + e][dt * 16 + r] = o[e];
+  }
+  __syncthreads();
+  // ---- thread (query q, columns d4 .. d4 + 3): the four waves' sums in wave order, the tile's (m, l) ----
+  const int q = t >> 4, d4 = (t & 15) * 4;
+  f32x4 acc = *reinterpret_cast<const f32x4*>(&osum[0][q][d4]);
+#pragma unroll
+  for (int w2 = 1; w2 < 4; ++w2) {
+    const f32x4 o2 = *reinterpret_cast<const f32x4*>(&osum[w2][q][d4]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] += o2[e];
+  }
+  float m_run = fmaxf(fmaxf(ms[0][q], ms[1][q]), fmaxf(ms[2][q], ms[3][q])), l_run = 0.f;
+#pragma unroll
+  for (int w2 = 0; w2 < 4; ++w2) l_run += (ms[w2][q] > -INFINITY) ? ls[w2][q] * expf(ms[w2][q] - m_run) : 0.f;
+
+  if (s_eff > 1) {
+    const int slot0 = (qt * (int)gridDim.y + h) * p.ksplit;
+    {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.part + (size_t)(slot0 + sp) * ATTN_PART_FLOATS), 0, ATTN_PART_FLOATS * 4, 0x00020000);
+      const u32x4 v = {__float_as_uint(acc[0]), __float_as_uint(acc[1]), __float_as_uint(acc[2]), __float_as_uint(acc[3])};
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs, (q * 64 + d4) * 4, 0, 16);          // aux 16 = sc1 (agent scope)
+      if ((t & 15) == 0) {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(m_run), rs, (1024 + q) * 4, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(l_run), rs, (1040 + q) * 4, 0, 16);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    unsigned* cnt = p.cnt + qt * (int)gridDim.y + h;
+    if (t == 0) s_last = (__hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(s_eff - 1)) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    // ---- the last arrival merges every key tile, in key-tile order ----
+    float mx = -INFINITY;
+    for (int g2 = 0; g2 < s_eff; ++g2) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.part + (size_t)(slot0 + g2) * ATTN_PART_FLOATS), 0, ATTN_PART_FLOATS * 4, 0x00020000);
+      mx = fmaxf(mx, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (1024 + q) * 4, 0, 16)));
+    }
+    acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    l_run = 0.f;
+    for (int g2 = 0; g2 < s_eff; ++g2) {
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          (void*)(p.part + (size_t)(slot0 + g2) * ATTN_PART_FLOATS), 0, ATTN_PART_FLOATS * 4, 0x00020000);
+      const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (q * 64 + d4) * 4, 0, 16);
+      const float mg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (1024 + q) * 4, 0, 16));
+      const float lg = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (1040 + q) * 4, 0, 16));
+      const float f = (mg > -INFINITY) ? expf(mg - mx) : 0.f;
+      l_run += lg * f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += __uint_as_float(v[e]) * f;
+    }
+    if (t == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch of this context
+  }
+  if (i0 + q < p.Tq) {
+    const float inv = 1.0f / l_run;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc[e] *= inv;
+    *reinterpret_cast<f32x4*>(p.O + (size_t)(i0 + q) * p.ldo + hoff + d4) = acc;
+  }
+}
+
 int launch_attention(const AttnArgs& a, hipStream_t stream) {
   const int tq = a.nseg > 0 ? a.max_q : a.Tq;
   if (tq <= 0 || (a.nseg == 0 && a.Tk <= 0)) return SS_OK;
@@ -645,6 +820,14 @@ int launch_attention(const AttnArgs& a, hipStream_t stream) {
     if (a.nseg > 0 && a.p_tmax <= 0) return SS_ERR_ARG;
     if (!disp().attn_no_mfma && ((a.ldq | a.ldo) & 3) == 0 && a.k_mask_tail == 0 && !a.causal) {
       const int nqt = cdiv(tq, MQ), nkt = cdiv(a.Tk, KT);
+      // a few query rows over all keys (the incremental streaming encoder's tail rows): 16-query tiles, one workgroup per key tile
+      if (a.nseg == 0 && tq <= 48 && disp().attn_q16 && (nkt == 1 || (a.part && cdiv(tq, 16) * a.H <= a.cnt_slots && cdiv(tq, 16) * a.H * nkt <= a.part_slots))) {
+        AttnArgs b = a;
+        b.ksplit = nkt; b.ktiles_per_split = 1;
+        hipLaunchKernelGGL(attention_relpos_q16_kernel, dim3(cdiv(tq, 16) * nkt, a.H, 1), dim3(256), 0, stream, b);
+        SS_LAUNCH_CHECK();
+        return SS_OK;
+      }
       // key split: one utterance with few (query tile, head) pairs and more than one key tile
       if (a.nseg == 0 && a.part && disp().attn_split >= 0 && nkt >= 2 && nqt * a.H <= a.cnt_slots && nqt * a.H < 128) {
         int tps = disp().attn_split > 0 ? disp().attn_split : cdiv(nkt, std::min(16, std::max(1, 256 / (nqt * a.H))));

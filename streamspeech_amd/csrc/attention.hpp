@@ -51,6 +51,7 @@ inline void attention_bind_split(AttnArgs& a, void* scratch) {
   a.cnt = reinterpret_cast<unsigned*>(a.part + (size_t)ATTN_PART_SLOTS * ATTN_PART_FLOATS);
   a.part_slots = ATTN_PART_SLOTS; a.cnt_slots = ATTN_CNT_SLOTS;
 }
+void attention_debug_q16(int v);       // test hook: 0 = never the few-queries rel-pos form (attention_relpos_q16_kernel), 1 = default
 void attention_debug_split(int v);     // test hook: -1 never split, 0 heuristic, n > 0 key tiles per split = n
 
 int launch_attention(const AttnArgs& a, hipStream_t stream);

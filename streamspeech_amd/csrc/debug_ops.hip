@@ -114,6 +114,7 @@ extern "C" int ss_op_attention(void* stream, const float* dQ, int ldq, const flo
 }
 
 extern "C" int ss_debug_attention_split(int v) { attention_debug_split(v); return SS_OK; }
+extern "C" int ss_debug_attention_q16(int v) { attention_debug_q16(v); return SS_OK; }
 
 extern "C" int ss_op_dwconv_bn_silu(void* stream, const float* dx, int ldx, float* dy, int ldy, const float* dwt,
                                     int K, const float* mean, const float* var, const float* gamma,

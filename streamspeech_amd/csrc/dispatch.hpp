@@ -17,6 +17,7 @@ namespace ss {
 struct Dispatch {
   // attention.hip
   int attn_no_mfma = 0;            // test hook: plain attention on the VALU kernel
+  int attn_q16 = 1;                // SS_ATTN_Q16=0: rel-pos attention of <= 48 query rows on the 64-query tile kernel instead of attention_relpos_q16_kernel
   int attn_split = 0;              // -1 never split keys, 0 heuristic, n > 0 key tiles per split        SS_ATTN_NO_SPLIT
   // per-conv slab kernels of the vocoder stages (conv_c16 / c32 / c64.hip) and their Winograd forms (conv_c64w.hip)
   int c16_off = 0, c32_off = 0, c64_off = 0;                                          // SS_NO_CONV_C16 / C32 / C64

@@ -891,7 +891,7 @@ Dispatch env_defaults() {
   Dispatch d;
   auto I = [](const char* k, int dflt) { const char* e = getenv(k); return e ? atoi(e) : dflt; };
   auto L = [](const char* k, long long dflt) { const char* e = getenv(k); return e ? atoll(e) : dflt; };
-  d.attn_split = I("SS_ATTN_NO_SPLIT", 0) ? -1 : 0;
+  d.attn_split = I("SS_ATTN_NO_SPLIT", 0) ? -1 : 0; d.attn_q16 = I("SS_ATTN_Q16", d.attn_q16);
   d.c16_off = I("SS_NO_CONV_C16", 0) ? 1 : 0; d.c32_off = I("SS_NO_CONV_C32", 0) ? 1 : 0; d.c64_off = I("SS_NO_CONV_C64", 0) ? 1 : 0;
   d.c16_min_rows = L("SS_CONV_C16_MIN_ROWS", d.c16_min_rows); d.c32_min_rows = L("SS_CONV_C32_MIN_ROWS", d.c32_min_rows);
   d.c64_min_rows = L("SS_CONV_C64_MIN_ROWS", d.c64_min_rows);

@@ -100,6 +100,7 @@ SIGNATURES = {
     "ss_debug_last_logits": (_i, [_vp, _vp, _vp, _i64, C.POINTER(_i), C.POINTER(_i)]),
     "ss_debug_sk_errors": (_i, []),
     "ss_debug_attention_split": (_i, [_i]),
+    "ss_debug_attention_q16": (_i, [_i]),
     "ss_op_conv_gemm": (_i, [_vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                              _i, _f, _i, _f, _f, _i]),
     "ss_op_layernorm": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _f]),

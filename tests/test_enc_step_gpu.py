@@ -70,3 +70,32 @@ def test_calls_with_more_than_48_rows_take_the_launch_per_op_form(model):
     assert lib.ss_debug_enc_step_launches() == n0
     assert (out - model.encoder_forward(fb, 8, 8)).abs().max().item() < 5e-5
     model.encoder_stream_reset()
+
+
+@pytest.mark.parametrize("persistent", [0, 64])
+@pytest.mark.parametrize("ac,cc,step", [(8, 8, 32), (16, 16, 64), (24, 16, 150)])
+def test_few_queries_attention_kernel_equals_the_tile_kernel_on_streaming_calls(model, persistent, ac, cc, step):
+    """attention_relpos_q16_kernel (<= 48 query rows at offset q0 over ALL keys so far: one workgroup per 16-query tile, 64-key tile and
+    head, key tiles merged by the last arrival) against the 64-query tile kernel on the same calls: prefixes up to 12 s, so 1 ... 5 key
+    tiles, in the launch-per-op and the persistent form; repeated runs reproduce their bits (arrival counters back at zero)."""
+    from streamspeech_amd import synth
+    lib = model.lib
+    fb_all = torch.from_numpy(synth.synth_fbank(47, 1200)).to(model.device)
+    Ts = list(range(40, 1200, step)) + [1200]
+    model.set_persistent_mt_step(persistent)
+    try:
+        lib.ss_debug_attention_q16(0)
+        ref, ref_final = _drive(model, fb_all, ac, cc, Ts)
+        lib.ss_debug_attention_q16(1)
+        got, got_final = _drive(model, fb_all, ac, cc, Ts)
+        again, _ = _drive(model, fb_all, ac, cc, Ts)
+    finally:
+        lib.ss_debug_attention_q16(1)
+        model.set_persistent_mt_step(64)
+    assert got_final == ref_final
+    for a, b, c in zip(got, ref, again):
+        assert (a - b).abs().max().item() < 2e-5
+        assert torch.equal(a, c)
+    full = model.encoder_forward(fb_all, ac, cc)
+    assert (got[-1] - full).abs().max().item() < 5e-5
+    assert lib.ss_debug_sk_errors() == 0

@@ -180,7 +180,7 @@ def _attn_ref(q, k, v, H, scale, causal, chunk, P=None, u=None, vb=None):
     return torch.matmul(torch.softmax(s, -1), vh).transpose(0, 1).reshape(Tq, H * 64)
 
 
-@pytest.mark.parametrize("T,chunk", [(21, 0), (21, 8), (125, 0), (125, 16), (200, 8), (64, 0), (65, 24)])
+@pytest.mark.parametrize("T,chunk", [(21, 0), (21, 8), (125, 0), (125, 16), (200, 8), (64, 0), (65, 24), (1, 0), (16, 8), (17, 16), (33, 8), (48, 0), (48, 24)])   # <= 48 rows: attention_relpos_q16_kernel
 def test_relpos_attention(lib, T, chunk):
     from streamspeech_amd import lib as L
     H = 4
