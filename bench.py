@@ -27,6 +27,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # kernel arguments in device memory (streamspeech_amd/__init__.py): must precede the first HIP call
+
 import numpy as np
 import torch
 

@@ -10,6 +10,8 @@ _NT = os.environ.get("SS_TEST_THREADS", "4")
 for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
     os.environ.setdefault(_k, _NT)
 
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")     # as the package sets it (streamspeech_amd/__init__.py), before anything starts the HIP runtime
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
