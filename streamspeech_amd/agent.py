@@ -75,6 +75,8 @@ class StreamSpeechS2STAgent(SpeechToSpeechAgent):
         self.ctc_generator = CTCSequenceGenerator(tgt_dict, eng, use_incremental_states=False, t2u_causal=uni)
         self.asr_ctc_generator = CTCDecoder(self.dict["source_unigram"], eng, 0)
         self.st_ctc_generator = CTCDecoder(self.dict["ctc_target_unigram"], eng, 1)
+        if hasattr(eng, "set_persistent_mt_step"):
+            eng.ctc_speculate = True                     # policy() asks for both CTC heads of every encoder output: one host round trip (engine.ctc_greedy)
         # generator_mt of the reference: beam 1, max_len_a=0, max_len_b=100, min_len=1 (agent :162-180)
         self.generator_mt = SequenceGenerator(eng, tgt_dict_mt, beam_size=1, max_len_a=0, max_len_b=100, max_len=0,
                                               min_len=1, eos=tgt_dict_mt.eos(), use_incremental_states=False)

@@ -33,6 +33,8 @@ class _TextAgentBase(SpeechToTextAgent):
             eng.set_persistent_mt_step(int(getattr(args, "mt_step_workgroups", 64)))
         self.asr_ctc_generator = CTCDecoder(self.dict["source_unigram"], eng, 0)
         self.st_ctc_generator = CTCDecoder(self.dict["ctc_target_unigram"], eng, 1)
+        if hasattr(eng, "set_persistent_mt_step"):       # both CTC heads per call only in the translation agent (engine.ctc_greedy)
+            eng.ctc_speculate = type(self).__name__ == "StreamSpeechS2TTAgent"
         tgt_dict_mt = self.dict[self.model.mt_task_name]
         # the text agents search with max_len_a=1, max_len_b=200 (s2tt agent :161-180) -- NOT the S2ST agent's 0 / 100:
         # a final hypothesis may run to (fbank frames + 200) subwords

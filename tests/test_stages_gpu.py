@@ -409,3 +409,45 @@ def test_offline_parity_sweep_vs_oracle(hip_model, hip_vocoder, synth_weights, s
         rms = float(torch.sqrt(torch.mean((out["wav"].cpu() - ref["wav"]) ** 2)))
         assert rms < WAV_RMS_TOL, f"rms {rms}"
     _tight(rms, WAV_RMS_TIGHT, "waveform rms")
+
+
+def test_both_ctc_heads_behind_one_round_trip_equal_the_separate_calls(hip_model):
+    """engine.ctc_greedy with ``ctc_speculate`` (the agents set it): the first head asked of the encoder output the engine produced last
+    also runs the other head and parks its answer; the second request takes it.  Same tokens / frame indices / raw ids as two separate
+    calls; the parked answer is handed out once, dies with the next encoder call, and is never used for another tensor or for a
+    request that wants logits."""
+    from streamspeech_amd import synth
+    m = hip_model
+    fb = torch.from_numpy(synth.synth_fbank(51, 330)).to(m.device)
+    enc = m.encoder_forward(fb, 8, 8)
+    m.ctc_speculate = False
+    ref = [m.ctc_greedy(h, enc) for h in (0, 1)]
+    try:
+        m.ctc_speculate = True
+        enc2 = m.encoder_forward(fb, 8, 8)
+        a0 = m.ctc_greedy(0, enc2)
+        assert m._ctc_stash is not None and m._ctc_stash[1] == 1
+        a1 = m.ctc_greedy(1, enc2)
+        assert m._ctc_stash is None                                   # handed out once
+        for got, want in ((a0, ref[0]), (a1, ref[1])):
+            assert got[0] == want[0] and got[1] == want[1] and torch.equal(got[2], want[2])
+        b1 = m.ctc_greedy(1, enc2)                                    # the other order
+        b0 = m.ctc_greedy(0, enc2)
+        assert b1[0] == ref[1][0] and b0[0] == ref[0][0]
+        m.ctc_greedy(0, enc2)                                         # parks head 1 ...
+        other = torch.zeros_like(enc2)
+        z1 = m.ctc_greedy(1, other)                                   # ... which must not answer for another tensor
+        assert z1[0] == m.ctc_greedy(1, other)[0] and m._ctc_stash is None
+        m.ctc_greedy(0, enc2)
+        enc3 = m.encoder_forward(fb[:200].contiguous(), 8, 8)         # a new encoder output: the parked answer is gone
+        assert m._ctc_stash is None
+        c1 = m.ctc_greedy(1, enc3)
+        m.ctc_speculate = False
+        assert c1[0] == m.ctc_greedy(1, enc3)[0]
+        m.ctc_speculate = True
+        m.ctc_greedy(0, enc3)
+        lg = m.ctc_greedy(1, enc3, want_logits=True)                  # a request for logits is always computed
+        assert lg[3] is not None and lg[0] == c1[0]
+    finally:
+        m.ctc_speculate = False
+        m._ctc_stash = None
