@@ -136,6 +136,16 @@ int ss_encoder_stream_reset(ss_model* m);
 int ss_encoder_stream_set_tail(ss_model* m, int unsettled_fbank_frames);
 int ss_encoder_stream_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
                               int conv_chunk, float* d_enc_out, int32_t* n_final, int32_t* n_computed);
+/* Deferred time-out check (off by default).  On a scratch set that runs the persistent forms (ss_mt_set_persistent), the call above ends
+ * with a stream synchronisation: it must know that none of its persistent layer launches timed out before anybody reads d_enc_out.
+ * A caller that queues more work behind the encoder anyway and synchronises once for all of it -- the agent's policy(): both CTC heads,
+ * then one device-to-host copy -- switches the check to deferred (on = 1): ss_encoder_stream_forward then returns without waiting, and
+ * ss_encoder_stream_status waits for the stream, sets *repeat = 1 if a launch timed out (the scratch set has then left the persistent
+ * form and the failed call's rows are not final any more) and 0 otherwise.  With *repeat = 1 everything computed from d_enc_out since
+ * the forward call is void: call ss_encoder_stream_forward again (it now runs one launch per op and waits) and recompute.  Until the
+ * status call returns 0, d_enc_out must not be trusted.  A forward call with a check still outstanding settles it first. */
+int ss_encoder_stream_set_deferred(ss_model* m, int on);
+int ss_encoder_stream_status(ss_model* m, void* stream, int32_t* repeat);
 
 /* ---- a8: CTCDecoder.generate (agent/ctc_decoder.py:39-111): head 0 = source_unigram (ASR),
  * 1 = ctc_target_unigram (ST).  Outputs (device int32): raw argmax per frame [Tp], collapsed
@@ -340,6 +350,9 @@ int ss_debug_attention_split(int v);
 /* Test hook for the few-queries form of the rel-pos attention (attention_relpos_q16_kernel: <= 48 query rows over all keys, the
  * incremental streaming encoder's calls): 0 = off (the 64-query tile kernel takes those launches), 1 = on (default). */
 int ss_debug_attention_q16(int v);
+/* Test hook: the next time-out check of this handle's scratch set (ss_encoder_stream_status, or the end of a non-deferred
+ * ss_encoder_stream_forward) reports a time-out although none happened -- drives the fall-back and the repeat protocol. */
+int ss_debug_enc_step_inject_timeout(ss_model* m);
 /* Test hook: the next launch of the persistent MT decode step behaves as if a bounded wait had timed out (it publishes -1),
  * without touching the counter above.  tests/test_mt_persistent_gpu.py drives the fall-back with it. */
 int ss_debug_mt_inject_timeout(ss_model* m);

@@ -184,7 +184,11 @@ template <int NT>
     const unsigned long long t0 = wall_clock64();
     while ((int)(__hip_atomic_load(p.bar, ES_RLX) - target) < 0) {
       if (__hip_atomic_load(p.err, ES_RLX) != 0u) break;
-      if (wall_clock64() - t0 > ES_WAIT_TICKS) { atomicAdd(p.err, 1u); break; }
+      if (wall_clock64() - t0 > ES_WAIT_TICKS) {
+        atomicAdd(p.err, 1u);
+        __hip_atomic_fetch_add(p.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
       __builtin_amdgcn_s_sleep(2);
     }
   }
@@ -491,7 +495,7 @@ static int launch_enc_step_nt(const EsArgs& a, hipStream_t stream) {
 // The kernel is compiled for 1, 2 and 3 MFMA row tiles: a read call of the 320-ms agent recomputes ~8-16 rows, and the 48-row form spent
 // two thirds of its MFMAs (and of its staging loads) on rows that do not exist.  Per row the arithmetic is the same in all three.
 int launch_enc_step(const EsArgs& a, hipStream_t stream) {
-  if (a.n <= 0 || a.n > ES_MAXR || a.ph0 > a.ph1 || a.dwk > 31 || !a.err || !a.bar || !a.part || !a.g2) return SS_ERR_ARG;
+  if (a.n <= 0 || a.n > ES_MAXR || a.ph0 > a.ph1 || a.dwk > 31 || !a.err || !a.err_host || !a.bar || !a.part || !a.g2) return SS_ERR_ARG;
   const int nt = (a.n + 15) / 16;
   const int rc = nt == 1 ? launch_enc_step_nt<1>(a, stream) : nt == 2 ? launch_enc_step_nt<2>(a, stream) : launch_enc_step_nt<3>(a, stream);
   if (rc != SS_OK) return rc;

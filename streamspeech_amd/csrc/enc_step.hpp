@@ -26,7 +26,8 @@ struct EsArgs {
   float* part;                // [ES_G][ES_MAXR][256] partial FFN outputs
   unsigned* bar;              // monotone arrival counter of this scratch set (zeroed once)
   unsigned bar_base;          // its value when this launch starts
-  unsigned* err;              // bounded-wait time-outs (must stay 0)
+  unsigned* err;              // bounded-wait time-outs (must stay 0): the device word every waiting workgroup polls
+  unsigned* err_host;         // the same count in pinned host memory, written only BY a time-out (read by the host after its synchronisation)
   int n, r0, T2, cchunk, dwk;
   int ph0, ph1;        // phases [ph0, ph1] of the layer (0-2: FFN1 + QKV; 4-9: attention output ... FFN2 + final LayerNorm)
 };

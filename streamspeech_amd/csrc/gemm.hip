@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256 * KS) void conv_gemm_kernel(const GemmArgs p) {
     const int* s = p.segs + 4 * blockIdx.z;
     out_start = s[0]; out_len = s[1]; in_start = s[2]; in_len = s[3];
   }
-  const int m0 = blockIdx.x * BM;
+  const int m0 = blockIdx.x * BM + p.m_begin;
   if (m0 >= out_len) return;
   const int n0 = blockIdx.y * BN;
   const int kpt = p.Cin / BK;          // k-steps per tap
@@ -816,7 +816,7 @@ static int launch_cfg(const GemmArgs& a, hipStream_t stream, int cls) {
   static_assert(kLds <= 160 * 1024, "LDS budget");
   static_assert((size_t)(KS - 1) * BM * BN * sizeof(float) <= kLds, "reduction scratch fits the staging buffers");
   if constexpr (kLds > 64 * 1024) SS_MAX_LDS_ONCE((&conv_gemm_kernel<BM, BN, BK, WM, WN, KS, PD, BLK>), kLds);
-  const int mmax = a.nseg > 0 ? a.max_seg_out : a.M;
+  const int mmax = (a.nseg > 0 ? a.max_seg_out : a.M) - a.m_begin;
   dim3 grid(cdiv(mmax, BM), cdiv(a.N, BN), a.nseg > 0 ? a.nseg : 1);
   // XCD affinity (speed only): blocks land on XCD (linear id % 8).  With a multiple of 8 m-tiles per grid row every n-tile
   // column keeps m-tile i on XCD i % 8, so each XCD's L2 fetches 1/8 of the A rows (and all of W) instead of all of both --
@@ -1051,7 +1051,13 @@ int launch_conv_gemm(const GemmArgs& a_in, hipStream_t stream) {
   const bool k32 = (a.Cin % 32) == 0;
   const int nseg = a.nseg > 0 ? a.nseg : 1;
   if (a.canon == CANON_NONE) a.canon = t_canon;
-  if (a.canon != CANON_NONE && !disp().force_bm) return launch_canon(a, stream);
+  if (a.canon != CANON_NONE && !disp().force_bm) { a.m_begin = 0; return launch_canon(a, stream); }
+  if (a.m_begin > 0) {       // a row range of a strided conv (ss_encoder_stream_forward): only the LDS-tile kernel starts anywhere but row 0
+    if (a.nseg > 0 || a.m_begin >= a.M || a.ln_g || a.ln_out || a.N <= 32) return SS_ERR_ARG;
+    const long t = (long)cdiv(a.M - a.m_begin, 32) * cdiv(a.N, 64);
+    if (k32 && t >= 768) return launch_cfg<32, 64, 32, 2, 2, 1>(a, stream, 9);
+    return k32 ? launch_cfg_ks<32, 64, 32, 2, 2, 4>(a, stream, 9, t) : launch_cfg_ks<32, 64, 16, 2, 2, 4>(a, stream, 10, t);
+  }
   // a forced tile (tuning hook) keeps M <= 4 launches off the GEMV -- except when the caller asked for ln_out, which only the GEMV writes
   if ((!disp().force_bm || a.ln_out) && gemv_eligible(a)) return launch_gemv(a, stream);
   if (a.ln_out) return SS_ERR_ARG;      // only the GEMV form publishes the normalised rows

@@ -27,6 +27,9 @@ struct GemmArgs {
   int taps = 1, dil = 1, stride = 1, pad = 0;
   int in_len = 0;             // valid input rows
   int chunk = 0;              // chunk-causal visibility (0 = off)
+  int m_begin = 0;            // conv_gemm tile kernel only (single utterance, no LayerNorm fusion): compute output rows [m_begin, M) -- pointers,
+                              // in_len and the chunk rule stay those of row 0, so a row's bits do not depend on where the launch starts
+                              // (the incremental streaming encoder re-runs the subsampler for its non-final rows only)
   int in_act = ACT_NONE;      // ACT_NONE or ACT_LRELU applied to A while staging
   float in_slope = 0.1f;
   int act = ACT_NONE;         // epilogue activation on (acc + bias)

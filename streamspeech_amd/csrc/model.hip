@@ -344,6 +344,7 @@ static int stream_final_rows(int T, int T1, int T2, int k, int achunk, int cchun
 extern "C" int ss_encoder_stream_reset(ss_model* m) {
   if (!m) return SS_ERR_ARG;
   m->sc->es_final = 0; m->sc->es_achunk = -1; m->sc->es_cchunk = -1;
+  m->sc->es_final_prev = 0;      // (a deferred check that is still outstanding must not bring the old utterance's rows back)
   return SS_OK;
 }
 
@@ -353,11 +354,62 @@ extern "C" int ss_encoder_stream_set_tail(ss_model* m, int unsettled_fbank_frame
   return SS_OK;
 }
 
+// The time-out check of the persistent layer launches: waits for the stream, reads the pinned error word; on a time-out the scratch
+// set leaves the persistent form, the rows of the failed call stop being final, and the caller must repeat the call.
+static int es_check(ss_model* m, hipStream_t s, bool* repeat) {
+  ss_scratch* sc = m->sc;
+  *repeat = false;
+  SS_HIP_CHECK(hipStreamSynchronize(s));
+  sc->es_pending = 0;
+  unsigned e = sc->es_err_host ? *static_cast<volatile unsigned*>(sc->es_err_host) : 0u;   // written by a timed-out wait only (system scope; visible after the synchronisation)
+  if (sc->es_inject) { e += 1u; sc->es_inject = 0; }
+  if (!e) return SS_OK;
+  fprintf(stderr, "streamspeech_hip: persistent encoder-layer launch timed out (its %d workgroups were not all resident); "
+                  "this context falls back to one launch per op\n", ES_G);
+  g_mt_timeouts.fetch_add((int)e, std::memory_order_relaxed);
+  if (sc->es_err_host) *sc->es_err_host = 0u;
+  if (sc->es_step.p) {
+    unsigned* es_sync = reinterpret_cast<unsigned*>(sc->es_step.f() + (size_t)ES_G * ES_MAXR * ES_D + (size_t)ES_MAXR * ES_D);
+    SS_HIP_CHECK(hipMemsetAsync(es_sync, 0, 512, s));
+  }
+  sc->es_bar = 0;
+  sc->es_step_off = 1;
+  sc->es_final = sc->es_final_prev;
+  *repeat = true;
+  return SS_OK;
+}
+
+extern "C" int ss_encoder_stream_set_deferred(ss_model* m, int on) {
+  if (!m) return SS_ERR_ARG;
+  m->sc->es_deferred = on ? 1 : 0;
+  return SS_OK;
+}
+
+extern "C" int ss_encoder_stream_status(ss_model* m, void* stream, int32_t* repeat) {
+  if (!m || !repeat) return SS_ERR_ARG;
+  *repeat = 0;
+  if (!m->sc->es_pending && !m->sc->es_inject) return SS_OK;
+  bool rep = false;
+  RET(es_check(m, (hipStream_t)stream, &rep));
+  *repeat = rep ? 1 : 0;
+  return SS_OK;
+}
+
+extern "C" int ss_debug_enc_step_inject_timeout(ss_model* m) {
+  if (!m) return SS_ERR_ARG;
+  m->sc->es_inject = 1;
+  return SS_OK;
+}
+
 extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float* d_fbank, int T, int attn_chunk,
                                          int conv_chunk, float* d_enc_out, int32_t* n_final, int32_t* n_computed) {
   if (!m || T <= 0) return SS_ERR_ARG;
   SkScope sk_scope(m->sc->skws);
   hipStream_t s = (hipStream_t)stream;
+  if (m->sc->es_pending) {        // the caller skipped ss_encoder_stream_status: settle the previous call first (its rows stop being final if it failed)
+    bool rep = false;
+    RET(es_check(m, s, &rep));
+  }
   const ss_config& c = m->cfg;
   const int d = c.enc_dim, f = c.enc_ffn, k = c.conv_kernel, Ld = c.enc_layers * d, L = c.enc_layers;
   const int T1 = conv_out_len(T, k, 2), T2 = conv_out_len(T1, k, 2);
@@ -403,16 +455,21 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
   float* ff = g2 + n_x;                 // FFN hidden (tail rows)
   float* x = d_enc_out + (size_t)r0 * d;  // running activations of the tail rows live in the output buffer
 
-  {
+  if (n > 0) {
+    // Only rows >= r0 of the subsampler output are read below: conv 2 starts at row r0, conv 1 at the first row conv 2 can reach
+    // (2 r0 - pad).  Both keep absolute row indices (GemmArgs::m_begin), so halo rows and the chunk rule are those of the full call;
+    // with the fbank rows cached by the front-end, nothing in front of the layers grows with the length of the utterance any more.
     GemmArgs a;
     a.A = d_fbank; a.lda = c.input_feat; a.W = m->sub0.w; a.bias = m->sub0.b; a.C = h1; a.ldc = c.conv_channels / 2;
     a.M = T1; a.N = c.conv_channels; a.Cin = c.input_feat; a.taps = k; a.stride = 2; a.pad = k / 2;
     a.in_len = T; a.chunk = cchunk; a.glu = 1;
+    a.m_begin = std::min(std::max(0, 2 * r0 - k / 2), T1 - 1);
     RET(launch_conv_gemm(a, s));
     GemmArgs b;
     b.A = h1; b.lda = c.conv_channels / 2; b.W = m->sub1.w; b.bias = m->sub1.b; b.C = g0; b.ldc = d;
     b.M = T2; b.N = 2 * d; b.Cin = c.conv_channels / 2; b.taps = k; b.stride = 2; b.pad = k / 2;
     b.in_len = T1; b.chunk = cchunk; b.glu = 1;
+    b.m_begin = r0;
     RET(launch_conv_gemm(b, s));
   }
   if (r0 > 0)
@@ -426,6 +483,10 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
     RET(m->sc->es_step.ensure(enc_step_scratch_bytes()));
     SS_HIP_CHECK(hipMemsetAsync(m->sc->es_step.p, 0, enc_step_scratch_bytes(), s));
     m->sc->es_bar = 0;
+  }
+  if (es_persistent && !m->sc->es_err_host) {
+    SS_HIP_CHECK(hipHostMalloc((void**)&m->sc->es_err_host, 64));
+    *m->sc->es_err_host = 0u;
   }
   float* es_part = es_persistent ? m->sc->es_step.f() : nullptr;
   float* es_g2 = es_persistent ? es_part + (size_t)ES_G * ES_MAXR * ES_D : nullptr;
@@ -444,7 +505,7 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
                        e.conv_ln.g, e.conv_ln.b, e.pw1.w, e.dw_wt, e.bn_mean, e.bn_var, e.bn_g, e.bn_b, e.pw2.w,
                        e.ffn2_ln.g, e.ffn2_ln.b, e.ffn2_w1.w, e.ffn2_w1.b, e.ffn2_w2.w, e.ffn2_w2.b, e.final_ln.g, e.final_ln.b};
         a.x = x; a.qkv = qkv; a.glu = glu; a.hctx = h; a.part = es_part; a.g2 = es_g2; a.bar = es_sync;
-        a.err = es_sync + 64; a.n = n; a.r0 = r0; a.T2 = T2; a.cchunk = cchunk; a.dwk = c.dw_kernel;
+        a.err = es_sync + 64; a.err_host = m->sc->es_err_host; a.n = n; a.r0 = r0; a.T2 = T2; a.cchunk = cchunk; a.dwk = c.dw_kernel;
         a.ph0 = 0; a.ph1 = 2; a.bar_base = m->sc->es_bar;
         RET(launch_enc_step(a, s));
         m->sc->es_bar += (unsigned)ES_G * 2u;
@@ -479,17 +540,14 @@ extern "C" int ss_encoder_stream_forward(ss_model* m, void* stream, const float*
     }
   }
   if (es_persistent) {
-    unsigned e = 0;
-    SS_HIP_CHECK(hipMemcpyAsync(&e, es_sync + 64, sizeof(e), hipMemcpyDeviceToHost, s));
-    SS_HIP_CHECK(hipStreamSynchronize(s));
-    if (e) {     // a workgroup of some launch was not resident: count it, leave the persistent form, compute this call again the other way
-      fprintf(stderr, "streamspeech_hip: persistent encoder-layer launch timed out (its %d workgroups were not all resident); "
-                      "this context falls back to one launch per op\n", ES_G);
-      g_mt_timeouts.fetch_add((int)e, std::memory_order_relaxed);
-      SS_HIP_CHECK(hipMemsetAsync(es_sync, 0, 512, s));
-      m->sc->es_bar = 0;
-      m->sc->es_step_off = 1;
-      return ss_encoder_stream_forward(m, stream, d_fbank, T, attn_chunk, conv_chunk, d_enc_out, n_final, n_computed);
+    m->sc->es_final_prev = r0;
+    if (m->sc->es_deferred) {
+      m->sc->es_pending = 1;      // ss_encoder_stream_status (or the next forward) settles it
+    } else {
+      bool rep = false;
+      RET(es_check(m, s, &rep));
+      if (rep)                    // a workgroup of some launch was not resident: this call again, one launch per op
+        return ss_encoder_stream_forward(m, stream, d_fbank, T, attn_chunk, conv_chunk, d_enc_out, n_final, n_computed);
     }
   }
   const int nf = std::max(r0, stream_final_rows(T, T1, T2, k, achunk_cfg, cchunk, c.dw_kernel, m->sc->es_tail));
@@ -564,6 +622,7 @@ extern "C" int ss_mt_set_persistent(ss_model* m, int workgroups) {
   if (!m || !(workgroups == 0 || workgroups == 64 || workgroups == 128 || workgroups == 256)) return SS_ERR_ARG;
   if (m->sc->mt_persistent > 0) RET(mt_collect_errors(m));
   m->sc->mt_persistent = workgroups;
+  if (workgroups > 0) m->sc->es_step_off = 0;      // asking for the persistent forms again also re-arms the persistent layer launches
   return SS_OK;
 }
 

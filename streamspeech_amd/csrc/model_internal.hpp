@@ -200,6 +200,12 @@ struct ss_scratch {
   DevBuf es_step;       // persistent layer launches (enc_step.hip): partial FFN outputs, depthwise output, arrival counter + error word (zeroed once)
   unsigned es_bar = 0;  // value of the arrival counter when the next launch starts
   int es_step_off = 0;  // 1 after a time-out: this scratch set stays on one launch per op
+  int es_deferred = 0;  // ss_encoder_stream_set_deferred: the persistent form's time-out check is left to ss_encoder_stream_status
+  int es_pending = 0;   // a deferred check is outstanding (the last forward's output must not be trusted yet)
+  int es_final_prev = 0;   // es_final before that forward (restored when the check fails)
+  int es_inject = 0;    // test hook: the next check reports a time-out
+  unsigned* es_err_host = nullptr;   // pinned host word the persistent layer launches bump on a time-out (next to the device word the workgroups poll):
+                                     // the host reads it after its stream synchronisation -- no device-to-host copy per call
   int es_cap = 0, es_final = 0, es_achunk = -1, es_cchunk = -1;
   int es_tail = 0;                                  // trailing fbank frames that may still change (resampler edge)
   // ss_debug_last_logits: where the last batched argmax stage of this context left its dense logits (scratch, valid until the
@@ -215,6 +221,7 @@ struct ss_scratch {
   ~ss_scratch() {
     for (DevBuf* b : all()) b->release();
     if (mt_tok_host) (void)hipHostFree(mt_tok_host);
+    if (es_err_host) (void)hipHostFree(es_err_host);
     sk_workspace_free(skws);
   }
   std::vector<DevBuf*> all() {

@@ -244,11 +244,13 @@ class HipModel(BatchMixin):
         return out
 
     # ---- a1 -------------------------------------------------------------------------------
-    def fbank_cmvn(self, pcm16k: torch.Tensor, pcm_scale: float = 32768.0) -> torch.Tensor:
-        """pcm16k: float32 [n] on the device -> [T, 80]."""
+    def fbank_cmvn(self, pcm16k: torch.Tensor, pcm_scale: float = 32768.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """pcm16k: float32 [n] on the device -> [T, 80] (into ``out`` -- T contiguous rows -- when given)."""
         n = pcm16k.numel()
         T = self.lib.ss_fbank_num_frames(n)
-        feat = torch.empty((T, 80), dtype=torch.float32, device=self.device)
+        if out is not None:
+            assert out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (T, 80)
+        feat = out if out is not None else torch.empty((T, 80), dtype=torch.float32, device=self.device)
         nf = C.c_int(0)
         L.check(self.lib.ss_fbank_cmvn(self.h, _stream(), _ptr(pcm16k), n, pcm_scale, _ptr(feat), C.byref(nf)),
                 "ss_fbank_cmvn")
@@ -266,7 +268,7 @@ class HipModel(BatchMixin):
         out = torch.empty((Tp, self.cfg.enc_dim), dtype=torch.float32, device=self.device)
         L.check(self.lib.ss_encoder_forward(self.h, _stream(), _ptr(fbank), T, int(min(attn_chunk, 1 << 30)),
                                             int(min(conv_chunk, 1 << 30)), _ptr(out)), "ss_encoder_forward")
-        self._last_enc, self._ctc_stash = (out.data_ptr(), Tp), None
+        self._last_enc, self._ctc_stash, self._ctc_both = (out.data_ptr(), Tp), None, None
         return out
 
     def encoder_stream_reset(self):
@@ -287,11 +289,41 @@ class HipModel(BatchMixin):
         Tp = self.lib.ss_encoder_out_len(T)
         out = torch.empty((Tp, self.cfg.enc_dim), dtype=torch.float32, device=self.device)
         nf, nc = C.c_int32(0), C.c_int32(0)
-        L.check(self.lib.ss_encoder_stream_forward(self.h, _stream(), _ptr(fbank), T, int(min(attn_chunk, 1 << 30)),
-                                                   int(min(conv_chunk, 1 << 30)), _ptr(out), C.byref(nf), C.byref(nc)),
-                "ss_encoder_stream_forward")
+
+        def forward():
+            L.check(self.lib.ss_encoder_stream_forward(self.h, _stream(), _ptr(fbank), T, int(min(attn_chunk, 1 << 30)),
+                                                       int(min(conv_chunk, 1 << 30)), _ptr(out), C.byref(nf), C.byref(nc)),
+                    "ss_encoder_stream_forward")
+        self._ctc_stash = None
+        if self.ctc_speculate and self.persistent_mt > 0 and Tp > 0 and not os.environ.get("SS_NO_CTC_DEFER"):
+            # The agents' policy() reads both CTC heads of every encoder output: queue them behind the layers and synchronise ONCE --
+            # the encoder's own time-out check is deferred to ss_encoder_stream_status (include/streamspeech_hip.h), so the device
+            # runs from the last layer straight into the heads while the host is on its way back (~40 us of a ~1-ms call).
+            L.check(self.lib.ss_encoder_stream_set_deferred(self.h, 1), "ss_encoder_stream_set_deferred")
+            try:
+                forward()
+                ibuf = torch.empty((2 * (3 * Tp + 1),), dtype=torch.int32, device=self.device)
+                for hd in (0, 1):
+                    b = ibuf[hd * (3 * Tp + 1):(hd + 1) * (3 * Tp + 1)]
+                    L.check(self.lib.ss_ctc_greedy(self.h, _stream(), hd, _ptr(out), Tp, _ptr(b[:Tp]), _ptr(b[Tp:2 * Tp]), _ptr(b[2 * Tp:3 * Tp]),
+                                                   _ptr(b[3 * Tp:]), None), "ss_ctc_greedy")
+                host = ibuf.cpu()
+                rep = C.c_int32(0)
+                L.check(self.lib.ss_encoder_stream_status(self.h, _stream(), C.byref(rep)), "ss_encoder_stream_status")
+            finally:
+                L.check(self.lib.ss_encoder_stream_set_deferred(self.h, 0), "ss_encoder_stream_set_deferred")
+            if rep.value:            # a persistent launch timed out: the call again (one launch per op now), heads on request
+                forward()
+            else:
+                self._ctc_both = ((out.data_ptr(), Tp), {0: host[:3 * Tp + 1], 1: host[3 * Tp + 1:]})
+                self.stream_stats = (nf.value, nc.value)
+                self._last_enc = (out.data_ptr(), Tp)
+                return out
+        else:
+            forward()
+        self._ctc_both = None
         self.stream_stats = (nf.value, nc.value)
-        self._last_enc, self._ctc_stash = (out.data_ptr(), Tp), None
+        self._last_enc = (out.data_ptr(), Tp)
         return out
 
     # ---- a8 -------------------------------------------------------------------------------
@@ -311,6 +343,9 @@ class HipModel(BatchMixin):
         """-> (tokens list, frame index list, raw argmax tensor, logits or None)."""
         Tp = enc_out.shape[0]
         key = (enc_out.data_ptr(), Tp)
+        both = getattr(self, "_ctc_both", None)
+        if both is not None and not want_logits and both[0] == key and head in both[1]:
+            return self._ctc_unpack(both[1].pop(head), Tp)              # computed behind the streaming encoder call (handed out once)
         stash = getattr(self, "_ctc_stash", None)
         if stash is not None:
             self._ctc_stash = None

@@ -91,6 +91,8 @@ class OnlineFeatureExtractor:
         self._buf = np.zeros(0, np.float32)      # backing store of _np (grows by doubling: appending a segment does not copy the history)
         self._dev = None
         self._n_dev = 0
+        self._fb = None                          # fbank rows of the cached history (16-kHz sources on the HIP engine; see __call__)
+        self._n_fb = 0
         self._src_id = None
 
     def _samples(self, samples, n):
@@ -148,6 +150,7 @@ class OnlineFeatureExtractor:
                 buf[: self._n_dev] = self._dev[: self._n_dev]
             else:
                 self._n_dev = 0
+                self._n_fb = 0
             self._dev = buf
         if effective > self._n_dev:
             self._dev[self._n_dev:effective] = torch.from_numpy(x[self._n_dev:effective]).to(dev)
@@ -155,4 +158,22 @@ class OnlineFeatureExtractor:
         pcm = self._dev[:effective]
         if sr != SAMPLE_RATE:
             pcm = self.engine.resample(pcm, int(sr), SAMPLE_RATE)
-        return self.engine.fbank_cmvn(pcm, 32768.0)
+            return self.engine.fbank_cmvn(pcm, 32768.0)
+        if not hasattr(self.engine, "lib"):              # the CPU oracle engine: as the reference, everything every time
+            return self.engine.fbank_cmvn(pcm, 32768.0)
+        # A fbank row is a function of ITS 400 samples only (one workgroup per 25-ms frame, global CMVN): rows of the cached history stay
+        # as they are and only the new frames are computed, into a buffer that grows by doubling.  Same bits as the full call
+        # (tests/test_stages_gpu.py); the reference recomputes all frames per policy() call (agent :66-98).
+        nf = int(num_frames)
+        k = self._n_fb if self._fb is not None else 0
+        if k > nf:
+            k = 0
+        if self._fb is None or self._fb.shape[0] < nf:
+            fb = torch.empty((max(2 * nf, 512), self.feature_dim), dtype=torch.float32, device=dev)
+            if k:
+                fb[:k] = self._fb[:k]
+            self._fb = fb
+        if nf > k:
+            self.engine.fbank_cmvn(self._dev[k * self.num_samples_per_shift:effective], 32768.0, out=self._fb[k:nf])
+        self._n_fb = nf
+        return self._fb[:nf]

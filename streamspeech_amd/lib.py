@@ -52,6 +52,9 @@ SIGNATURES = {
     "ss_encoder_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "ss_encoder_stream_reset": (_i, [_vp]),
     "ss_encoder_stream_set_tail": (_i, [_vp, _i]),
+    "ss_encoder_stream_set_deferred": (_i, [_vp, _i]),
+    "ss_encoder_stream_status": (_i, [_vp, _vp, _vp]),
+    "ss_debug_enc_step_inject_timeout": (_i, [_vp]),
     "ss_encoder_stream_forward": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ss_ctc_greedy": (_i, [_vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "ss_mt_begin": (_i, [_vp, _vp, _vp, _i]),

@@ -99,3 +99,46 @@ def test_few_queries_attention_kernel_equals_the_tile_kernel_on_streaming_calls(
     full = model.encoder_forward(fb_all, ac, cc)
     assert (got[-1] - full).abs().max().item() < 5e-5
     assert lib.ss_debug_sk_errors() == 0
+
+
+def test_deferred_time_out_check_and_the_repeat_protocol(model):
+    """The agents' engine path: with ``ctc_speculate`` on a persistent context, encoder_stream_forward queues both CTC heads behind the
+    layers and synchronises once (ss_encoder_stream_set_deferred / ss_encoder_stream_status).  Same encoder rows and CTC answers as the
+    synchronous form; an injected time-out (ss_debug_enc_step_inject_timeout) makes the status call ask for a repeat, the repeated call
+    runs one launch per op, the failed call's rows are not final, and the outputs are still those of the reference run."""
+    from streamspeech_amd import synth
+    lib = model.lib
+    fb_all = torch.from_numpy(synth.synth_fbank(53, 700)).to(model.device)
+    Ts = list(range(40, 700, 32)) + [700]
+    model.set_persistent_mt_step(64)
+    model.ctc_speculate = False
+    ref, ref_final = _drive(model, fb_all, 8, 8, Ts)
+    ref_ctc = [(model.ctc_greedy(0, o)[0], model.ctc_greedy(1, o)[0]) for o in ref]
+    try:
+        model.ctc_speculate = True
+        model.encoder_stream_reset()
+        n0 = lib.ss_debug_enc_step_launches()
+        for i, T in enumerate(Ts):
+            if i == 7:
+                lib.ss_debug_enc_step_inject_timeout(model.h)
+            out = model.encoder_stream_forward(fb_all[:T].contiguous(), 8, 8)
+            assert model.stream_stats[0] == ref_final[i]
+            assert (out - ref[i]).abs().max().item() < 2e-5
+            if i != 7:
+                assert model._ctc_both is not None or i > 7 or out.shape[0] == 0
+            a0, a1 = model.ctc_greedy(0, out)[0], model.ctc_greedy(1, out)[0]
+            assert (a0, a1) == ref_ctc[i], i
+            if i == 6:
+                used = lib.ss_debug_enc_step_launches() - n0
+                assert used > 0                                          # the persistent form ran until the injected time-out
+            if i == 7:
+                used7 = lib.ss_debug_enc_step_launches()
+        assert lib.ss_debug_enc_step_launches() == used7                 # after it: one launch per op
+    finally:
+        model.ctc_speculate = False
+        model._ctc_both = None
+        model.set_persistent_mt_step(64)                                 # re-arms the persistent layer launches
+        model.encoder_stream_reset()
+    n1 = lib.ss_debug_enc_step_launches()
+    _drive(model, fb_all, 8, 8, Ts[:4])
+    assert lib.ss_debug_enc_step_launches() > n1

@@ -451,3 +451,30 @@ def test_both_ctc_heads_behind_one_round_trip_equal_the_separate_calls(hip_model
     finally:
         m.ctc_speculate = False
         m._ctc_stash = None
+
+
+def test_front_end_computes_only_the_new_fbank_rows_and_returns_the_same_bits(hip_model):
+    """OnlineFeatureExtractor on the HIP engine (16-kHz source): rows of the cached sample history are kept, only the new frames go
+    through the fbank kernel -- every call must return exactly what the full computation over all samples returns, for irregular
+    segment lengths, across the buffer's growth, after a new utterance (another list) and after a shrinking history."""
+    import types
+    from streamspeech_amd import synth
+    from streamspeech_amd.frontend import OnlineFeatureExtractor
+    args = types.SimpleNamespace(shift_size=10, window_size=25, sample_rate=16000, feature_dim=80, global_cmvn=None)
+    fe = OnlineFeatureExtractor(args, hip_model)
+    for seed, steps in ((71, [5120] * 9 + [333, 4000, 7777, 16000, 160, 159, 161]), (72, [2000, 9000, 5120, 5120])):
+        pcm = synth.synth_pcm(seed, sum(steps)).tolist()
+        hist, n = [], 0
+        for st in steps:
+            hist.extend(pcm[n:n + st])
+            n += st
+            got = fe(hist)
+            full = hip_model.fbank_cmvn(torch.tensor(hist[:], dtype=torch.float32, device=hip_model.device), 32768.0)
+            nf = full.shape[0]
+            assert got.shape[0] == nf or (nf <= 0 and got.shape[0] == 0)
+            if nf > 0:
+                assert torch.equal(got, full[:got.shape[0]]), (seed, n)
+    short = hist[:6000]                                # the same list object cut down: history shrank
+    del hist[6000:]
+    got = fe(hist)
+    assert torch.equal(got, hip_model.fbank_cmvn(torch.tensor(short, dtype=torch.float32, device=hip_model.device), 32768.0))
