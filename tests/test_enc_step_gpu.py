@@ -142,3 +142,4 @@ def test_deferred_time_out_check_and_the_repeat_protocol(model):
     n1 = lib.ss_debug_enc_step_launches()
     _drive(model, fb_all, 8, 8, Ts[:4])
     assert lib.ss_debug_enc_step_launches() > n1
+    assert lib.ss_debug_sk_errors() == 0                                 # the injected time-out is not a time-out of the process
