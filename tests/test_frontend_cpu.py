@@ -107,3 +107,34 @@ def test_offline_driver_on_cpu_doubles(tmp_path):
         got = subprocess.run(["bash", "-c", cmd], capture_output=True, text=True, check=True).stdout
         assert got == (tmp_path / f"generate-{sp}.{ext}").read_text(), ext
     assert (tmp_path / f"generate-{sp}.unit").read_text().splitlines() == [" ".join(str(u) for u in hyps[i]["units"]) for i in sorted(hyps)]
+
+
+def test_sample_history_cache_appends_without_copying_and_detects_another_source():
+    """OnlineFeatureExtractor._samples: the float32 view of SimulEval's growing sample list -- only the new tail is converted (array('d')
+    then a cast: the rounding of np.asarray(list, float32)), the backing store grows by doubling, earlier views stay valid, and another
+    list object, a shrunk history or changed contents start a fresh cache."""
+    import types
+    args = types.SimpleNamespace(shift_size=10, window_size=25, sample_rate=16000, feature_dim=80)
+    fe = frontend.OnlineFeatureExtractor(args, engine=None)
+    rng = np.random.default_rng(5)
+    hist, views = [], []
+    for step in (5120, 5120, 333, 70000, 5120, 1, 40000):
+        hist.extend((rng.standard_normal(step) * 0.3).tolist())
+        got = fe._samples(hist, len(hist))
+        assert got.dtype == np.float32 and np.array_equal(got, np.asarray(hist, dtype=np.float32))
+        views.append((got, len(hist)))
+    for v, n in views:                                   # views handed out earlier still show their samples
+        assert np.array_equal(v, np.asarray(hist[:n], dtype=np.float32))
+    buf_before = fe._buf
+    hist.extend([0.25] * 100)
+    fe._samples(hist, len(hist))
+    assert fe._buf is buf_before                         # room left: appended in place
+    other = list(hist)                                   # same contents, another list object (a new utterance's states.source)
+    other[10] = 0.5
+    assert np.array_equal(fe._samples(other, 3000), np.asarray(other[:3000], dtype=np.float32))
+    del other[2000:]                                     # the history shrank
+    assert np.array_equal(fe._samples(other, 2000), np.asarray(other, dtype=np.float32))
+    other.extend([0.125] * 50)
+    other[5] = -0.75                                     # contents changed under the cache: the spot check may or may not see index 5 ...
+    fe.clear_cache()                                     # ... which is why the agents clear the cache in reset()
+    assert np.array_equal(fe._samples(other, len(other)), np.asarray(other, dtype=np.float32))
